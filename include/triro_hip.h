@@ -1,0 +1,156 @@
+/*
+ * triro_hip.h -- C ABI of libtriro_hip.so: the MI355X (gfx950) ray / triangle-mesh
+ * intersection path behind triro.ray.ray_optix.RayMeshIntersector.
+ *
+ * This is the drop-in boundary.  Each entry point replaces one function of the reference's
+ * pybind11 module "triro" (triro/backend/binding.cpp:31-59); plain pointers and sizes only,
+ * no torch types.  All pointers named d_* are DEVICE pointers on the device the BVH was
+ * built on; every call enqueues work on `stream` (a hipStream_t passed as void*, NULL =
+ * the null stream) and returns without synchronising unless stated otherwise.  Outputs are
+ * allocated by the caller (the reference allocates them inside the extension with
+ * torch::empty, ray.cpp:239-259).
+ *
+ * Return value: 0 (TR_OK) or a tr_status code; tr_last_error() gives a thread-local
+ * message.  Nothing here ever calls exit() (the reference does: optix8.h:41-60).
+ */
+#ifndef TRIRO_HIP_H
+#define TRIRO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TR_ABI_VERSION 1
+#define TR_MAX_ANYHIT_SIZE 8 /* LaunchParams.h:8  (per-ray cap of intersects_location) */
+#define TR_MAX_SIZE_LENGTH 4 /* LaunchParams.h:9  (ray tensors have <= 4 dims)         */
+#define TR_MAX_HITS_CAP 32   /* largest `cap` tr_intersects_location_fill accepts      */
+
+typedef enum tr_status {
+    TR_OK = 0,
+    TR_ERR_INVALID_ARG = 1,
+    TR_ERR_HIP = 2,           /* a HIP runtime call failed; message has the hipError name */
+    TR_ERR_NO_DEVICE = 3,
+    TR_ERR_OUT_OF_MEMORY = 4,
+    TR_ERR_INTERNAL = 5
+} tr_status;
+
+/* Opaque acceleration structure (replaces OptixAccelStructureWrapperCPP, ray.h:11-16). */
+typedef struct tr_bvh tr_bvh;
+
+/*
+ * Ray batch = the reference's RayInput (LaunchParams.h:11-28) as filled by ray.cpp:151-159,
+ * 177-179: shape and strides RIGHT-ALIGNED in 4 slots; unused leading shape slots hold
+ * INT64_MAX, unused leading stride slots 0; strides in ELEMENTS (floats); the last dim is
+ * 3 (x,y,z, element stride = stride[3]).  origins and directions share `shape`
+ * (= origins.sizes()) and have independent strides (stride 0 = broadcast is legal).
+ * nray = product of the leading dims.
+ */
+typedef struct tr_rays {
+    const float *d_origins;
+    const float *d_directions;
+    int64_t nray;
+    int64_t shape[TR_MAX_SIZE_LENGTH];
+    int64_t ostride[TR_MAX_SIZE_LENGTH];
+    int64_t dstride[TR_MAX_SIZE_LENGTH];
+} tr_rays;
+
+typedef struct tr_bvh_info {
+    int32_t device;        /* HIP device ordinal the arena lives on                 */
+    int64_t num_tris;      /* F                                                       */
+    int64_t num_nodes;     /* internal nodes (F-1 for F >= 2, else 0)               */
+    int32_t depth;         /* height of the hierarchy in internal-node levels       */
+    int32_t key_mode;      /* 0: 63-bit Morton keys, 1: depth-bounded fallback keys */
+    int64_t arena_bytes;   /* bytes of device memory owned by the handle            */
+    int64_t node_bytes;    /* bytes of traversal nodes (64 B each)                  */
+    int64_t tri_bytes;     /* bytes of leaf triangle records (48 B each)            */
+    float aabb_min[3];     /* mesh bounds                                            */
+    float aabb_max[3];
+} tr_bvh_info;
+
+/* Per-launch traversal statistics (diagnostic build of the kernels; tr_trace_stats). */
+typedef struct tr_trace_stats {
+    uint64_t rays;
+    uint64_t node_visits;   /* internal nodes fetched (64 B each)   */
+    uint64_t tri_tests;     /* leaf triangles fetched (48 B each)   */
+    uint64_t climb_steps;   /* parent-link loads while backtracking */
+} tr_trace_stats;
+
+/* -- runtime bring-up: replaces initOptix/createOptixContext/createOptixModule/
+ *    createOptixPipelines/buildSBT (base.cpp:31-157, binding.cpp:41-48).  Idempotent,
+ *    thread-safe; device < 0 selects the current HIP device.                             */
+int tr_init(int device);
+int tr_abi_version(void);
+const char *tr_last_error(void);
+
+/* -- acceleration structure: replaces buildAccelStructure / freeAccelStructure
+ *    (ray.cpp:27-102, binding.cpp:35-38).  d_vertices: [nv,3] float32 dense, d_faces:
+ *    [nf,3] int32 dense.  The handle keeps its own copy of the triangle data (as the GAS
+ *    does with ALLOW_RANDOM_VERTEX_ACCESS, ray.cpp:37), so the inputs may be freed after
+ *    the call returns.  Synchronises `stream` once (tree height read-back).              */
+int tr_bvh_build(const float *d_vertices, int64_t nv, const int32_t *d_faces, int64_t nf,
+                 void *stream, tr_bvh **out);
+/*    rebuild in place for RayMeshIntersector.update_raw (ray_optix.py:55-69)             */
+int tr_bvh_update(tr_bvh *bvh, const float *d_vertices, int64_t nv, const int32_t *d_faces,
+                  int64_t nf, void *stream);
+int tr_bvh_destroy(tr_bvh *bvh);
+int tr_bvh_get_info(const tr_bvh *bvh, tr_bvh_info *info);
+/*    test hook: copy the traversal arrays to HOST buffers (any may be NULL).
+ *    nodes: num_nodes*16 words (64 B), links: num_nodes*2 int32, tris: num_tris*12 words. */
+int tr_bvh_download(const tr_bvh *bvh, void *h_nodes, void *h_links, void *h_tris,
+                    void *stream);
+
+/* -- queries: replace intersectsAny/First/Closest/Count/Location (ray.cpp:161-378,
+ *    binding.cpp:49-58).  Output element i belongs to flat ray index i.
+ *    any     : hit[i] = 1/0                                   (shaders.cu:67-89)
+ *    first   : tri[i] = closest triangle or -1                (shaders.cu:93-116)
+ *    closest : hit, front (uint8 0/1), tri (int32, -1 on miss), loc [n,3], uv [n,2];
+ *              miss values 0                                  (shaders.cu:120-172)
+ *    count   : number of triangles hit in [0, 1e7], uncapped  (shaders.cu:176-194)      */
+int tr_intersects_any(const tr_bvh *bvh, const tr_rays *rays, uint8_t *d_hit, void *stream);
+int tr_intersects_first(const tr_bvh *bvh, const tr_rays *rays, int32_t *d_tri, void *stream);
+int tr_intersects_closest(const tr_bvh *bvh, const tr_rays *rays, uint8_t *d_hit,
+                          uint8_t *d_front, int32_t *d_tri, float *d_loc, float *d_uv,
+                          void *stream);
+int tr_intersects_count(const tr_bvh *bvh, const tr_rays *rays, int32_t *d_count, void *stream);
+
+/* -- multi-hit (intersectsLocation, ray.cpp:324-378):
+ *    tr_hits_scan replaces the torch glue of ray.cpp:333-342: d_offsets[i] = exclusive
+ *    prefix sum of min(d_count[i], cap); the grand total is written to *d_total (device)
+ *    and, if h_total != NULL, copied to the host after synchronising `stream` (the
+ *    reference's .item<int>(), ray.cpp:339).  d_offsets has n elements (int64).
+ *    tr_intersects_location_fill is the second pass (shaders.cu:196-246): for ray i it
+ *    writes its min(count,cap) nearest hits, ordered by (distance, triangle index), at
+ *    rows d_offsets[i].. of loc [h,3], ray_idx [h] (= i + ray_base), tri_idx [h].        */
+int tr_hits_scan(const int32_t *d_count, int64_t n, int32_t cap, int64_t *d_offsets,
+                 int64_t *d_total, int64_t *h_total, void *stream);
+int tr_intersects_location_fill(const tr_bvh *bvh, const tr_rays *rays, int32_t cap,
+                                const int64_t *d_offsets, float *d_loc, int32_t *d_ray_idx,
+                                int32_t *d_tri_idx, int64_t ray_base, void *stream);
+
+/* -- stream compaction of closest-hit results (ray_optix.py:142-144, 219-223): keeps the
+ *    rows with hit != 0, in ray order.  d_offsets (n int64) = exclusive scan of hit, from
+ *    tr_mask_scan (same total/h_total convention as tr_hits_scan).  Any output may be NULL. */
+int tr_mask_scan(const uint8_t *d_hit, int64_t n, int64_t *d_offsets, int64_t *d_total,
+                 int64_t *h_total, void *stream);
+int tr_compact_closest(const uint8_t *d_hit, const int64_t *d_offsets, int64_t n,
+                       const uint8_t *d_front, const int32_t *d_tri, const float *d_loc,
+                       const float *d_uv, int64_t ray_base, uint8_t *d_front_out,
+                       int32_t *d_ray_idx_out, int32_t *d_tri_out, float *d_loc_out,
+                       float *d_uv_out, void *stream);
+
+/* -- diagnostics: run closest-hit with the instrumented kernel and return counters
+ *    (synchronises).  Not on the hot path.                                               */
+int tr_trace_stats_closest(const tr_bvh *bvh, const tr_rays *rays, tr_trace_stats *h_stats,
+                           void *stream);
+
+/* -- tuning knob (process-wide): kernel variant for the query launchers.
+ *    name = "persistent" (0/1), "blocks_per_cu" (int).  Returns TR_ERR_INVALID_ARG for
+ *    unknown names.                                                                      */
+int tr_set_option(const char *name, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRIRO_HIP_H */

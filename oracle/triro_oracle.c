@@ -1,0 +1,555 @@
+/*
+ * triro_oracle.c -- CPU ORACLE for the ray/triangle-mesh intersection path.
+ *
+ * THIS FILE IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, the
+ * smoke() entry point and bench.py's cpu_baseline leg may load it.  The
+ * shipped library (libtriro_hip.so) never links, loads or calls it.
+ *
+ * PARITY STATUS: *parity unpinned* against the real reference.  The reference
+ * (lcp29/trimesh-ray-optix, "triro" 1.3.1) performs BVH build, traversal and
+ * the ray/triangle test inside NVIDIA OptiX (closed source, pinned only as
+ * ">= 7.7", README.md:8) on RTX hardware; it cannot be compiled, imported or
+ * run here, and its own tests (test/test.py) hold no assertions or golden
+ * vectors.  What this file restates is everything the repository itself
+ * defines around optixTrace:
+ *
+ *   - strided ray fetch          triro/backend/shaders.cu:27-63  (getRay/getIndices)
+ *   - ray interval tmin=0,tmax=1e7, no culling   shaders.cu:86,112,163,191,238
+ *   - intersects_any   -> bool                    shaders.cu:67-89
+ *   - intersects_first -> tri index or -1         shaders.cu:93-116
+ *   - intersects_closest -> hit, front, tri, loc, uv; miss values
+ *                                                  shaders.cu:120-172
+ *       loc = u*V1 + v*V2 + (1-u-v)*V0            shaders.cu:143-146
+ *       uv  = (1-u-v, u)                          shaders.cu:149
+ *   - intersects_count -> every triangle once      shaders.cu:176-194, ray.cpp:60-62
+ *   - intersects_location: clamp counts to 8, exclusive scan, fill
+ *                                                  ray.cpp:324-378, shaders.cu:196-246,
+ *                                                  LaunchParams.h:8
+ *
+ * and anchors it on the hand-derived known answers for the inputs of
+ * test/test.py and README.md (tests/golden/known_answers.json).
+ *
+ * The ray/triangle arithmetic itself (closed source in the reference) is the
+ * published Moller-Trumbore test, fixed here as an ARITHMETIC CONTRACT that the
+ * HIP kernels follow operation by operation so that integer outputs are
+ * bit-exact.  The contract (also in DESIGN.md, "Arithmetic contract"):
+ *
+ *   ray:   valid iff all six of o,d are finite (else the ray misses everything)
+ *          inv_i = 1/d_i (IEEE); if |inv_i| > 3.0e38 -> copysign(3.0e38, d_i)
+ *   box of a triangle: l = min(min(a_i,b_i),c_i), h = max(...);  pad(x) = |x|*2^-21 + 2^-100
+ *          lo_i = l - pad(l), hi_i = h + pad(h)   (so that a ray lying exactly in a bounding
+ *          plane with d_i = 0 is inside the slab on both sides: 2^-100 * 3e38 > TMAX)
+ *   slab:  t1 = (lo_i-o_i)*inv_i, t2 = (hi_i-o_i)*inv_i  (sub, then mul)
+ *          tn = max_i min(t1,t2); tf = (min_i max(t1,t2)) * (1+2^-22)
+ *          box is hit iff tn <= tf && tf >= 0 && tn <= TMAX
+ *   MT:    e1=b-a, e2=c-a, p=cross(d,e2), det=dot(e1,p); det==0 -> miss
+ *          s=o-a, U=dot(s,p), q=cross(s,e1), V=dot(d,q), T=dot(e2,q)
+ *          cross(x,y).x = fma(x.y, y.z, -(x.z*y.y)) (cyclic)
+ *          dot(x,y)     = fma(x.z, y.z, fma(x.y, y.y, x.x*y.x))
+ *          det>0: U>=0 && V>=0 && U+V<=det ; det<0: U<=0 && V<=0 && U+V>=det
+ *          t = T/det (IEEE division)
+ *   key:   t_key = min(max(t, tn), tf)   (the MT distance clamped into the
+ *          triangle's own slab interval); accepted iff 0 <= t_key <= 1e7
+ *   closest = lexicographic minimum of (t_key, tri_idx) over accepted triangles
+ *   front  = det > 0  (counter-clockwise seen from the ray origin)
+ *   u=U/det, v=V/det, w=(1-u)-v, loc_i = fma(w,a_i, fma(v,c_i, u*b_i)), uv=(w,u)
+ *   multi-hit: the (up to) 8 accepted hits with smallest (t_key, tri_idx),
+ *          ascending; the reference keeps "the first 8 in traversal order",
+ *          which is unspecified (shaders.cu:209-212).
+ *
+ * Because the predicate is a pure function of (ray, triangle) and every BVH
+ * box is a superset of its triangles' boxes, any conservative BVH returns
+ * exactly what the brute-force loop returns (slab is monotone under box
+ * inclusion, and t_key >= tn of every enclosing box).  Both are here:
+ * mode 0 = brute force (ground truth), mode 1 = median-split BVH (fast; used
+ * for the CPU baseline and for parity at sizes brute force cannot reach).
+ *
+ * Build:  see oracle/Makefile (gcc -O2 -ffp-contract=off -mfma -fopenmp).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define TR_TMAX 1.0e7f
+#define TR_HUGE 3.0e38f
+#define TR_SLAB_PAD 1.00000023841857910156f /* 1 + 2^-22 */
+#define TR_MAX_HITS_CAP 64
+#define TR_PAD_REL 4.76837158203125e-07f  /* 2^-21  */
+#define TR_PAD_ABS 7.888609052210118e-31f /* 2^-100 */
+
+typedef struct {
+    float o[3], d[3], inv[3];
+    int valid;
+} ray_t;
+
+typedef struct {
+    float lo[3], hi[3];
+    int32_t left;  /* internal: index of left child; leaf: first prim slot */
+    int32_t right; /* internal: index of right child; leaf: -(count)       */
+} onode_t;
+
+typedef struct {
+    int64_t nv, nf;
+    float *verts;   /* nv*3 */
+    int32_t *faces; /* nf*3 */
+    /* median-split BVH */
+    onode_t *nodes;
+    int32_t nnodes;
+    int32_t *prim; /* permutation of triangle ids */
+} omesh_t;
+
+static inline float minf_(float a, float b) { return a < b ? a : b; }
+static inline float maxf_(float a, float b) { return a > b ? a : b; }
+
+static inline float dot3(const float *x, const float *y) {
+    return fmaf(x[2], y[2], fmaf(x[1], y[1], x[0] * y[0]));
+}
+static inline void cross3(const float *x, const float *y, float *r) {
+    r[0] = fmaf(x[1], y[2], -(x[2] * y[1]));
+    r[1] = fmaf(x[2], y[0], -(x[0] * y[2]));
+    r[2] = fmaf(x[0], y[1], -(x[1] * y[0]));
+}
+
+static void ray_setup(ray_t *r, const float *o, const float *d) {
+    int ok = 1;
+    for (int i = 0; i < 3; i++) {
+        r->o[i] = o[i];
+        r->d[i] = d[i];
+        if (!isfinite(o[i]) || !isfinite(d[i])) ok = 0;
+        float inv = 1.0f / d[i];
+        if (fabsf(inv) > TR_HUGE) inv = copysignf(TR_HUGE, d[i]);
+        r->inv[i] = inv;
+    }
+    r->valid = ok;
+}
+
+/* slab test; returns 1 if the (padded) interval is non-empty and overlaps [0,TMAX] */
+static inline int slab(const ray_t *r, const float *lo, const float *hi, float *tn_out,
+                       float *tf_out) {
+    float tn = -INFINITY, tf = INFINITY;
+    for (int i = 0; i < 3; i++) {
+        float t1 = (lo[i] - r->o[i]) * r->inv[i];
+        float t2 = (hi[i] - r->o[i]) * r->inv[i];
+        tn = maxf_(tn, minf_(t1, t2));
+        tf = minf_(tf, maxf_(t1, t2));
+    }
+    tf = tf * TR_SLAB_PAD;
+    *tn_out = tn;
+    *tf_out = tf;
+    return (tn <= tf) && (tf >= 0.0f) && (tn <= TR_TMAX);
+}
+
+typedef struct {
+    float t, U, V, det;
+} hit_t;
+
+/* box of a triangle, padded outward by |x|*2^-21 + 2^-100 per bound (see contract) */
+static inline float pad_(float x) { return fabsf(x) * TR_PAD_REL + TR_PAD_ABS; }
+static inline void tri_box_padded(const float *a, const float *b, const float *c, float *lo,
+                                  float *hi) {
+    for (int i = 0; i < 3; i++) {
+        float l = minf_(minf_(a[i], b[i]), c[i]);
+        float h = maxf_(maxf_(a[i], b[i]), c[i]);
+        lo[i] = l - pad_(l);
+        hi[i] = h + pad_(h);
+    }
+}
+
+/* the hit predicate: pure function of (ray, triangle) */
+static inline int tri_hit(const ray_t *r, const float *a, const float *b, const float *c,
+                          hit_t *h) {
+    float lo[3], hi[3], tn, tf;
+    tri_box_padded(a, b, c, lo, hi);
+    if (!slab(r, lo, hi, &tn, &tf)) return 0;
+    float e1[3], e2[3], s[3], p[3], q[3];
+    for (int i = 0; i < 3; i++) {
+        e1[i] = b[i] - a[i];
+        e2[i] = c[i] - a[i];
+        s[i] = r->o[i] - a[i];
+    }
+    cross3(r->d, e2, p);
+    float det = dot3(e1, p);
+    if (det == 0.0f) return 0;
+    float U = dot3(s, p);
+    cross3(s, e1, q);
+    float V = dot3(r->d, q);
+    if (det > 0.0f) {
+        if (!(U >= 0.0f && V >= 0.0f && (U + V) <= det)) return 0;
+    } else {
+        if (!(U <= 0.0f && V <= 0.0f && (U + V) >= det)) return 0;
+    }
+    float T = dot3(e2, q);
+    float t = T / det;
+    float tk = minf_(maxf_(t, tn), tf);
+    if (!(tk >= 0.0f && tk <= TR_TMAX)) return 0;
+    h->t = tk;
+    h->U = U;
+    h->V = V;
+    h->det = det;
+    return 1;
+}
+
+static inline void tri_verts(const omesh_t *m, int32_t f, const float **a, const float **b,
+                             const float **c) {
+    const int32_t *idx = m->faces + 3 * (int64_t)f;
+    *a = m->verts + 3 * (int64_t)idx[0];
+    *b = m->verts + 3 * (int64_t)idx[1];
+    *c = m->verts + 3 * (int64_t)idx[2];
+}
+
+/* ------------------------------------------------------------------ */
+/* median-split BVH (deliberately NOT the LBVH the GPU library builds) */
+/* ------------------------------------------------------------------ */
+typedef struct {
+    float c[3];
+    int32_t id;
+} cent_t;
+
+static int g_axis;
+static int cmp_cent(const void *x, const void *y) {
+    float a = ((const cent_t *)x)->c[g_axis], b = ((const cent_t *)y)->c[g_axis];
+    if (a < b) return -1;
+    if (a > b) return 1;
+    int32_t ia = ((const cent_t *)x)->id, ib = ((const cent_t *)y)->id;
+    return (ia > ib) - (ia < ib);
+}
+
+static void tri_box(const omesh_t *m, int32_t f, float *lo, float *hi) {
+    const float *a, *b, *c;
+    tri_verts(m, f, &a, &b, &c);
+    tri_box_padded(a, b, c, lo, hi);
+}
+
+static int32_t build_rec(omesh_t *m, cent_t *cents, int32_t first, int32_t count) {
+    int32_t me = m->nnodes++;
+    onode_t *n = &m->nodes[me];
+    float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = 0; i < 3; i++) {
+        n->lo[i] = INFINITY;
+        n->hi[i] = -INFINITY;
+    }
+    for (int32_t k = first; k < first + count; k++) {
+        float lo[3], hi[3];
+        tri_box(m, cents[k].id, lo, hi);
+        for (int i = 0; i < 3; i++) {
+            n->lo[i] = minf_(n->lo[i], lo[i]);
+            n->hi[i] = maxf_(n->hi[i], hi[i]);
+            clo[i] = minf_(clo[i], cents[k].c[i]);
+            chi[i] = maxf_(chi[i], cents[k].c[i]);
+        }
+    }
+    if (count <= 4) {
+        n->left = first;
+        n->right = -count;
+        return me;
+    }
+    int axis = 0;
+    float ext = chi[0] - clo[0];
+    for (int i = 1; i < 3; i++)
+        if (chi[i] - clo[i] > ext) {
+            ext = chi[i] - clo[i];
+            axis = i;
+        }
+    g_axis = axis;
+    qsort(cents + first, (size_t)count, sizeof(cent_t), cmp_cent);
+    int32_t half = count / 2;
+    int32_t l = build_rec(m, cents, first, half);
+    int32_t rr = build_rec(m, cents, first + half, count - half);
+    /* m->nodes is preallocated, so n is still valid */
+    m->nodes[me].left = l;
+    m->nodes[me].right = rr;
+    return me;
+}
+
+void *oracle_mesh_create(const float *verts, int64_t nv, const int32_t *faces, int64_t nf) {
+    omesh_t *m = (omesh_t *)calloc(1, sizeof(omesh_t));
+    m->nv = nv;
+    m->nf = nf;
+    m->verts = (float *)malloc(sizeof(float) * 3 * (size_t)(nv > 0 ? nv : 1));
+    m->faces = (int32_t *)malloc(sizeof(int32_t) * 3 * (size_t)(nf > 0 ? nf : 1));
+    memcpy(m->verts, verts, sizeof(float) * 3 * (size_t)nv);
+    memcpy(m->faces, faces, sizeof(int32_t) * 3 * (size_t)nf);
+    if (nf > 0) {
+        m->nodes = (onode_t *)malloc(sizeof(onode_t) * (size_t)(2 * nf));
+        m->prim = (int32_t *)malloc(sizeof(int32_t) * (size_t)nf);
+        cent_t *cents = (cent_t *)malloc(sizeof(cent_t) * (size_t)nf);
+        for (int64_t f = 0; f < nf; f++) {
+            float lo[3], hi[3];
+            tri_box(m, (int32_t)f, lo, hi);
+            for (int i = 0; i < 3; i++) cents[f].c[i] = 0.5f * lo[i] + 0.5f * hi[i];
+            cents[f].id = (int32_t)f;
+        }
+        build_rec(m, cents, 0, (int32_t)nf);
+        for (int64_t f = 0; f < nf; f++) m->prim[f] = cents[f].id;
+        free(cents);
+    }
+    return m;
+}
+
+void oracle_mesh_destroy(void *h) {
+    omesh_t *m = (omesh_t *)h;
+    if (!m) return;
+    free(m->verts);
+    free(m->faces);
+    free(m->nodes);
+    free(m->prim);
+    free(m);
+}
+
+/* ------------------------------------------------------------------ */
+/* per-ray visitors                                                     */
+/* ------------------------------------------------------------------ */
+typedef struct {
+    int found;
+    float t;
+    int32_t tri;
+    float U, V, det;
+} best_t;
+
+static inline void consider(best_t *b, const hit_t *h, int32_t f) {
+    if (!b->found || h->t < b->t || (h->t == b->t && f < b->tri)) {
+        b->found = 1;
+        b->t = h->t;
+        b->tri = f;
+        b->U = h->U;
+        b->V = h->V;
+        b->det = h->det;
+    }
+}
+
+typedef struct {
+    int32_t n;   /* entries kept (<= cap)   */
+    int32_t cap; /* <= TR_MAX_HITS_CAP       */
+    int64_t total;
+    float t[TR_MAX_HITS_CAP];
+    int32_t tri[TR_MAX_HITS_CAP];
+    float U[TR_MAX_HITS_CAP], V[TR_MAX_HITS_CAP], det[TR_MAX_HITS_CAP];
+} hitlist_t;
+
+static inline void hl_insert(hitlist_t *l, const hit_t *h, int32_t f) {
+    l->total++;
+    if (l->cap == 0) return;
+    int32_t pos = l->n;
+    if (l->n == l->cap) {
+        int32_t last = l->n - 1;
+        if (!(h->t < l->t[last] || (h->t == l->t[last] && f < l->tri[last]))) return;
+        pos = last;
+    } else {
+        l->n++;
+    }
+    while (pos > 0 &&
+           (h->t < l->t[pos - 1] || (h->t == l->t[pos - 1] && f < l->tri[pos - 1]))) {
+        l->t[pos] = l->t[pos - 1];
+        l->tri[pos] = l->tri[pos - 1];
+        l->U[pos] = l->U[pos - 1];
+        l->V[pos] = l->V[pos - 1];
+        l->det[pos] = l->det[pos - 1];
+        pos--;
+    }
+    l->t[pos] = h->t;
+    l->tri[pos] = f;
+    l->U[pos] = h->U;
+    l->V[pos] = h->V;
+    l->det[pos] = h->det;
+}
+
+/* closest hit */
+static void closest_ray(const omesh_t *m, const ray_t *r, int mode, best_t *best) {
+    best->found = 0;
+    best->t = INFINITY;
+    best->tri = -1;
+    if (!r->valid || m->nf == 0) return;
+    hit_t h;
+    const float *a, *b, *c;
+    if (mode == 0) {
+        for (int64_t f = 0; f < m->nf; f++) {
+            tri_verts(m, (int32_t)f, &a, &b, &c);
+            if (tri_hit(r, a, b, c, &h)) consider(best, &h, (int32_t)f);
+        }
+        return;
+    }
+    int32_t stack[128];
+    int sp = 0;
+    stack[sp++] = 0;
+    while (sp > 0) {
+        const onode_t *n = &m->nodes[stack[--sp]];
+        float tn, tf;
+        if (!slab(r, n->lo, n->hi, &tn, &tf)) continue;
+        if (best->found && tn > best->t) continue;
+        if (n->right < 0) {
+            for (int32_t k = 0; k < -n->right; k++) {
+                int32_t f = m->prim[n->left + k];
+                tri_verts(m, f, &a, &b, &c);
+                if (tri_hit(r, a, b, c, &h)) consider(best, &h, f);
+            }
+        } else {
+            stack[sp++] = n->left;
+            stack[sp++] = n->right;
+        }
+    }
+}
+
+/* all hits: count (uncapped) and the cap nearest */
+static void allhits_ray(const omesh_t *m, const ray_t *r, int mode, hitlist_t *l) {
+    l->n = 0;
+    l->total = 0;
+    if (!r->valid || m->nf == 0) return;
+    hit_t h;
+    const float *a, *b, *c;
+    if (mode == 0) {
+        for (int64_t f = 0; f < m->nf; f++) {
+            tri_verts(m, (int32_t)f, &a, &b, &c);
+            if (tri_hit(r, a, b, c, &h)) hl_insert(l, &h, (int32_t)f);
+        }
+        return;
+    }
+    int32_t stack[128];
+    int sp = 0;
+    stack[sp++] = 0;
+    while (sp > 0) {
+        const onode_t *n = &m->nodes[stack[--sp]];
+        float tn, tf;
+        if (!slab(r, n->lo, n->hi, &tn, &tf)) continue;
+        if (n->right < 0) {
+            for (int32_t k = 0; k < -n->right; k++) {
+                int32_t f = m->prim[n->left + k];
+                tri_verts(m, f, &a, &b, &c);
+                if (tri_hit(r, a, b, c, &h)) hl_insert(l, &h, f);
+            }
+        } else {
+            stack[sp++] = n->left;
+            stack[sp++] = n->right;
+        }
+    }
+}
+
+static inline void hit_outputs(const omesh_t *m, int32_t f, float U, float V, float det,
+                               float *loc, float *uv, uint8_t *front) {
+    const float *a, *b, *c;
+    tri_verts(m, f, &a, &b, &c);
+    float u = U / det, v = V / det;
+    float w = (1.0f - u) - v;
+    if (loc)
+        for (int i = 0; i < 3; i++) loc[i] = fmaf(w, a[i], fmaf(v, c[i], u * b[i]));
+    if (uv) {
+        uv[0] = w;
+        uv[1] = u;
+    }
+    if (front) *front = det > 0.0f;
+}
+
+static void set_threads(int nthreads) {
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+    (void)nthreads;
+#endif
+}
+
+/* intersects_closest: shaders.cu:120-172; outputs may be NULL.  t is an extra
+ * diagnostic output (the reference does not return it). */
+int oracle_closest(const void *mesh, const float *o, const float *d, int64_t n, int mode,
+                   int nthreads, uint8_t *hit, uint8_t *front, int32_t *tri, float *loc,
+                   float *uv, float *t) {
+    const omesh_t *m = (const omesh_t *)mesh;
+    set_threads(nthreads);
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t i = 0; i < n; i++) {
+        ray_t r;
+        best_t b;
+        ray_setup(&r, o + 3 * i, d + 3 * i);
+        closest_ray(m, &r, mode, &b);
+        float l3[3] = {0, 0, 0}, uv2[2] = {0, 0};
+        uint8_t fr = 0;
+        if (b.found) hit_outputs(m, b.tri, b.U, b.V, b.det, l3, uv2, &fr);
+        if (hit) hit[i] = (uint8_t)b.found;
+        if (front) front[i] = fr;
+        if (tri) tri[i] = b.found ? b.tri : -1;
+        if (loc) memcpy(loc + 3 * i, l3, sizeof l3);
+        if (uv) memcpy(uv + 2 * i, uv2, sizeof uv2);
+        if (t) t[i] = b.found ? b.t : INFINITY;
+    }
+    return 0;
+}
+
+/* intersects_count (shaders.cu:176-194) and intersects_any (:67-89): counts are
+ * uncapped; any = count > 0 (the reference's anyhit does not terminate the ray) */
+int oracle_count(const void *mesh, const float *o, const float *d, int64_t n, int mode,
+                 int nthreads, int32_t *count) {
+    const omesh_t *m = (const omesh_t *)mesh;
+    set_threads(nthreads);
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t i = 0; i < n; i++) {
+        ray_t r;
+        hitlist_t l;
+        l.cap = 0;
+        ray_setup(&r, o + 3 * i, d + 3 * i);
+        allhits_ray(m, &r, mode, &l);
+        count[i] = (int32_t)l.total;
+    }
+    return 0;
+}
+
+/* intersects_location second pass (ray.cpp:344-378, shaders.cu:207-246): for ray
+ * i write min(count,cap) hits at offsets[i]..; hits ordered by (t_key, tri). */
+int oracle_location_fill(const void *mesh, const float *o, const float *d, int64_t n,
+                         int mode, int nthreads, int32_t cap, const int64_t *offsets,
+                         float *loc, int32_t *ray_idx, int32_t *tri_idx, float *t_out) {
+    const omesh_t *m = (const omesh_t *)mesh;
+    if (cap > TR_MAX_HITS_CAP) return -1;
+    set_threads(nthreads);
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t i = 0; i < n; i++) {
+        ray_t r;
+        hitlist_t l;
+        l.cap = cap;
+        ray_setup(&r, o + 3 * i, d + 3 * i);
+        allhits_ray(m, &r, mode, &l);
+        for (int32_t k = 0; k < l.n; k++) {
+            int64_t g = offsets[i] + k;
+            hit_outputs(m, l.tri[k], l.U[k], l.V[k], l.det[k], loc + 3 * g, NULL, NULL);
+            ray_idx[g] = (int32_t)i;
+            tri_idx[g] = l.tri[k];
+            if (t_out) t_out[g] = l.t[k];
+        }
+    }
+    return 0;
+}
+
+/* Strided ray fetch: shaders.cu:27-63 (getIndices + getRay) with the launch-param
+ * marshaling of ray.cpp:151-159,177-179: shape/strides right-aligned in 4 slots,
+ * shape padded with INT64_MAX, strides padded with 0, strides in elements.
+ * Unlike the reference (int arithmetic, shaders.cu:37) the index math is 64-bit. */
+int oracle_fetch_rays(const float *obase, const float *dbase, const int64_t shape[4],
+                      const int64_t ostride[4], const int64_t dstride[4], int64_t n,
+                      float *o_out, float *d_out) {
+    for (int64_t idx = 0; idx < n; idx++) {
+        int64_t fi = idx * 3, ind[4];
+        for (int i = 3; i >= 0; i--) {
+            ind[i] = fi % shape[i];
+            fi /= shape[i];
+        }
+        int64_t oi = 0, di = 0;
+        for (int i = 0; i < 4; i++) {
+            oi += ind[i] * ostride[i];
+            di += ind[i] * dstride[i];
+        }
+        for (int k = 0; k < 3; k++) {
+            o_out[3 * idx + k] = obase[oi + k * ostride[3]];
+            d_out[3 * idx + k] = dbase[di + k * dstride[3]];
+        }
+    }
+    return 0;
+}
+
+int oracle_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,210 @@
+// host_sim.cpp -- TEST-ONLY: compiles the product's host+device headers (tr_math.h, tr_lbvh.h,
+// tr_bvh.h) with g++ and runs the per-lane logic in a plain loop, so the LBVH construction
+// rules (Morton keys, Karras nodes, depth-bounded fallback keys) and the stackless
+// trail/parent-link traversal can be checked against the oracle on a machine without a GPU.
+// It is not reachable from libtriro_hip.so and is not a CPU fallback.
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+#include "../../trimesh-ray-optix_amd/csrc/tr_bvh.h"
+#include "../../trimesh-ray-optix_amd/csrc/tr_lbvh.h"
+
+struct SimBvh {
+    std::vector<tr_node> nodes;
+    std::vector<tr_link> links;
+    std::vector<tr_tri> tris;
+    int depth = 0;
+    int key_mode = 0;
+};
+
+template <int MODE>
+static int build_hierarchy(SimBvh& b, const std::vector<uint64_t>& keys, const std::vector<float>& sbox) {
+    const int64_t n = (int64_t)keys.size(), ni = n - 1;
+    std::vector<int32_t> cl(ni), cr(ni), par(ni, -1);
+    for (int64_t i = 0; i < ni; i++) {
+        tr_karras_node<MODE>(keys.data(), n, i, &cl[i], &cr[i]);
+    }
+    for (int64_t i = 0; i < ni; i++) {
+        if (cl[i] >= 0) par[cl[i]] = (int32_t)i;
+        if (cr[i] >= 0) par[cr[i]] = (int32_t)i;
+    }
+    par[0] = -1;
+    // level-synchronous refit, as the GPU builder does it
+    std::vector<float> ibox(6 * ni);
+    std::vector<int32_t> ready(ni, 0);
+    int round = 0;
+    while (ready[0] == 0 && round < 200) {
+        ++round;
+        for (int64_t i = 0; i < ni; i++) {
+            if (ready[i]) continue;
+            if (cl[i] >= 0 && (ready[cl[i]] == 0 || ready[cl[i]] >= round)) continue;
+            if (cr[i] >= 0 && (ready[cr[i]] == 0 || ready[cr[i]] >= round)) continue;
+            const float* a = cl[i] < 0 ? &sbox[6 * (int64_t)(~cl[i])] : &ibox[6 * (int64_t)cl[i]];
+            const float* c = cr[i] < 0 ? &sbox[6 * (int64_t)(~cr[i])] : &ibox[6 * (int64_t)cr[i]];
+            for (int k = 0; k < 3; k++) {
+                ibox[6 * i + k] = fminf(a[k], c[k]);
+                ibox[6 * i + 3 + k] = fmaxf(a[3 + k], c[3 + k]);
+            }
+            ready[i] = round;
+        }
+    }
+    if (ready[0] == 0) return -1;
+    b.nodes.resize(ni);
+    b.links.resize(ni);
+    for (int64_t i = 0; i < ni; i++) {
+        const float* a = cl[i] < 0 ? &sbox[6 * (int64_t)(~cl[i])] : &ibox[6 * (int64_t)cl[i]];
+        const float* c = cr[i] < 0 ? &sbox[6 * (int64_t)(~cr[i])] : &ibox[6 * (int64_t)cr[i]];
+        tr_node nd;
+        for (int k = 0; k < 3; k++) {
+            nd.lo0[k] = a[k]; nd.hi0[k] = a[3 + k];
+            nd.lo1[k] = c[k]; nd.hi1[k] = c[3 + k];
+        }
+        nd.c0 = cl[i]; nd.c1 = cr[i];
+        int32_t p = par[i], sib = 0;
+        if (p >= 0) sib = (cl[p] == (int32_t)i) ? cr[p] : cl[p];
+        nd.parent = p; nd.sibling = sib;
+        b.nodes[i] = nd;
+        b.links[i].parent = p; b.links[i].sibling = sib;
+    }
+    return round;
+}
+
+extern "C" {
+
+// force_mode: -1 = as the GPU builder decides (mode 0, fallback to 1 if height > 64), 0/1 force
+// morton_shift: drop this many low Morton bits (test hook to create long runs of equal keys)
+void* sim_build(const float* verts, int64_t nv, const int32_t* faces, int64_t nf, int force_mode,
+                int morton_shift) {
+    (void)nv;
+    SimBvh* b = new SimBvh();
+    if (nf <= 0) return b;
+    std::vector<float> tribox(6 * nf);
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t f = 0; f < nf; f++) {
+        const float* a = verts + 3 * (int64_t)faces[3 * f];
+        const float* bb = verts + 3 * (int64_t)faces[3 * f + 1];
+        const float* c = verts + 3 * (int64_t)faces[3 * f + 2];
+        tr_tri_box(a[0], a[1], a[2], bb[0], bb[1], bb[2], c[0], c[1], c[2], &tribox[6 * f], &tribox[6 * f + 3]);
+        for (int k = 0; k < 3; k++) {
+            mn[k] = fminf(mn[k], tribox[6 * f + k]);
+            mx[k] = fmaxf(mx[k], tribox[6 * f + 3 + k]);
+        }
+    }
+    std::vector<uint64_t> keys(nf);
+    for (int64_t f = 0; f < nf; f++) keys[f] = (tr_morton63(&tribox[6 * f], mn, mx) >> morton_shift) << morton_shift;
+    std::vector<uint32_t> order(nf);
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return keys[x] < keys[y]; });
+    std::vector<uint64_t> skeys(nf);
+    std::vector<float> sbox(6 * nf);
+    b->tris.resize(nf);
+    for (int64_t k = 0; k < nf; k++) {
+        uint32_t f = order[k];
+        skeys[k] = keys[f];
+        const float* a = verts + 3 * (int64_t)faces[3 * f];
+        const float* bb = verts + 3 * (int64_t)faces[3 * f + 1];
+        const float* c = verts + 3 * (int64_t)faces[3 * f + 2];
+        tr_tri t;
+        t.ax = a[0]; t.ay = a[1]; t.az = a[2];
+        t.bx = bb[0]; t.by = bb[1]; t.bz = bb[2];
+        t.cx = c[0]; t.cy = c[1]; t.cz = c[2];
+        t.face = (int32_t)f; t.pad0 = t.pad1 = 0;
+        b->tris[k] = t;
+        memcpy(&sbox[6 * k], &tribox[6 * f], 24);
+    }
+    if (nf >= 2) {
+        int h = -1;
+        if (force_mode != 1) { h = build_hierarchy<0>(*b, skeys, sbox); b->key_mode = 0; }
+        if (force_mode == 1 || (force_mode < 0 && h > 64)) { h = build_hierarchy<1>(*b, skeys, sbox); b->key_mode = 1; }
+        b->depth = h;
+    }
+    return b;
+}
+
+void sim_destroy(void* h) { delete (SimBvh*)h; }
+int sim_depth(void* h) { return ((SimBvh*)h)->depth; }
+int sim_key_mode(void* h) { return ((SimBvh*)h)->key_mode; }
+int64_t sim_num_nodes(void* h) { return (int64_t)((SimBvh*)h)->nodes.size(); }
+void sim_get(void* h, void* nodes, void* links, void* tris) {
+    SimBvh* b = (SimBvh*)h;
+    if (nodes) memcpy(nodes, b->nodes.data(), b->nodes.size() * sizeof(tr_node));
+    if (links) memcpy(links, b->links.data(), b->links.size() * sizeof(tr_link));
+    if (tris) memcpy(tris, b->tris.data(), b->tris.size() * sizeof(tr_tri));
+}
+}  // extern "C"
+
+// traverse with externally supplied arrays (e.g. downloaded from the GPU builder)
+static tr_bvh_view view_of(const tr_node* nodes, const tr_link* links, const tr_tri* tris, int64_t nf) {
+    tr_bvh_view v; v.nodes = nodes; v.links = links; v.tris = tris; v.num_tris = nf; return v;
+}
+
+template <int Q>
+static void run_query(const tr_bvh_view& v, const float* o, const float* d, int64_t n, uint8_t* hit,
+                      uint8_t* front, int32_t* tri, float* loc, float* uv, int32_t* count, uint64_t* stats) {
+    tr_counters cnt = {0, 0, 0};
+    uint64_t tn = 0, tt = 0, tc = 0;
+    for (int64_t i = 0; i < n; i++) {
+        tr_ray r;
+        bool valid = tr_ray_setup(r, o[3 * i], o[3 * i + 1], o[3 * i + 2], d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+        tr_result res;
+        tr_topk<1> top;
+        cnt.nodes = cnt.tris = cnt.climbs = 0;
+        if (v.num_tris >= 2) tr_traverse<Q, 1, true>(v, r, valid, res, top, &cnt);
+        else {
+            res.best_face = -1; res.count = 0; res.best_t = TR_TMAX;
+            if (valid && v.num_tris == 1) {
+                const tr_tri& t = v.tris[0]; tr_hit h;
+                if (tr_tri_hit(r, t.ax, t.ay, t.az, t.bx, t.by, t.bz, t.cx, t.cy, t.cz, h)) {
+                    res.best_t = h.t; res.best_face = t.face; res.best_slot = 0; res.U = h.U; res.V = h.V; res.det = h.det; res.count = 1;
+                }
+            }
+        }
+        tn += cnt.nodes; tt += cnt.tris; tc += cnt.climbs;
+        if (Q == TR_Q_ANY) hit[i] = res.best_face >= 0;
+        if (Q == TR_Q_FIRST) tri[i] = res.best_face;
+        if (Q == TR_Q_COUNT) count[i] = res.count;
+        if (Q == TR_Q_CLOSEST) {
+            float l3[3] = {0, 0, 0}, u2[2] = {0, 0};
+            hit[i] = res.best_face >= 0; front[i] = 0; tri[i] = res.best_face;
+            if (res.best_face >= 0) {
+                const tr_tri& t = v.tris[res.best_slot];
+                tr_hit h; h.t = res.best_t; h.U = res.U; h.V = res.V; h.det = res.det;
+                tr_hit_outputs(h, t.ax, t.ay, t.az, t.bx, t.by, t.bz, t.cx, t.cy, t.cz, l3, u2);
+                front[i] = res.det > 0.f;
+            }
+            memcpy(loc + 3 * i, l3, 12); memcpy(uv + 2 * i, u2, 8);
+        }
+    }
+    if (stats) { stats[0] = (uint64_t)n; stats[1] = tn; stats[2] = tt; stats[3] = tc; }
+}
+
+extern "C" {
+void sim_query(int q, const void* nodes, const void* links, const void* tris, int64_t nf, const float* o,
+               const float* d, int64_t n, uint8_t* hit, uint8_t* front, int32_t* tri, float* loc, float* uv,
+               int32_t* count, uint64_t* stats) {
+    tr_bvh_view v = view_of((const tr_node*)nodes, (const tr_link*)links, (const tr_tri*)tris, nf);
+    switch (q) {
+        case TR_Q_ANY: run_query<TR_Q_ANY>(v, o, d, n, hit, front, tri, loc, uv, count, stats); break;
+        case TR_Q_FIRST: run_query<TR_Q_FIRST>(v, o, d, n, hit, front, tri, loc, uv, count, stats); break;
+        case TR_Q_CLOSEST: run_query<TR_Q_CLOSEST>(v, o, d, n, hit, front, tri, loc, uv, count, stats); break;
+        case TR_Q_COUNT: run_query<TR_Q_COUNT>(v, o, d, n, hit, front, tri, loc, uv, count, stats); break;
+    }
+}
+
+// multi-hit: counts[i] hits (uncapped), first min(count,cap) nearest written at i*cap
+void sim_location(const void* nodes, const void* links, const void* tris, int64_t nf, const float* o,
+                  const float* d, int64_t n, int32_t cap, int32_t* count, int32_t* tri_out, float* t_out) {
+    tr_bvh_view v = view_of((const tr_node*)nodes, (const tr_link*)links, (const tr_tri*)tris, nf);
+    for (int64_t i = 0; i < n; i++) {
+        tr_ray r;
+        bool valid = tr_ray_setup(r, o[3 * i], o[3 * i + 1], o[3 * i + 2], d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+        tr_result res; tr_topk<8> top; tr_counters cnt;
+        tr_traverse<TR_Q_LOCATION, 8, false>(v, r, valid, res, top, &cnt);
+        count[i] = res.count;
+        for (int k = 0; k < 8 && k < cap; k++) { tri_out[i * cap + k] = k < res.count ? top.face[k] : -1; t_out[i * cap + k] = top.t[k]; }
+    }
+}
+}

@@ -1,0 +1,83 @@
+"""ctypes front-end of tests/host_sim/libhost_sim.so (TEST-ONLY logic simulation of the
+product's host+device headers; see host_sim.cpp)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libhost_sim.so")
+        src = os.path.join(_HERE, "host_sim.cpp")
+        hdr = os.path.join(_HERE, "..", "..", "trimesh-ray-optix_amd", "csrc")
+        newest = max([os.path.getmtime(src)] + [os.path.getmtime(os.path.join(hdr, h))
+                                                for h in ("tr_math.h", "tr_bvh.h", "tr_lbvh.h")])
+        if not os.path.exists(so) or os.path.getmtime(so) < newest:
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+                                   "-mfma", "-Wno-unknown-pragmas", "-o", so, src])
+        L = C.CDLL(so)
+        L.sim_build.restype = C.c_void_p
+        L.sim_build.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int]
+        L.sim_destroy.argtypes = [C.c_void_p]
+        L.sim_depth.argtypes = [C.c_void_p]
+        L.sim_key_mode.argtypes = [C.c_void_p]
+        L.sim_num_nodes.argtypes = [C.c_void_p]
+        L.sim_num_nodes.restype = C.c_int64
+        L.sim_get.argtypes = [C.c_void_p] * 4
+        L.sim_query.argtypes = [C.c_int] + [C.c_void_p] * 3 + [C.c_int64, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p] * 7
+        L.sim_location.argtypes = [C.c_void_p] * 3 + [C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 3
+        _LIB = L
+    return _LIB
+
+
+NODE_WORDS, LINK_WORDS, TRI_WORDS = 16, 2, 12
+
+
+class SimBVH:
+    def __init__(self, verts=None, faces=None, force_mode=-1, morton_shift=0, arrays=None):
+        if arrays is not None:
+            self.nodes, self.links, self.tris = arrays
+            self.nf = len(self.tris)
+            self.depth = None
+            return
+        v = np.ascontiguousarray(verts, np.float32)
+        f = np.ascontiguousarray(faces, np.int32)
+        L = lib()
+        h = L.sim_build(v.ctypes.data, len(v), f.ctypes.data, len(f), force_mode, morton_shift)
+        self.nf = len(f)
+        nn = L.sim_num_nodes(h)
+        self.depth = L.sim_depth(h)
+        self.key_mode = L.sim_key_mode(h)
+        self.nodes = np.zeros((nn, NODE_WORDS), np.uint32)
+        self.links = np.zeros((nn, LINK_WORDS), np.int32)
+        self.tris = np.zeros((self.nf, TRI_WORDS), np.uint32)
+        L.sim_get(h, self.nodes.ctypes.data, self.links.ctypes.data, self.tris.ctypes.data)
+        L.sim_destroy(h)
+
+    def query(self, q, o, d):
+        o = np.ascontiguousarray(o, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)
+        n = len(o)
+        hit = np.zeros(n, np.uint8); front = np.zeros(n, np.uint8); tri = np.zeros(n, np.int32)
+        loc = np.zeros((n, 3), np.float32); uv = np.zeros((n, 2), np.float32)
+        cnt = np.zeros(n, np.int32); stats = np.zeros(4, np.uint64)
+        lib().sim_query(q, self.nodes.ctypes.data, self.links.ctypes.data, self.tris.ctypes.data, self.nf,
+                        o.ctypes.data, d.ctypes.data, n, hit.ctypes.data, front.ctypes.data, tri.ctypes.data,
+                        loc.ctypes.data, uv.ctypes.data, cnt.ctypes.data, stats.ctypes.data)
+        return dict(hit=hit.astype(bool), front=front.astype(bool), tri=tri, loc=loc, uv=uv, count=cnt,
+                    stats=stats)
+
+    def location(self, o, d, cap=8):
+        o = np.ascontiguousarray(o, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)
+        n = len(o)
+        cnt = np.zeros(n, np.int32); tri = np.zeros((n, cap), np.int32); t = np.zeros((n, cap), np.float32)
+        lib().sim_location(self.nodes.ctypes.data, self.links.ctypes.data, self.tris.ctypes.data, self.nf,
+                           o.ctypes.data, d.ctypes.data, n, cap, cnt.ctypes.data, tri.ctypes.data, t.ctypes.data)
+        return cnt, tri, t

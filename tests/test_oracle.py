@@ -1,0 +1,163 @@
+"""CPU tests of the oracle (test infrastructure): known answers of the reference's own test
+inputs, golden fixtures, brute force == oracle BVH, strided fetch."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+import workloads as W
+from oracle.oracle import OracleIntersector, fetch_rays
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+KA = json.load(open(os.path.join(GOLD, "known_answers.json")))
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_T1_single_triangle(mode):
+    k = KA["T1"]
+    R = OracleIntersector(np.array(k["vertices"], np.float32), np.array(k["faces"], np.int32), mode)
+    o, d = np.array(k["origins"], np.float32), np.array(k["directions"], np.float32)
+    assert R.intersects_any(o, d).tolist() == k["any"]
+    assert R.intersects_first(o, d).tolist() == k["first"]
+    hit, front, tri, loc, uv = R.intersects_closest(o, d)
+    c = k["closest"]
+    assert hit.tolist() == c["hit"] and front.tolist() == c["front"] and tri.tolist() == c["tri"]
+    np.testing.assert_allclose(loc, c["loc"], atol=1e-7)
+    np.testing.assert_allclose(uv, c["uv"], atol=1e-7)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_T2_two_triangles(mode):
+    k = KA["T2"]
+    R = OracleIntersector(np.array(k["vertices"], np.float32), np.array(k["faces"], np.int32), mode)
+    o, d = np.array(k["origins"], np.float32), np.array(k["directions"], np.float32)
+    assert R.intersects_count(o, d).tolist() == k["count"]
+    loc, ray, tri = R.intersects_location(o, d)
+    assert ray.tolist() == k["location"]["ray_idx"]
+    got = {}
+    for l, r, t in zip(loc, ray, tri):
+        got.setdefault(int(r), []).append((int(t), l))
+    for r, exp in enumerate(k["location"]["per_ray"]):
+        assert sorted(t for t, _ in got[r]) == sorted(t for t, _ in exp)
+        for t, l in exp:
+            np.testing.assert_allclose([g for tt, g in got[r] if tt == t][0], l, atol=1e-6)
+    hit, front, tri, loc, uv = R.intersects_closest(o, d)
+    c = k["closest"]
+    assert hit.tolist() == c["hit"] and front.tolist() == c["front"] and tri.tolist() == c["tri"]
+    np.testing.assert_allclose(uv, c["uv"], atol=1e-6)
+    # intersects_id conventions (ray_optix.py:207-223)
+    t2, r2 = R.intersects_id(o, d)
+    assert np.array_equal(t2, R.intersects_location(o, d)[2])
+    t1, r1, l1 = R.intersects_id(o, d, return_locations=True, multiple_hits=False)
+    assert t1.tolist() == c["tri"] and r1.tolist() == [0, 1]
+
+
+def test_T3_contains_points():
+    v, f = W.icosphere(3)
+    R = OracleIntersector(v, f, 0)
+    assert R.contains_points(np.array(KA["T3"]["points"], np.float32)).tolist() == KA["T3"]["contains"]
+    pts = np.array([[0, 0, 0], [0.5, 0.2, 0.1], [0, 0, 1.01], [2, 2, 2], [0.9, 0.9, 0.9]], np.float32)
+    assert R.contains_points(pts).tolist() == [True, True, False, False, False]
+
+
+def test_T4_readme_scene():
+    v, f = W.icosphere(3)
+    o, d = W.readme_perspective(800)
+    R = OracleIntersector(v, f, 1)
+    hit, front, ray_idx, tri, loc, uv = R.intersects_closest(o, d, stream_compaction=True)
+    ys, xs = np.nonzero(hit)
+    rad = np.sqrt((ys - 399.5) ** 2 + (xs - 399.5) ** 2).max()
+    assert 139.0 < rad <= KA["T4"]["max_hit_radius_px"]
+    assert front.all() and (loc[:, 2] > 0).all()
+    assert np.array_equal(ray_idx, np.flatnonzero(hit.reshape(-1)).astype(np.int32))
+    # uv are weights of vertices 0 and 1 (shaders.cu:149; consumer test/test.py:41)
+    vv = v[f[tri]]
+    rec = uv[:, :1] * vv[:, 0] + uv[:, 1:] * vv[:, 1] + (1 - uv[:, :1] - uv[:, 1:]) * vv[:, 2]
+    np.testing.assert_allclose(rec, loc, atol=2e-6)
+
+
+def test_icosphere_is_outward_wound():
+    v, f = W.icosphere(2)
+    assert v.shape == (162, 3) and f.shape == (320, 3)
+    n = np.cross(v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]])
+    assert (np.einsum("ij,ij->i", n, v[f].mean(1)) > 0).all()
+    v1, f1 = W.icosphere(1)
+    assert len(f1) == 80 and len(v1) == 42     # BASELINE.json config 1
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "*.npz"))))
+@pytest.mark.parametrize("mode", [0, 1])
+def test_golden_fixtures(path, mode):
+    g = np.load(path)
+    R = OracleIntersector(g["vertices"], g["faces"], mode)
+    hit, front, tri, loc, uv, t = R.closest_raw(g["origins"], g["directions"])
+    assert np.array_equal(hit, g["hit"]) and np.array_equal(front, g["front"])
+    assert np.array_equal(tri, g["tri"]) and np.array_equal(t, g["t"])
+    assert np.array_equal(loc, g["loc"]) and np.array_equal(uv, g["uv"])
+    assert np.array_equal(R.intersects_count(g["origins"], g["directions"]), g["count"])
+    lloc, lray, ltri, lt = R.intersects_location(g["origins"], g["directions"], with_t=True)
+    assert np.array_equal(lray, g["loc_ray"]) and np.array_equal(ltri, g["loc_tri"])
+    assert np.array_equal(lloc, g["loc_loc"]) and np.array_equal(lt, g["loc_t"])
+
+
+def test_cube_boundary_rays_hit_both_sides():
+    g = np.load(os.path.join(GOLD, "cube_axis_rays.npz"))
+    o, hit = g["origins"], g["hit"]
+    first = slice(0, 625)
+    inside = (np.abs(o[first, 0]) <= 1) & (np.abs(o[first, 1]) <= 1)   # includes x = +-1, y = +-1
+    assert np.array_equal(hit[first], inside)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_brute_equals_bvh_random(seed):
+    v, f = W.random_soup(600, seed=seed)
+    o, d = W.hash_rays(6000, 100 + seed, v.min(0) * 1.5, v.max(0) * 1.5)
+    a = OracleIntersector(v, f, 0)
+    b = OracleIntersector(v, f, 1)
+    for x, y in zip(a.closest_raw(o, d), b.closest_raw(o, d)):
+        assert np.array_equal(x, y)
+    assert np.array_equal(a.intersects_count(o, d), b.intersects_count(o, d))
+    for x, y in zip(a.intersects_location(o, d, with_t=True), b.intersects_location(o, d, with_t=True)):
+        assert np.array_equal(x, y)
+
+
+def test_location_cap_and_order():
+    v, f = W.nested_shells(2, radii=(1.0, 0.8, 0.6, 0.4, 0.3))
+    R = OracleIntersector(v, f, 1)
+    o = np.array([[0.01, 0.02, 3]], np.float32)
+    d = np.array([[0, 0, -1]], np.float32)
+    assert R.intersects_count(o, d).tolist() == [10]
+    loc, ray, tri, t = R.intersects_location(o, d, with_t=True)
+    assert len(ray) == 8 and (np.diff(t) >= 0).all()        # clamp to MAX_ANYHIT_SIZE, nearest first
+    assert abs(loc[0, 2] - 1.0) < 0.02 and loc[-1, 2] < 0   # starts at the outer shell
+
+
+def test_invalid_and_degenerate():
+    v = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [2, 2, 2], [2, 2, 2], [2, 2, 2]], np.float32)
+    f = np.array([[0, 1, 2], [3, 4, 5]], np.int32)          # second triangle is degenerate
+    R = OracleIntersector(v, f, 0)
+    o = np.array([[0.2, 0.2, 1], [np.nan, 0, 1], [0.2, 0.2, 1], [2, 2, 3], [0.2, 0.2, 1]], np.float32)
+    d = np.array([[0, 0, -1], [0, 0, -1], [0, 0, np.inf], [0, 0, -1], [0, 0, 0]], np.float32)
+    hit = R.intersects_any(o, d)
+    assert hit.tolist() == [True, False, False, False, False]
+    # tmax = 1e7 (shaders.cu:86): a triangle farther than that is not hit
+    o = np.array([[0.2, 0.2, 2e7], [0.2, 0.2, 9e6]], np.float32)
+    d = np.array([[0, 0, -1], [0, 0, -1]], np.float32)
+    assert R.intersects_any(o, d).tolist() == [False, True]
+
+
+def test_fetch_rays_strides():
+    rng = np.random.default_rng(0)
+    base = rng.random((5, 7, 6)).astype(np.float32)
+    d = base[:, :, ::2]                                    # last-dim stride 2
+    o = np.broadcast_to(np.array([1, 2, 3], np.float32), d.shape)   # stride-0 origin
+    oo, dd = fetch_rays(o, d)
+    assert np.array_equal(dd, d.reshape(-1, 3)) and np.array_equal(oo, np.tile([1, 2, 3], (35, 1)))
+    t = base.transpose(1, 0, 2)[:, :, 3:]                  # permuted leading dims
+    oo, dd = fetch_rays(t, t)
+    assert np.array_equal(oo, np.ascontiguousarray(t).reshape(-1, 3))
+    four = rng.random((2, 3, 4, 3)).astype(np.float32)
+    oo, _ = fetch_rays(four, four)
+    assert np.array_equal(oo, four.reshape(-1, 3))

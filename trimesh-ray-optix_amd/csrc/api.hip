@@ -1,0 +1,185 @@
+// api.hip -- runtime bring-up, error reporting and acceleration-structure entry points of the
+// C ABI (include/triro_hip.h).  Replaces triro/backend/base.cpp (global OptiX context, module,
+// pipelines, SBTs: base.cpp:15-157) -- none of those concepts survive; what remains is a
+// per-device table {CU count, work-counter ring, scan scratch} created on first use.
+#include <mutex>
+#include <string.h>
+
+#include "tr_internal.h"
+
+namespace {
+thread_local std::string g_last_error;
+std::mutex g_mutex;
+constexpr int TR_MAX_DEVICES = 64;
+tr_device_state g_devices[TR_MAX_DEVICES];
+tr_options g_options;
+
+struct DeviceGuard {
+    int prev = -1;
+    bool changed = false;
+    int enter(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) return TR_ERR_NO_DEVICE;
+        if (prev != device) {
+            if (hipSetDevice(device) != hipSuccess) return TR_ERR_NO_DEVICE;
+            changed = true;
+        }
+        return TR_OK;
+    }
+    ~DeviceGuard() {
+        if (changed) (void)hipSetDevice(prev);
+    }
+};
+}  // namespace
+
+void tr_set_error(const std::string& msg) { g_last_error = msg; }
+int tr_fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+tr_options& tr_opts() { return g_options; }
+
+int tr_get_device_state(int device, tr_device_state** out) {
+    if (device < 0 || device >= TR_MAX_DEVICES) return tr_fail(TR_ERR_INVALID_ARG, "device ordinal out of range");
+    std::lock_guard<std::mutex> lock(g_mutex);
+    tr_device_state& st = g_devices[device];
+    if (!st.ready) {
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+            return tr_fail(TR_ERR_NO_DEVICE, "no HIP device available (libtriro_hip has no CPU fallback)");
+        if (device >= count) return tr_fail(TR_ERR_NO_DEVICE, "device ordinal >= device count");
+        DeviceGuard g;
+        if (g.enter(device) != TR_OK) return tr_fail(TR_ERR_NO_DEVICE, "hipSetDevice failed");
+        hipDeviceProp_t prop;
+        TR_HIP_TRY(hipGetDeviceProperties(&prop, device));
+        st.device = device;
+        st.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        TR_HIP_TRY(hipMalloc((void**)&st.counters, sizeof(unsigned long long) * TR_NUM_COUNTERS));
+        TR_HIP_TRY(hipMemset(st.counters, 0, sizeof(unsigned long long) * TR_NUM_COUNTERS));
+        st.ready = true;
+    }
+    *out = &st;
+    return TR_OK;
+}
+
+int tr_scratch_reserve(tr_device_state* st, size_t bytes, void** out) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    if (st->scratch_bytes < bytes) {
+        DeviceGuard g;
+        if (g.enter(st->device) != TR_OK) return tr_fail(TR_ERR_NO_DEVICE, "hipSetDevice failed");
+        if (st->scratch) { TR_HIP_TRY(hipFree(st->scratch)); st->scratch = nullptr; st->scratch_bytes = 0; }
+        size_t want = bytes < (1u << 20) ? (1u << 20) : bytes * 2;
+        TR_HIP_TRY(hipMalloc(&st->scratch, want));
+        st->scratch_bytes = want;
+    }
+    *out = st->scratch;
+    return TR_OK;
+}
+
+extern "C" {
+
+int tr_abi_version(void) { return TR_ABI_VERSION; }
+
+const char* tr_last_error(void) { return g_last_error.c_str(); }
+
+int tr_init(int device) {
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess)
+            return tr_fail(TR_ERR_NO_DEVICE, "no HIP device available (libtriro_hip has no CPU fallback)");
+    }
+    tr_device_state* st;
+    return tr_get_device_state(device, &st);
+}
+
+int tr_bvh_build(const float* d_vertices, int64_t nv, const int32_t* d_faces, int64_t nf,
+                 void* stream, tr_bvh** out) {
+    if (!out) return tr_fail(TR_ERR_INVALID_ARG, "out == NULL");
+    *out = nullptr;
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess)
+        return tr_fail(TR_ERR_NO_DEVICE, "no HIP device available (libtriro_hip has no CPU fallback)");
+    if (nf > 0 && d_vertices) {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, d_vertices) == hipSuccess && attr.type == hipMemoryTypeDevice)
+            device = attr.device;
+        else (void)hipGetLastError();
+    }
+    tr_device_state* st;
+    TR_TRY(tr_get_device_state(device, &st));
+    DeviceGuard g;
+    if (g.enter(device) != TR_OK) return tr_fail(TR_ERR_NO_DEVICE, "hipSetDevice failed");
+    tr_bvh* bvh = new (std::nothrow) tr_bvh();
+    if (!bvh) return tr_fail(TR_ERR_OUT_OF_MEMORY, "host allocation failed");
+    bvh->device = device;
+    int s = tr_build_impl(bvh, d_vertices, nv, d_faces, nf, (hipStream_t)stream);
+    if (s != TR_OK) {
+        if (bvh->arena) (void)hipFree(bvh->arena);
+        delete bvh;
+        return s;
+    }
+    *out = bvh;
+    return TR_OK;
+}
+
+int tr_bvh_update(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_t* d_faces,
+                  int64_t nf, void* stream) {
+    if (!bvh) return tr_fail(TR_ERR_INVALID_ARG, "bvh == NULL");
+    DeviceGuard g;
+    if (g.enter(bvh->device) != TR_OK) return tr_fail(TR_ERR_NO_DEVICE, "hipSetDevice failed");
+    return tr_build_impl(bvh, d_vertices, nv, d_faces, nf, (hipStream_t)stream);
+}
+
+int tr_bvh_destroy(tr_bvh* bvh) {
+    if (!bvh) return TR_OK;
+    int status = TR_OK;
+    {
+        DeviceGuard g;
+        if (g.enter(bvh->device) == TR_OK && bvh->arena) {
+            if (hipFree(bvh->arena) != hipSuccess) status = tr_fail(TR_ERR_HIP, "hipFree(arena)");
+        }
+    }
+    delete bvh;
+    return status;
+}
+
+int tr_bvh_get_info(const tr_bvh* bvh, tr_bvh_info* info) {
+    if (!bvh || !info) return tr_fail(TR_ERR_INVALID_ARG, "null argument");
+    info->device = bvh->device;
+    info->num_tris = bvh->num_tris;
+    info->num_nodes = bvh->num_nodes;
+    info->depth = bvh->depth;
+    info->key_mode = bvh->key_mode;
+    info->arena_bytes = bvh->arena_bytes;
+    info->node_bytes = bvh->num_nodes * (int64_t)sizeof(tr_node);
+    info->tri_bytes = bvh->num_tris * (int64_t)sizeof(tr_tri);
+    for (int k = 0; k < 3; k++) { info->aabb_min[k] = bvh->aabb_min[k]; info->aabb_max[k] = bvh->aabb_max[k]; }
+    return TR_OK;
+}
+
+int tr_bvh_download(const tr_bvh* bvh, void* h_nodes, void* h_links, void* h_tris, void* stream) {
+    if (!bvh) return tr_fail(TR_ERR_INVALID_ARG, "bvh == NULL");
+    hipStream_t s = (hipStream_t)stream;
+    DeviceGuard g;
+    if (g.enter(bvh->device) != TR_OK) return tr_fail(TR_ERR_NO_DEVICE, "hipSetDevice failed");
+    if (h_nodes && bvh->num_nodes)
+        TR_HIP_TRY(hipMemcpyAsync(h_nodes, bvh->nodes, sizeof(tr_node) * (size_t)bvh->num_nodes, hipMemcpyDeviceToHost, s));
+    if (h_links && bvh->num_nodes)
+        TR_HIP_TRY(hipMemcpyAsync(h_links, bvh->links, sizeof(tr_link) * (size_t)bvh->num_nodes, hipMemcpyDeviceToHost, s));
+    if (h_tris && bvh->num_tris)
+        TR_HIP_TRY(hipMemcpyAsync(h_tris, bvh->tris, sizeof(tr_tri) * (size_t)bvh->num_tris, hipMemcpyDeviceToHost, s));
+    TR_HIP_TRY(hipStreamSynchronize(s));
+    return TR_OK;
+}
+
+int tr_set_option(const char* name, int64_t value) {
+    if (!name) return tr_fail(TR_ERR_INVALID_ARG, "name == NULL");
+    if (!strcmp(name, "persistent")) { g_options.persistent = value != 0; return TR_OK; }
+    if (!strcmp(name, "blocks_per_cu")) {
+        if (value < 1 || value > 32) return tr_fail(TR_ERR_INVALID_ARG, "blocks_per_cu out of range");
+        g_options.blocks_per_cu = (int)value;
+        return TR_OK;
+    }
+    if (!strcmp(name, "refill")) { g_options.refill = value != 0; return TR_OK; }
+    return tr_fail(TR_ERR_INVALID_ARG, std::string("unknown option: ") + name);
+}
+
+}  // extern "C"

@@ -1,0 +1,459 @@
+// bvh_build.hip -- on-GPU LBVH builder for gfx950 (replaces optixAccelBuild/optixAccelCompact,
+// triro/backend/ray.cpp:27-100).
+//
+// Pipeline (all on the caller's stream, one host sync to read the tree height):
+//   1. k_tri_bounds    per-triangle exact box + mesh bounds (ordered-uint atomic min/max)
+//   2. k_morton        63-bit Morton code of the box centre (21 bits/axis), value = face id
+//   3. radix sort      LSD, 8 passes x 8 bits, keys u64 + values u32.  One wave64 per tile:
+//                      k_rs_count (LDS histogram per wave) -> k_rs_scan (digit-major
+//                      exclusive scan, single workgroup) -> k_rs_scatter (stable: ranks from
+//                      8 __ballot's per round, running per-digit base in LDS)
+//   4. k_gather        Morton-ordered triangle records (48 B) + their boxes
+//   5. k_karras        Karras 2012 binary radix tree: one thread per internal node
+//   6. k_refit_round   bottom-up boxes, ONE KERNEL LAUNCH PER TREE LEVEL.  A node is
+//                      computed in round r only if both children were finished in a round
+//                      < r, so every cross-workgroup read is ordered by a kernel boundary
+//                      (gfx950 L2s are per-XCD and not coherent; the classic single-launch
+//                      "second thread to arrive" refit needs agent-scope release/acquire
+//                      per node and is wrong-not-slow without it).  #rounds = tree height.
+//   7. k_emit          64-B traversal nodes {box0, box1, c0, c1, parent, sibling} + links
+//
+// If the height exceeds 64 (long runs of identical Morton codes) the hierarchy is rebuilt
+// with depth-bounded keys (top 32 Morton bits << 32 | sorted position), which caps the
+// height at 64 -- the traversal trail is a single 64-bit word.
+#include <string.h>
+
+#include "tr_internal.h"
+#include "tr_lbvh.h"
+
+namespace {
+
+constexpr int RS_KPT = 32;                 // keys per lane per tile
+constexpr int RS_TILE = 64 * RS_KPT;       // 2048 keys per wave-tile
+constexpr int RS_WAVES = 4;                // waves (tiles) per workgroup
+
+__device__ __forceinline__ uint32_t enc_f32(float f) {
+    uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float dec_f32(uint32_t e) {
+    uint32_t b = (e & 0x80000000u) ? (e & 0x7fffffffu) : ~e;
+    return __uint_as_float(b);
+}
+
+__global__ void k_init_bounds(uint32_t* bounds) {
+    int t = threadIdx.x;
+    if (t < 3) bounds[t] = 0xffffffffu;        // min (encoded)
+    else if (t < 6) bounds[t] = 0u;            // max (encoded)
+}
+
+// ---- 1. triangle boxes + mesh bounds ------------------------------------------------
+__global__ __launch_bounds__(256) void k_tri_bounds(const float* __restrict__ verts,
+                                                    const int32_t* __restrict__ faces, int64_t nf,
+                                                    float* __restrict__ tribox,
+                                                    uint32_t* __restrict__ bounds) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    if (i < nf) {
+        int32_t ia = faces[3 * i], ib = faces[3 * i + 1], ic = faces[3 * i + 2];
+        const float* a = verts + 3 * (int64_t)ia;
+        const float* b = verts + 3 * (int64_t)ib;
+        const float* c = verts + 3 * (int64_t)ic;
+        tr_tri_box(a[0], a[1], a[2], b[0], b[1], b[2], c[0], c[1], c[2], lo, hi);
+        float* o = tribox + 6 * i;
+        o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2];
+        o[3] = hi[0]; o[4] = hi[1]; o[5] = hi[2];
+    }
+    // wave reduce, then one atomic per wave and component
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float l = lo[k], h = hi[k];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            l = fminf(l, __shfl_xor(l, off));
+            h = fmaxf(h, __shfl_xor(h, off));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin(&bounds[k], enc_f32(l));
+            atomicMax(&bounds[3 + k], enc_f32(h));
+        }
+    }
+}
+
+// ---- 2. Morton codes -------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_morton(const float* __restrict__ tribox, int64_t nf,
+                                                const uint32_t* __restrict__ bounds,
+                                                uint64_t* __restrict__ keys,
+                                                uint32_t* __restrict__ vals) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nf) return;
+    float mn[3], mx[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { mn[k] = dec_f32(bounds[k]); mx[k] = dec_f32(bounds[3 + k]); }
+    keys[i] = tr_morton63(tribox + 6 * i, mn, mx);
+    vals[i] = (uint32_t)i;
+}
+
+// ---- 3. radix sort -----------------------------------------------------------------------
+// histogram of one 8-bit digit per wave-tile; hist layout is digit-major: hist[d*ntiles+tile]
+__global__ __launch_bounds__(64 * RS_WAVES) void k_rs_count(const uint64_t* __restrict__ keys,
+                                                            int64_t n, int shift, int64_t ntiles,
+                                                            uint32_t* __restrict__ hist) {
+    __shared__ uint32_t lh[RS_WAVES][256];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * RS_WAVES + wave;
+#pragma unroll
+    for (int k = 0; k < 4; k++) lh[wave][lane + 64 * k] = 0;
+    __syncthreads();
+    if (tile < ntiles) {
+        const int64_t base = tile * RS_TILE;
+#pragma unroll 4
+        for (int r = 0; r < RS_KPT; r++) {
+            int64_t idx = base + (int64_t)r * 64 + lane;
+            if (idx < n) atomicAdd(&lh[wave][(keys[idx] >> shift) & 0xff], 1u);
+        }
+    }
+    __syncthreads();
+    if (tile < ntiles) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) hist[(int64_t)(lane + 64 * k) * ntiles + tile] = lh[wave][lane + 64 * k];
+    }
+}
+
+// exclusive scan of `total` uint32 entries in place, single workgroup of 1024 threads
+__global__ __launch_bounds__(1024) void k_rs_scan(uint32_t* __restrict__ data, int64_t total) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < total; base += 4096) {
+        int64_t i0 = base + (int64_t)tid * 4;
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = (i0 + k < total) ? data[i0 + k] : 0u;
+        uint32_t s = v[0] + v[1] + v[2] + v[3];
+        // inclusive wave scan
+        uint32_t inc = s;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t o = __shfl_up(inc, off);
+            if (lane >= off) inc += o;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t wpre = 0;
+        for (int w = 0; w < wave; w++) wpre += wsum[w];
+        uint32_t carry = carry_s;
+        uint32_t ex = carry + wpre + inc - s;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (i0 + k < total) data[i0 + k] = ex;
+            ex += v[k];
+        }
+        __syncthreads();
+        if (tid == 1023) carry_s = carry + wpre + inc;
+        __syncthreads();
+    }
+}
+
+// stable scatter: one wave per tile
+__global__ __launch_bounds__(64 * RS_WAVES) void k_rs_scatter(
+    const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, int64_t n,
+    int shift, int64_t ntiles, const uint32_t* __restrict__ hist_scanned,
+    uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
+    __shared__ uint32_t base[RS_WAVES][256];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * RS_WAVES + wave;
+    if (tile >= ntiles) return;   // whole wave exits together; no block-level barrier below
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        base[wave][lane + 64 * k] = hist_scanned[(int64_t)(lane + 64 * k) * ntiles + tile];
+    __builtin_amdgcn_wave_barrier();
+    const uint64_t lt = (1ull << lane) - 1ull;
+    const int64_t tbase = tile * RS_TILE;
+    for (int r = 0; r < RS_KPT; r++) {
+        int64_t idx = tbase + (int64_t)r * 64 + lane;
+        bool valid = idx < n;
+        uint64_t key = valid ? keys_in[idx] : 0ull;
+        uint32_t val = valid ? vals_in[idx] : 0u;
+        uint32_t digit = (uint32_t)(key >> shift) & 0xffu;
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            bool bit = (digit >> b) & 1u;
+            uint64_t bal = __ballot(valid && bit);
+            peers &= bit ? bal : ~bal;
+        }
+        uint32_t rank = (uint32_t)__popcll(peers & lt);
+        uint32_t cnt = (uint32_t)__popcll(peers);
+        uint32_t pos = 0;
+        if (valid) pos = base[wave][digit] + rank;
+        __builtin_amdgcn_wave_barrier();
+        if (valid && rank == 0) base[wave][digit] += cnt;
+        __builtin_amdgcn_wave_barrier();
+        if (valid) {
+            keys_out[pos] = key;
+            vals_out[pos] = val;
+        }
+    }
+}
+
+// ---- 4. gather Morton-ordered triangle records -------------------------------------------
+__global__ __launch_bounds__(256) void k_gather(const float* __restrict__ verts,
+                                                const int32_t* __restrict__ faces,
+                                                const uint32_t* __restrict__ order, int64_t nf,
+                                                tr_tri* __restrict__ tris,
+                                                float* __restrict__ sbox) {
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nf) return;
+    int64_t f = order[k];
+    const float* a = verts + 3 * (int64_t)faces[3 * f];
+    const float* b = verts + 3 * (int64_t)faces[3 * f + 1];
+    const float* c = verts + 3 * (int64_t)faces[3 * f + 2];
+    tr_tri t;
+    t.ax = a[0]; t.ay = a[1]; t.az = a[2];
+    t.bx = b[0]; t.by = b[1]; t.bz = b[2];
+    t.cx = c[0]; t.cy = c[1]; t.cz = c[2];
+    t.face = (int32_t)f; t.pad0 = 0; t.pad1 = 0;
+    tris[k] = t;
+    float lo[3], hi[3];
+    tr_tri_box(t.ax, t.ay, t.az, t.bx, t.by, t.bz, t.cx, t.cy, t.cz, lo, hi);
+    float* o = sbox + 6 * k;
+    o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2];
+    o[3] = hi[0]; o[4] = hi[1]; o[5] = hi[2];
+}
+
+// ---- 5. Karras hierarchy ------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void k_karras(const uint64_t* __restrict__ keys, int64_t n,
+                                                int32_t* __restrict__ childL,
+                                                int32_t* __restrict__ childR,
+                                                int32_t* __restrict__ parent) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    int32_t cl, cr;
+    tr_karras_node<MODE>(keys, n, i, &cl, &cr);
+    childL[i] = cl;
+    childR[i] = cr;
+    if (cl >= 0) parent[cl] = (int32_t)i;
+    if (cr >= 0) parent[cr] = (int32_t)i;
+    if (i == 0) parent[0] = -1;
+}
+
+// ---- 6. refit, one launch per level ----------------------------------------------------------
+__global__ __launch_bounds__(256) void k_refit_round(const int32_t* __restrict__ childL,
+                                                     const int32_t* __restrict__ childR,
+                                                     const float* __restrict__ sbox,
+                                                     float* __restrict__ ibox,
+                                                     int32_t* __restrict__ ready, int64_t ninternal,
+                                                     int32_t round) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ninternal) return;
+    if (ready[i] != 0) return;
+    int32_t cl = childL[i], cr = childR[i];
+    if (cl >= 0) { int32_t r = ready[cl]; if (r == 0 || r >= round) return; }
+    if (cr >= 0) { int32_t r = ready[cr]; if (r == 0 || r >= round) return; }
+    const float* a = cl < 0 ? sbox + 6 * (int64_t)(~cl) : ibox + 6 * (int64_t)cl;
+    const float* b = cr < 0 ? sbox + 6 * (int64_t)(~cr) : ibox + 6 * (int64_t)cr;
+    float* o = ibox + 6 * i;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        o[k] = fminf(a[k], b[k]);
+        o[3 + k] = fmaxf(a[3 + k], b[3 + k]);
+    }
+    ready[i] = round;
+}
+
+// ---- 7. emit traversal nodes -------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_emit(const int32_t* __restrict__ childL,
+                                              const int32_t* __restrict__ childR,
+                                              const int32_t* __restrict__ parent,
+                                              const float* __restrict__ sbox,
+                                              const float* __restrict__ ibox, int64_t ninternal,
+                                              tr_node* __restrict__ nodes,
+                                              tr_link* __restrict__ links) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ninternal) return;
+    int32_t cl = childL[i], cr = childR[i];
+    const float* a = cl < 0 ? sbox + 6 * (int64_t)(~cl) : ibox + 6 * (int64_t)cl;
+    const float* b = cr < 0 ? sbox + 6 * (int64_t)(~cr) : ibox + 6 * (int64_t)cr;
+    tr_node nd;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        nd.lo0[k] = a[k]; nd.hi0[k] = a[3 + k];
+        nd.lo1[k] = b[k]; nd.hi1[k] = b[3 + k];
+    }
+    nd.c0 = cl; nd.c1 = cr;
+    int32_t p = parent[i];
+    int32_t sib = 0;
+    if (p >= 0) sib = (childL[p] == (int32_t)i) ? childR[p] : childL[p];
+    nd.parent = p; nd.sibling = sib;
+    nodes[i] = nd;
+    tr_link l; l.parent = p; l.sibling = sib;
+    links[i] = l;
+}
+
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct Carver {
+    char* base; size_t off = 0;
+    template <class T> T* take(size_t count) {
+        off = align_up(off, 256);
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += count * sizeof(T);
+        return p;
+    }
+};
+
+}  // namespace
+
+// Arena layout for `nf` triangles; returns total bytes and sets the pointers when base != 0
+static size_t carve_arena(tr_bvh* bvh, char* base, int64_t nf) {
+    Carver c{base};
+    int64_t nn = nf >= 2 ? nf - 1 : 0;
+    tr_node* nodes = c.take<tr_node>((size_t)(nn > 0 ? nn : 1));
+    tr_link* links = c.take<tr_link>((size_t)(nn > 0 ? nn : 1));
+    tr_tri* tris = c.take<tr_tri>((size_t)(nf > 0 ? nf : 1));
+    if (base) { bvh->nodes = nodes; bvh->links = links; bvh->tris = tris; }
+    return align_up(c.off, 256);
+}
+
+int tr_build_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_t* d_faces,
+                  int64_t nf, hipStream_t stream) {
+    if (nf < 0 || nv < 0) return tr_fail(TR_ERR_INVALID_ARG, "negative mesh size");
+    if (nf >= (int64_t)1 << 31) return tr_fail(TR_ERR_INVALID_ARG, "more than 2^31-1 triangles");
+    if (nf > 0 && (!d_vertices || !d_faces)) return tr_fail(TR_ERR_INVALID_ARG, "null mesh pointer");
+
+    // (re)allocate the arena
+    if (!bvh->arena || bvh->capacity_tris < nf) {
+        if (bvh->arena) { TR_HIP_TRY(hipFree(bvh->arena)); bvh->arena = nullptr; }
+        size_t bytes = carve_arena(bvh, nullptr, nf);
+        TR_HIP_TRY(hipMalloc(&bvh->arena, bytes));
+        bvh->arena_bytes = (int64_t)bytes;
+        bvh->capacity_tris = nf;
+    }
+    carve_arena(bvh, (char*)bvh->arena, nf);
+    bvh->num_tris = nf;
+    bvh->num_nodes = nf >= 2 ? nf - 1 : 0;
+    bvh->depth = 0;
+    bvh->key_mode = 0;
+    for (int k = 0; k < 3; k++) { bvh->aabb_min[k] = 0.f; bvh->aabb_max[k] = 0.f; }
+    if (nf == 0) return TR_OK;
+
+    // temporaries: one allocation
+    const int64_t ntiles = cdiv(nf, RS_TILE);
+    Carver tc{nullptr};
+    auto plan = [&](Carver& c, float*& tribox, float*& sbox, float*& ibox, uint64_t*& k0,
+                    uint64_t*& k1, uint32_t*& v0, uint32_t*& v1, uint32_t*& hist,
+                    uint32_t*& bounds, int32_t*& cl, int32_t*& cr, int32_t*& par, int32_t*& ready) {
+        tribox = c.take<float>(6 * (size_t)nf);
+        sbox = c.take<float>(6 * (size_t)nf);
+        ibox = c.take<float>(6 * (size_t)nf);
+        k0 = c.take<uint64_t>((size_t)nf);
+        k1 = c.take<uint64_t>((size_t)nf);
+        v0 = c.take<uint32_t>((size_t)nf);
+        v1 = c.take<uint32_t>((size_t)nf);
+        hist = c.take<uint32_t>(256 * (size_t)ntiles);
+        bounds = c.take<uint32_t>(8);
+        cl = c.take<int32_t>((size_t)nf);
+        cr = c.take<int32_t>((size_t)nf);
+        par = c.take<int32_t>((size_t)nf);
+        ready = c.take<int32_t>((size_t)nf);
+    };
+    float *tribox, *sbox, *ibox; uint64_t *k0, *k1; uint32_t *v0, *v1, *hist, *bounds;
+    int32_t *cl, *cr, *par, *ready;
+    plan(tc, tribox, sbox, ibox, k0, k1, v0, v1, hist, bounds, cl, cr, par, ready);
+    void* temp = nullptr;
+    TR_HIP_TRY(hipMalloc(&temp, align_up(tc.off, 256)));
+    Carver tc2{(char*)temp};
+    plan(tc2, tribox, sbox, ibox, k0, k1, v0, v1, hist, bounds, cl, cr, par, ready);
+
+    int status = TR_OK;
+    auto check = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && status == TR_OK)
+            status = tr_fail(TR_ERR_HIP, std::string(what) + ": " + hipGetErrorName(e));
+    };
+    const int TB = 256;
+    const unsigned gF = (unsigned)cdiv(nf, TB);
+
+    hipLaunchKernelGGL(k_init_bounds, dim3(1), dim3(64), 0, stream, bounds);
+    hipLaunchKernelGGL(k_tri_bounds, dim3(gF), dim3(TB), 0, stream, d_vertices, d_faces, nf, tribox, bounds);
+    check(hipGetLastError(), "k_tri_bounds");
+
+    if (nf == 1) {
+        // single triangle: no hierarchy; queries use the brute-force kernel
+        hipLaunchKernelGGL(k_morton, dim3(gF), dim3(TB), 0, stream, tribox, nf, bounds, k0, v0);
+        hipLaunchKernelGGL(k_gather, dim3(gF), dim3(TB), 0, stream, d_vertices, d_faces, v0, nf, bvh->tris, sbox);
+        check(hipGetLastError(), "k_gather");
+    } else {
+        hipLaunchKernelGGL(k_morton, dim3(gF), dim3(TB), 0, stream, tribox, nf, bounds, k0, v0);
+        check(hipGetLastError(), "k_morton");
+        uint64_t* kin = k0; uint64_t* kout = k1; uint32_t* vin = v0; uint32_t* vout = v1;
+        const unsigned gT = (unsigned)cdiv(ntiles, RS_WAVES);
+        for (int pass = 0; pass < 8; pass++) {
+            int shift = 8 * pass;
+            hipLaunchKernelGGL(k_rs_count, dim3(gT), dim3(64 * RS_WAVES), 0, stream, kin, nf, shift, ntiles, hist);
+            hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(1024), 0, stream, hist, 256 * ntiles);
+            hipLaunchKernelGGL(k_rs_scatter, dim3(gT), dim3(64 * RS_WAVES), 0, stream, kin, vin, nf, shift,
+                               ntiles, hist, kout, vout);
+            uint64_t* tk = kin; kin = kout; kout = tk;
+            uint32_t* tv = vin; vin = vout; vout = tv;
+        }
+        check(hipGetLastError(), "radix sort");
+        // after 8 passes the sorted data is back in (k0, v0) == (kin, vin)
+        hipLaunchKernelGGL(k_gather, dim3(gF), dim3(TB), 0, stream, d_vertices, d_faces, vin, nf, bvh->tris, sbox);
+        check(hipGetLastError(), "k_gather");
+
+        const int64_t ni = nf - 1;
+        const unsigned gI = (unsigned)cdiv(ni, TB);
+        for (int mode = 0; mode < 2 && status == TR_OK; mode++) {
+            if (mode == 0)
+                hipLaunchKernelGGL(k_karras<0>, dim3(gI), dim3(TB), 0, stream, kin, nf, cl, cr, par);
+            else
+                hipLaunchKernelGGL(k_karras<1>, dim3(gI), dim3(TB), 0, stream, kin, nf, cl, cr, par);
+            check(hipGetLastError(), "k_karras");
+            check(hipMemsetAsync(ready, 0, sizeof(int32_t) * (size_t)ni, stream), "memset ready");
+            int32_t root_ready = 0;
+            int32_t round = 0;
+            const int32_t max_rounds = 160;   // > 64 + 32 + slack
+            while (root_ready == 0 && round < max_rounds && status == TR_OK) {
+                for (int k = 0; k < 8; k++) {
+                    ++round;
+                    hipLaunchKernelGGL(k_refit_round, dim3(gI), dim3(TB), 0, stream, cl, cr, sbox, ibox, ready, ni, round);
+                }
+                check(hipGetLastError(), "k_refit_round");
+                check(hipMemcpyAsync(&root_ready, ready, sizeof(int32_t), hipMemcpyDeviceToHost, stream), "memcpy root");
+                check(hipStreamSynchronize(stream), "sync refit");
+            }
+            if (status != TR_OK) break;
+            if (root_ready == 0) { status = tr_fail(TR_ERR_INTERNAL, "refit did not reach the root"); break; }
+            bvh->depth = root_ready;
+            bvh->key_mode = mode;
+            if (root_ready <= 64) break;
+            if (mode == 1) { status = tr_fail(TR_ERR_INTERNAL, "tree height > 64 with bounded keys"); break; }
+        }
+        if (status == TR_OK) {
+            hipLaunchKernelGGL(k_emit, dim3(gI), dim3(TB), 0, stream, cl, cr, par, sbox, ibox, ni, bvh->nodes, bvh->links);
+            check(hipGetLastError(), "k_emit");
+        }
+    }
+    // mesh bounds back to the host (also orders the frees below after all kernels)
+    uint32_t hb[8] = {0};
+    check(hipMemcpyAsync(hb, bounds, sizeof(uint32_t) * 6, hipMemcpyDeviceToHost, stream), "memcpy bounds");
+    check(hipStreamSynchronize(stream), "sync build");
+    if (status == TR_OK) {
+        for (int k = 0; k < 3; k++) {
+            uint32_t e0 = hb[k], e1 = hb[3 + k];
+            uint32_t b0 = (e0 & 0x80000000u) ? (e0 & 0x7fffffffu) : ~e0;
+            uint32_t b1 = (e1 & 0x80000000u) ? (e1 & 0x7fffffffu) : ~e1;
+            memcpy(&bvh->aabb_min[k], &b0, 4);
+            memcpy(&bvh->aabb_max[k], &b1, 4);
+        }
+    }
+    hipError_t fe = hipFree(temp);
+    if (fe != hipSuccess && status == TR_OK) status = tr_fail(TR_ERR_HIP, "hipFree(temp)");
+    (void)nv;
+    return status;
+}

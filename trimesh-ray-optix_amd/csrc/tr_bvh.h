@@ -1,0 +1,203 @@
+// tr_bvh.h -- traversal-side data layout of the LBVH and the per-ray traversal core.
+//
+// The core is host+device code on purpose: the HIP kernels (traverse.hip) instantiate it
+// per lane, and tests/host_sim compiles the very same functions with g++ to check the
+// trail/parent-link state machine against the oracle without a GPU.  It is not a CPU
+// fallback: nothing in the C ABI can reach the host instantiation.
+//
+// Layout in HBM (one arena per mesh, see DESIGN.md "Data layout"):
+//   nodes : (F-1) x 64 B   tr_node   both children's boxes + child ids + parent + sibling
+//   links : (F-1) x  8 B   tr_link   {parent, sibling} again, packed 8 per 64-B line, read
+//                                    only while backtracking (keeps the climb off the
+//                                    64-B node lines)
+//   tris  :  F    x 48 B   tr_tri    Morton-ordered copy of the triangle (v0,v1,v2) + the
+//                                    original face index
+// Child ids: c >= 0 internal node index, c < 0 leaf, slot = ~c into `tris`.
+// One triangle per leaf, so the leaf box stored in the parent IS the triangle's exact box
+// and its slab interval is reused as the [tn, tf] of the hit predicate (tr_math.h).
+//
+// Traversal is stackless: a 64-bit trail (bit k set = the node at depth k on the current
+// path still owes its far child) plus parent/sibling links (Hapala 2011 / Afra &
+// Szirmay-Kalos 2014 style backtracking).  The builder guarantees depth <= 64.
+#pragma once
+#include "tr_math.h"
+
+struct alignas(16) tr_f4 {
+    float x, y, z, w;
+};
+struct alignas(16) tr_i4 {
+    int32_t x, y, z, w;
+};
+
+struct alignas(64) tr_node {
+    float lo0[3], hi0[3];  // child 0 box
+    float lo1[3], hi1[3];  // child 1 box
+    int32_t c0, c1;
+    int32_t parent;   // -1 at the root
+    int32_t sibling;  // other child of parent (same encoding as c0/c1); root: 0
+};
+static_assert(sizeof(tr_node) == 64, "node must be 64 B");
+
+struct alignas(8) tr_link {
+    int32_t parent, sibling;
+};
+
+struct alignas(16) tr_tri {
+    float ax, ay, az, bx, by, bz, cx, cy, cz;
+    int32_t face;  // original triangle index
+    int32_t pad0, pad1;
+};
+static_assert(sizeof(tr_tri) == 48, "tri record must be 48 B");
+
+struct tr_bvh_view {
+    const tr_node* nodes;
+    const tr_link* links;
+    const tr_tri* tris;
+    int64_t num_tris;
+};
+
+enum tr_query { TR_Q_ANY = 0, TR_Q_FIRST = 1, TR_Q_CLOSEST = 2, TR_Q_COUNT = 3, TR_Q_LOCATION = 4 };
+
+struct tr_counters {
+    uint32_t nodes, tris, climbs;
+};
+
+// sorted list of the K nearest hits (by (t, face)); static indexing only
+template <int K>
+struct tr_topk {
+    float t[K];
+    int32_t face[K];
+    int32_t slot[K];
+    TR_HDM void init() {
+#pragma unroll
+        for (int i = 0; i < K; i++) { t[i] = INFINITY; face[i] = 0x7fffffff; slot[i] = -1; }
+    }
+    TR_HDM void insert(float nt, int32_t nface, int32_t nslot) {
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            bool lt = tr_closer(nt, nface, t[i], face[i]);
+            float tt = t[i]; int32_t tf_ = face[i], ts = slot[i];
+            t[i] = lt ? nt : tt; face[i] = lt ? nface : tf_; slot[i] = lt ? nslot : ts;
+            nt = lt ? tt : nt; nface = lt ? tf_ : nface; nslot = lt ? ts : nslot;
+        }
+    }
+};
+
+struct tr_result {
+    // closest / first / any
+    float best_t;
+    int32_t best_face;   // -1 = miss
+    int32_t best_slot;
+    float U, V, det;
+    // count
+    int32_t count;
+};
+
+template <bool STATS>
+TR_HD tr_tri tr_load_tri(const tr_bvh_view& b, int32_t slot, tr_counters* cnt) {
+    const tr_f4* p = reinterpret_cast<const tr_f4*>(b.tris + slot);
+    tr_f4 q0 = p[0], q1 = p[1], q2 = p[2];
+    tr_tri t;
+    t.ax = q0.x; t.ay = q0.y; t.az = q0.z; t.bx = q0.w;
+    t.by = q1.x; t.bz = q1.y; t.cx = q1.z; t.cy = q1.w;
+    t.cz = q2.x;
+    union { float f; int32_t i; } u;
+    u.f = q2.y;
+    t.face = u.i;
+    t.pad0 = t.pad1 = 0;
+    if (STATS) cnt->tris++;
+    return t;
+}
+
+// One leaf: evaluate the predicate with the slab interval already computed from the parent's
+// child box and fold the result into the per-query state.
+// returns true when the ray is finished (ANY query, first accepted hit)
+template <int Q, int K, bool STATS>
+TR_HD bool tr_visit_leaf(const tr_bvh_view& b, const tr_ray& r, int32_t slot, float tn, float tf,
+                         tr_result& res, tr_topk<K>& top, tr_counters* cnt) {
+    tr_tri t = tr_load_tri<STATS>(b, slot, cnt);
+    tr_hit h;
+    if (!tr_tri_mt(r, t.ax, t.ay, t.az, t.bx, t.by, t.bz, t.cx, t.cy, t.cz, tn, tf, h)) return false;
+    if (Q == TR_Q_ANY) {
+        res.best_face = t.face;
+        return true;
+    } else if (Q == TR_Q_COUNT) {
+        res.count++;
+    } else if (Q == TR_Q_LOCATION) {
+        res.count++;
+        top.insert(h.t, t.face, slot);
+    } else {
+        if (tr_closer(h.t, t.face, res.best_t, res.best_face < 0 ? 0x7fffffff : res.best_face)) {
+            res.best_t = h.t; res.best_face = t.face; res.best_slot = slot;
+            res.U = h.U; res.V = h.V; res.det = h.det;
+        }
+    }
+    return false;
+}
+
+// Full traversal of one ray.  `valid` = tr_ray_setup's result.
+template <int Q, int K, bool STATS>
+TR_HD void tr_traverse(const tr_bvh_view& b, const tr_ray& r, bool valid, tr_result& res,
+                       tr_topk<K>& top, tr_counters* cnt) {
+    res.best_t = TR_TMAX; res.best_face = -1; res.best_slot = -1;
+    res.U = 0.f; res.V = 0.f; res.det = 1.f; res.count = 0;
+    if (Q == TR_Q_LOCATION) top.init();
+    if (!valid || b.num_tris < 2) return;   // F < 2 is handled by the brute-force kernel
+
+    const bool ordered = (Q == TR_Q_FIRST || Q == TR_Q_CLOSEST);
+    int32_t node = 0;
+    uint32_t depth = 0;
+    uint64_t trail = 0;
+    for (;;) {
+        const tr_f4* np = reinterpret_cast<const tr_f4*>(b.nodes + node);
+        tr_f4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+        if (STATS) cnt->nodes++;
+        // n0 = lo0.xyz hi0.x | n1 = hi0.yz lo1.xy | n2 = lo1.z hi1.xyz | n3 = c0 c1 parent sibling
+        float tn0, tf0, tn1, tf1;
+        tr_slab(r, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tn0, tf0);
+        tr_slab(r, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, tn1, tf1);
+        union { float f; int32_t i; } u0, u1, u2, u3;
+        u0.f = n3.x; u1.f = n3.y; u2.f = n3.z; u3.f = n3.w;
+        const int32_t c0 = u0.i, c1 = u1.i;
+        int32_t parent = u2.i, sibling = u3.i;
+        const float lim = ordered ? res.best_t : TR_TMAX;
+        bool h0 = tr_slab_hit(tn0, tf0, lim);
+        bool h1 = tr_slab_hit(tn1, tf1, lim);
+        // leaves first (they can only shrink best_t)
+        if (h0 && c0 < 0) {
+            if (tr_visit_leaf<Q, K, STATS>(b, r, ~c0, tn0, tf0, res, top, cnt)) return;
+            h0 = false;
+        }
+        if (h1 && c1 < 0) {
+            if (!ordered || tn1 <= res.best_t)
+                if (tr_visit_leaf<Q, K, STATS>(b, r, ~c1, tn1, tf1, res, top, cnt)) return;
+            h1 = false;
+        }
+        if (ordered) {
+            h0 = h0 && (tn0 <= res.best_t);
+            h1 = h1 && (tn1 <= res.best_t);
+        }
+        if (h0 | h1) {
+            if (h0 & h1) {
+                trail |= (1ull << depth);
+                node = (tn1 < tn0) ? c1 : c0;
+            } else {
+                node = h0 ? c0 : c1;
+            }
+            depth++;
+            continue;
+        }
+        // backtrack to the deepest ancestor that still owes its far child
+        if (trail == 0) return;
+        const uint32_t j = 63u - (uint32_t)__builtin_clzll(trail);
+        trail &= ~(1ull << j);
+        while (depth > j + 1) {   // climb; `node` is at `depth`, (parent, sibling) are its links
+            node = parent;
+            const tr_link l = b.links[node];
+            parent = l.parent; sibling = l.sibling;
+            depth--;
+            if (STATS) cnt->climbs++;
+        }
+        node = sibling;           // far child at depth j+1 (internal by construction)
+    }
+}

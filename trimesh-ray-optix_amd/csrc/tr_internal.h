@@ -1,0 +1,72 @@
+// tr_internal.h -- host-side shared declarations of libtriro_hip (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/triro_hip.h"
+#include "tr_bvh.h"
+
+// error plumbing ----------------------------------------------------------------------
+void tr_set_error(const std::string& msg);
+int tr_fail(int code, const std::string& msg);
+
+#define TR_HIP_TRY(expr)                                                                  \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            return tr_fail(_e == hipErrorOutOfMemory ? TR_ERR_OUT_OF_MEMORY : TR_ERR_HIP, \
+                           std::string(#expr) + ": " + hipGetErrorName(_e) + " (" +       \
+                               hipGetErrorString(_e) + ")");                              \
+        }                                                                                 \
+    } while (0)
+
+#define TR_TRY(expr)            \
+    do {                        \
+        int _s = (expr);        \
+        if (_s != TR_OK) return _s; \
+    } while (0)
+
+// the opaque handle ---------------------------------------------------------------------
+struct tr_bvh {
+    int device = 0;
+    int64_t num_tris = 0;
+    int64_t num_nodes = 0;
+    int32_t depth = 0;
+    int32_t key_mode = 0;
+    void* arena = nullptr;      // one hipMalloc: nodes | links | tris
+    int64_t arena_bytes = 0;
+    int64_t capacity_tris = 0;  // arena was sized for this many triangles
+    tr_node* nodes = nullptr;
+    tr_link* links = nullptr;
+    tr_tri* tris = nullptr;
+    float aabb_min[3] = {0, 0, 0};
+    float aabb_max[3] = {0, 0, 0};
+};
+
+// per-device runtime state (tr_init) ------------------------------------------------------
+struct tr_device_state {
+    bool ready = false;
+    int device = 0;
+    int num_cus = 0;
+    int* counters = nullptr;        // ring of work counters for persistent launches
+    unsigned next_counter = 0;
+    void* scratch = nullptr;        // scan partials etc.
+    size_t scratch_bytes = 0;
+};
+constexpr int TR_NUM_COUNTERS = 4096;
+
+int tr_get_device_state(int device, tr_device_state** out);
+int tr_scratch_reserve(tr_device_state* st, size_t bytes, void** out);
+
+// builder (bvh_build.hip) -----------------------------------------------------------------
+int tr_build_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_t* d_faces,
+                  int64_t nf, hipStream_t stream);
+
+// options ---------------------------------------------------------------------------------
+struct tr_options {
+    int persistent = 1;
+    int blocks_per_cu = 8;
+    int refill = 1;
+};
+tr_options& tr_opts();

@@ -1,0 +1,513 @@
+// traverse.hip -- query kernels and their C-ABI launchers (replace the five OptiX pipelines
+// of triro/backend/shaders.cu:67-246 and the launch wrappers of ray.cpp:161-378).
+//
+// One ray per lane, wave64.  Two launch shapes:
+//   persistent : grid = CUs x blocks_per_cu; each wave pulls 64-ray batches from a global
+//                work counter (Aila & Laine style persistent threads) -- no tail of
+//                half-empty workgroups, and the counter ring lets launches overlap.
+//   direct     : grid = ceil(n/256), ray = global thread id.
+// The per-ray state machine is tr_traverse (tr_bvh.h): stackless trail + parent links.
+// Kernel parameters travel by value (no per-call malloc/memcpy/free as in ray.cpp:279-287).
+#include "tr_internal.h"
+
+namespace {
+
+struct RayFetch {
+    const float* o;
+    const float* d;
+    int64_t n;
+    int64_t s0, s1, s2;   // leading dims (right-aligned; unused = INT64_MAX)
+    int64_t os[4], ds[4]; // element strides
+    int omode, dmode;     // 0 dense [n,3], 1 broadcast (all leading strides 0), 2 general
+};
+
+struct QueryOut {
+    uint8_t* hit;
+    uint8_t* front;
+    int32_t* tri;
+    float* loc;
+    float* uv;
+    int32_t* count;
+};
+
+// strided fetch of ray `idx`: the reference's getRay/getIndices (shaders.cu:27-63) with
+// 64-bit index math and fast paths for dense and broadcast tensors
+__device__ __forceinline__ void fetch_ray(const RayFetch& rf, int64_t idx, float* o, float* d) {
+    int64_t i0 = 0, i1 = 0, i2 = 0;
+    if (rf.omode == 2 || rf.dmode == 2) {
+        uint64_t r = (uint64_t)idx;
+        i2 = (int64_t)(r % (uint64_t)rf.s2); r /= (uint64_t)rf.s2;
+        i1 = (int64_t)(r % (uint64_t)rf.s1); r /= (uint64_t)rf.s1;
+        i0 = (int64_t)(r % (uint64_t)rf.s0);
+    }
+    {
+        int64_t off, s3 = rf.os[3];
+        if (rf.omode == 0) { off = idx * 3; s3 = 1; }
+        else if (rf.omode == 1) off = 0;
+        else off = i0 * rf.os[0] + i1 * rf.os[1] + i2 * rf.os[2];
+        o[0] = rf.o[off]; o[1] = rf.o[off + s3]; o[2] = rf.o[off + 2 * s3];
+    }
+    {
+        int64_t off, s3 = rf.ds[3];
+        if (rf.dmode == 0) { off = idx * 3; s3 = 1; }
+        else if (rf.dmode == 1) off = 0;
+        else off = i0 * rf.ds[0] + i1 * rf.ds[1] + i2 * rf.ds[2];
+        d[0] = rf.d[off]; d[1] = rf.d[off + s3]; d[2] = rf.d[off + 2 * s3];
+    }
+}
+
+template <int Q>
+__device__ __forceinline__ void write_result(const tr_bvh_view& b, const QueryOut& out, int64_t i,
+                                             const tr_result& res) {
+    if (Q == TR_Q_ANY) {
+        out.hit[i] = res.best_face >= 0 ? 1 : 0;
+    } else if (Q == TR_Q_FIRST) {
+        out.tri[i] = res.best_face;
+    } else if (Q == TR_Q_COUNT) {
+        out.count[i] = res.count;
+    } else if (Q == TR_Q_CLOSEST) {
+        float loc[3] = {0.f, 0.f, 0.f}, uv[2] = {0.f, 0.f};
+        uint8_t hit = 0, front = 0;
+        if (res.best_face >= 0) {
+            tr_counters* nc = nullptr;
+            tr_tri t = tr_load_tri<false>(b, res.best_slot, nc);
+            tr_hit h; h.t = res.best_t; h.U = res.U; h.V = res.V; h.det = res.det;
+            tr_hit_outputs(h, t.ax, t.ay, t.az, t.bx, t.by, t.bz, t.cx, t.cy, t.cz, loc, uv);
+            hit = 1; front = res.det > 0.f ? 1 : 0;
+        }
+        out.hit[i] = hit;
+        out.front[i] = front;
+        out.tri[i] = res.best_face;
+        out.loc[3 * i] = loc[0]; out.loc[3 * i + 1] = loc[1]; out.loc[3 * i + 2] = loc[2];
+        out.uv[2 * i] = uv[0]; out.uv[2 * i + 1] = uv[1];
+    }
+}
+
+// single-triangle / empty meshes: no hierarchy exists; evaluate the predicate directly
+template <int Q>
+__device__ __forceinline__ void brute_one(const tr_bvh_view& b, const tr_ray& r, bool valid,
+                                          tr_result& res) {
+    res.best_t = TR_TMAX; res.best_face = -1; res.best_slot = -1;
+    res.U = 0.f; res.V = 0.f; res.det = 1.f; res.count = 0;
+    if (!valid || b.num_tris < 1) return;
+    tr_counters* nc = nullptr;
+    tr_tri t = tr_load_tri<false>(b, 0, nc);
+    tr_hit h;
+    if (tr_tri_hit(r, t.ax, t.ay, t.az, t.bx, t.by, t.bz, t.cx, t.cy, t.cz, h)) {
+        res.best_t = h.t; res.best_face = t.face; res.best_slot = 0;
+        res.U = h.U; res.V = h.V; res.det = h.det; res.count = 1;
+    }
+}
+
+template <int Q, bool STATS>
+__device__ __forceinline__ void process_ray(const tr_bvh_view& b, const RayFetch& rf,
+                                            const QueryOut& out, int64_t i, tr_counters* cnt) {
+    float o[3], d[3];
+    fetch_ray(rf, i, o, d);
+    tr_ray r;
+    bool valid = tr_ray_setup(r, o[0], o[1], o[2], d[0], d[1], d[2]);
+    tr_result res;
+    tr_topk<1> top;
+    if (b.num_tris >= 2) tr_traverse<Q, 1, STATS>(b, r, valid, res, top, cnt);
+    else brute_one<Q>(b, r, valid, res);
+    write_result<Q>(b, out, i, res);
+}
+
+template <bool STATS>
+__device__ __forceinline__ void flush_stats(const tr_counters& c, unsigned long long* stats) {
+    if (!STATS) return;
+    unsigned long long a = c.nodes, t = c.tris, k = c.climbs;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        a += __shfl_xor(a, off); t += __shfl_xor(t, off); k += __shfl_xor(k, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&stats[1], a); atomicAdd(&stats[2], t); atomicAdd(&stats[3], k);
+    }
+}
+
+template <int Q, bool STATS>
+__global__ __launch_bounds__(256) void k_query_direct(tr_bvh_view b, RayFetch rf, QueryOut out,
+                                                      unsigned long long* stats) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    tr_counters cnt = {0, 0, 0};
+    if (i < rf.n) process_ray<Q, STATS>(b, rf, out, i, &cnt);
+    flush_stats<STATS>(cnt, stats);
+}
+
+template <int Q, bool STATS>
+__global__ __launch_bounds__(256) void k_query_persistent(tr_bvh_view b, RayFetch rf, QueryOut out,
+                                                          unsigned long long* counter,
+                                                          unsigned long long* stats) {
+    const int lane = threadIdx.x & 63;
+    tr_counters cnt = {0, 0, 0};
+    for (;;) {
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(counter, 64ull);
+        base = __shfl(base, 0);
+        if ((int64_t)base >= rf.n) break;
+        int64_t i = (int64_t)base + lane;
+        if (i < rf.n) process_ray<Q, STATS>(b, rf, out, i, &cnt);
+    }
+    flush_stats<STATS>(cnt, stats);
+}
+
+// ---- multi-hit second pass (shaders.cu:196-246) ----------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void k_location(tr_bvh_view b, RayFetch rf, int32_t cap,
+                                                  const int64_t* __restrict__ offsets,
+                                                  float* __restrict__ loc,
+                                                  int32_t* __restrict__ ray_idx,
+                                                  int32_t* __restrict__ tri_idx, int64_t ray_base) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rf.n) return;
+    float o[3], d[3];
+    fetch_ray(rf, i, o, d);
+    tr_ray r;
+    bool valid = tr_ray_setup(r, o[0], o[1], o[2], d[0], d[1], d[2]);
+    tr_result res;
+    tr_topk<K> top;
+    tr_counters* nc = nullptr;
+    if (b.num_tris >= 2) {
+        tr_traverse<TR_Q_LOCATION, K, false>(b, r, valid, res, top, nc);
+    } else {
+        top.init();
+        brute_one<TR_Q_LOCATION>(b, r, valid, res);
+        if (res.count) top.insert(res.best_t, res.best_face, 0);
+    }
+    int32_t nout = res.count < cap ? res.count : cap;
+    int64_t g = offsets[i];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        if (k < nout) {
+            tr_tri t = tr_load_tri<false>(b, top.slot[k], nc);
+            tr_hit h;
+            // recompute (U, V, det) of the kept hit: same arithmetic, same values
+            tr_tri_hit(r, t.ax, t.ay, t.az, t.bx, t.by, t.bz, t.cx, t.cy, t.cz, h);
+            float l3[3], uv[2];
+            tr_hit_outputs(h, t.ax, t.ay, t.az, t.bx, t.by, t.bz, t.cx, t.cy, t.cz, l3, uv);
+            loc[3 * (g + k)] = l3[0]; loc[3 * (g + k) + 1] = l3[1]; loc[3 * (g + k) + 2] = l3[2];
+            ray_idx[g + k] = (int32_t)(i + ray_base);
+            tri_idx[g + k] = t.face;
+        }
+    }
+}
+
+// ---- scans (replace the torch glue of ray.cpp:333-342 and ray_optix.py:142-144) ---------------
+constexpr int SCAN_ITEMS = 4;
+constexpr int SCAN_BLOCK = 1024;
+constexpr int SCAN_TILE = SCAN_ITEMS * SCAN_BLOCK;
+
+template <typename T>
+__device__ __forceinline__ int64_t scan_value(const T* in, int64_t i, int64_t n, int32_t cap) {
+    if (i >= n) return 0;
+    int64_t v = (int64_t)in[i];
+    if (sizeof(T) == 1) return v != 0 ? 1 : 0;
+    return v < cap ? v : cap;
+}
+
+__device__ __forceinline__ int64_t block_exclusive(int64_t s, int64_t* total_out) {
+    __shared__ int64_t wsum[SCAN_BLOCK / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int64_t inc = s;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int64_t o = __shfl_up(inc, off);
+        if (lane >= off) inc += o;
+    }
+    __syncthreads();
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int64_t wpre = 0, tot = 0;
+    for (int w = 0; w < SCAN_BLOCK / 64; w++) {
+        int64_t x = wsum[w];
+        if (w < wave) wpre += x;
+        tot += x;
+    }
+    *total_out = tot;
+    return wpre + inc - s;
+}
+
+template <typename T>
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_partial(const T* __restrict__ in, int64_t n,
+                                                             int32_t cap,
+                                                             int64_t* __restrict__ partial) {
+    int64_t i0 = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) s += scan_value(in, i0 + k, n, cap);
+    int64_t tot;
+    block_exclusive(s, &tot);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_partials(int64_t* __restrict__ partial,
+                                                              int64_t nblocks,
+                                                              int64_t* __restrict__ total) {
+    __shared__ int64_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < nblocks; base += SCAN_BLOCK) {
+        int64_t i = base + threadIdx.x;
+        int64_t v = i < nblocks ? partial[i] : 0;
+        int64_t tot;
+        int64_t ex = block_exclusive(v, &tot);
+        int64_t carry = carry_s;
+        if (i < nblocks) partial[i] = carry + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry_s;
+}
+
+template <typename T>
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_final(const T* __restrict__ in, int64_t n,
+                                                           int32_t cap,
+                                                           const int64_t* __restrict__ partial,
+                                                           int64_t* __restrict__ offsets) {
+    int64_t i0 = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int64_t v[SCAN_ITEMS], s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) { v[k] = scan_value(in, i0 + k, n, cap); s += v[k]; }
+    int64_t tot;
+    int64_t ex = block_exclusive(s, &tot) + partial[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        if (i0 + k < n) offsets[i0 + k] = ex;
+        ex += v[k];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_compact_closest(
+    const uint8_t* __restrict__ hit, const int64_t* __restrict__ offsets, int64_t n,
+    const uint8_t* __restrict__ front, const int32_t* __restrict__ tri,
+    const float* __restrict__ loc, const float* __restrict__ uv, int64_t ray_base,
+    uint8_t* __restrict__ front_o, int32_t* __restrict__ ray_o, int32_t* __restrict__ tri_o,
+    float* __restrict__ loc_o, float* __restrict__ uv_o) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !hit[i]) return;
+    int64_t j = offsets[i];
+    if (front_o) front_o[j] = front[i];
+    if (ray_o) ray_o[j] = (int32_t)(i + ray_base);
+    if (tri_o) tri_o[j] = tri[i];
+    if (loc_o) { loc_o[3 * j] = loc[3 * i]; loc_o[3 * j + 1] = loc[3 * i + 1]; loc_o[3 * j + 2] = loc[3 * i + 2]; }
+    if (uv_o) { uv_o[2 * j] = uv[2 * i]; uv_o[2 * j + 1] = uv[2 * i + 1]; }
+}
+
+// ---- host side ----------------------------------------------------------------------------------
+int make_fetch(const tr_rays* rays, RayFetch* rf) {
+    if (!rays) return tr_fail(TR_ERR_INVALID_ARG, "rays == NULL");
+    if (rays->nray < 0) return tr_fail(TR_ERR_INVALID_ARG, "nray < 0");
+    if (rays->shape[3] != 3) return tr_fail(TR_ERR_INVALID_ARG, "last ray dimension must be 3");
+    int64_t prod = 1;
+    for (int k = 0; k < 3; k++) {
+        int64_t s = rays->shape[k];
+        if (s == INT64_MAX) continue;
+        if (s < 0) return tr_fail(TR_ERR_INVALID_ARG, "negative ray dimension");
+        prod *= s;
+    }
+    if (prod != rays->nray) return tr_fail(TR_ERR_INVALID_ARG, "nray != product of leading dims");
+    if (rays->nray > 0 && (!rays->d_origins || !rays->d_directions))
+        return tr_fail(TR_ERR_INVALID_ARG, "null ray pointer");
+    rf->o = rays->d_origins; rf->d = rays->d_directions; rf->n = rays->nray;
+    rf->s0 = rays->shape[0]; rf->s1 = rays->shape[1]; rf->s2 = rays->shape[2];
+    auto classify = [&](const int64_t* st) {
+        bool bcast = true, dense = st[3] == 1;
+        int64_t expect = 3;
+        for (int k = 2; k >= 0; k--) {
+            int64_t s = rays->shape[k];
+            if (s == INT64_MAX || s == 1) continue;
+            if (st[k] != 0) bcast = false;
+            if (st[k] != expect) dense = false;
+            expect *= s;
+        }
+        return dense ? 0 : (bcast ? 1 : 2);
+    };
+    for (int k = 0; k < 4; k++) { rf->os[k] = rays->ostride[k]; rf->ds[k] = rays->dstride[k]; }
+    rf->omode = classify(rays->ostride);
+    rf->dmode = classify(rays->dstride);
+    if (rf->s0 == INT64_MAX) rf->s0 = 1;   // keep the general path's divisions cheap and safe
+    if (rf->s1 == INT64_MAX) rf->s1 = 1;
+    if (rf->s2 == INT64_MAX) rf->s2 = 1;
+    if (rf->s0 == 0 || rf->s1 == 0 || rf->s2 == 0) { rf->s0 = rf->s1 = rf->s2 = 1; }
+    return TR_OK;
+}
+
+tr_bvh_view make_view(const tr_bvh* bvh) {
+    tr_bvh_view v;
+    v.nodes = bvh->nodes; v.links = bvh->links; v.tris = bvh->tris; v.num_tris = bvh->num_tris;
+    return v;
+}
+
+template <int Q, bool STATS>
+int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
+                 unsigned long long* d_stats, hipStream_t stream) {
+    if (!bvh) return tr_fail(TR_ERR_INVALID_ARG, "bvh == NULL");
+    RayFetch rf;
+    TR_TRY(make_fetch(rays, &rf));
+    if (rf.n == 0) return TR_OK;
+    tr_device_state* st;
+    TR_TRY(tr_get_device_state(bvh->device, &st));
+    tr_bvh_view view = make_view(bvh);
+    const tr_options& opt = tr_opts();
+    const int64_t nblocks_direct = (rf.n + 255) / 256;
+    int64_t pgrid = (int64_t)st->num_cus * opt.blocks_per_cu;
+    if (opt.persistent && nblocks_direct > pgrid) {
+        unsigned slot = __atomic_fetch_add(&st->next_counter, 1u, __ATOMIC_RELAXED) % TR_NUM_COUNTERS;
+        unsigned long long* counter = reinterpret_cast<unsigned long long*>(st->counters) + slot;
+        TR_HIP_TRY(hipMemsetAsync(counter, 0, sizeof(unsigned long long), stream));
+        hipLaunchKernelGGL((k_query_persistent<Q, STATS>), dim3((unsigned)pgrid), dim3(256), 0, stream,
+                           view, rf, out, counter, d_stats);
+    } else {
+        hipLaunchKernelGGL((k_query_direct<Q, STATS>), dim3((unsigned)nblocks_direct), dim3(256), 0, stream,
+                           view, rf, out, d_stats);
+    }
+    TR_HIP_TRY(hipGetLastError());
+    return TR_OK;
+}
+
+template <typename T>
+int scan_impl(const T* d_in, int64_t n, int32_t cap, int64_t* d_offsets, int64_t* d_total,
+              int64_t* h_total, hipStream_t stream) {
+    if (n < 0) return tr_fail(TR_ERR_INVALID_ARG, "n < 0");
+    if (!d_total) return tr_fail(TR_ERR_INVALID_ARG, "d_total == NULL");
+    if (n > 0 && (!d_in || !d_offsets)) return tr_fail(TR_ERR_INVALID_ARG, "null scan pointer");
+    int dev = 0;
+    TR_HIP_TRY(hipGetDevice(&dev));
+    tr_device_state* st;
+    TR_TRY(tr_get_device_state(dev, &st));
+    if (n == 0) {
+        TR_HIP_TRY(hipMemsetAsync(d_total, 0, sizeof(int64_t), stream));
+    } else {
+        int64_t nblocks = (n + SCAN_TILE - 1) / SCAN_TILE;
+        void* scratch;
+        TR_TRY(tr_scratch_reserve(st, sizeof(int64_t) * (size_t)nblocks, &scratch));
+        int64_t* partial = (int64_t*)scratch;
+        hipLaunchKernelGGL((k_scan_partial<T>), dim3((unsigned)nblocks), dim3(SCAN_BLOCK), 0, stream, d_in, n, cap, partial);
+        hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(SCAN_BLOCK), 0, stream, partial, nblocks, d_total);
+        hipLaunchKernelGGL((k_scan_final<T>), dim3((unsigned)nblocks), dim3(SCAN_BLOCK), 0, stream, d_in, n, cap, partial, d_offsets);
+        TR_HIP_TRY(hipGetLastError());
+    }
+    if (h_total) {
+        TR_HIP_TRY(hipMemcpyAsync(h_total, d_total, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+        TR_HIP_TRY(hipStreamSynchronize(stream));
+    }
+    return TR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tr_intersects_any(const tr_bvh* bvh, const tr_rays* rays, uint8_t* d_hit, void* stream) {
+    if (!d_hit && rays && rays->nray > 0) return tr_fail(TR_ERR_INVALID_ARG, "d_hit == NULL");
+    QueryOut out = {d_hit, nullptr, nullptr, nullptr, nullptr, nullptr};
+    return launch_query<TR_Q_ANY, false>(bvh, rays, out, nullptr, (hipStream_t)stream);
+}
+
+int tr_intersects_first(const tr_bvh* bvh, const tr_rays* rays, int32_t* d_tri, void* stream) {
+    if (!d_tri && rays && rays->nray > 0) return tr_fail(TR_ERR_INVALID_ARG, "d_tri == NULL");
+    QueryOut out = {nullptr, nullptr, d_tri, nullptr, nullptr, nullptr};
+    return launch_query<TR_Q_FIRST, false>(bvh, rays, out, nullptr, (hipStream_t)stream);
+}
+
+int tr_intersects_closest(const tr_bvh* bvh, const tr_rays* rays, uint8_t* d_hit, uint8_t* d_front,
+                          int32_t* d_tri, float* d_loc, float* d_uv, void* stream) {
+    if (rays && rays->nray > 0 && (!d_hit || !d_front || !d_tri || !d_loc || !d_uv))
+        return tr_fail(TR_ERR_INVALID_ARG, "null output pointer");
+    QueryOut out = {d_hit, d_front, d_tri, d_loc, d_uv, nullptr};
+    return launch_query<TR_Q_CLOSEST, false>(bvh, rays, out, nullptr, (hipStream_t)stream);
+}
+
+int tr_intersects_count(const tr_bvh* bvh, const tr_rays* rays, int32_t* d_count, void* stream) {
+    if (!d_count && rays && rays->nray > 0) return tr_fail(TR_ERR_INVALID_ARG, "d_count == NULL");
+    QueryOut out = {nullptr, nullptr, nullptr, nullptr, nullptr, d_count};
+    return launch_query<TR_Q_COUNT, false>(bvh, rays, out, nullptr, (hipStream_t)stream);
+}
+
+int tr_hits_scan(const int32_t* d_count, int64_t n, int32_t cap, int64_t* d_offsets,
+                 int64_t* d_total, int64_t* h_total, void* stream) {
+    if (cap < 0) return tr_fail(TR_ERR_INVALID_ARG, "cap < 0");
+    return scan_impl<int32_t>(d_count, n, cap, d_offsets, d_total, h_total, (hipStream_t)stream);
+}
+
+int tr_mask_scan(const uint8_t* d_hit, int64_t n, int64_t* d_offsets, int64_t* d_total,
+                 int64_t* h_total, void* stream) {
+    return scan_impl<uint8_t>(d_hit, n, 1, d_offsets, d_total, h_total, (hipStream_t)stream);
+}
+
+int tr_intersects_location_fill(const tr_bvh* bvh, const tr_rays* rays, int32_t cap,
+                                const int64_t* d_offsets, float* d_loc, int32_t* d_ray_idx,
+                                int32_t* d_tri_idx, int64_t ray_base, void* stream) {
+    if (!bvh) return tr_fail(TR_ERR_INVALID_ARG, "bvh == NULL");
+    if (cap < 0 || cap > TR_MAX_HITS_CAP) return tr_fail(TR_ERR_INVALID_ARG, "cap out of range");
+    RayFetch rf;
+    TR_TRY(make_fetch(rays, &rf));
+    if (rf.n == 0 || cap == 0) return TR_OK;
+    if (!d_offsets) return tr_fail(TR_ERR_INVALID_ARG, "d_offsets == NULL");
+    tr_bvh_view view = make_view(bvh);
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)((rf.n + 255) / 256)), block(256);
+    if (cap <= 8)
+        hipLaunchKernelGGL(k_location<8>, grid, block, 0, s, view, rf, cap, d_offsets, d_loc, d_ray_idx, d_tri_idx, ray_base);
+    else if (cap <= 16)
+        hipLaunchKernelGGL(k_location<16>, grid, block, 0, s, view, rf, cap, d_offsets, d_loc, d_ray_idx, d_tri_idx, ray_base);
+    else
+        hipLaunchKernelGGL(k_location<32>, grid, block, 0, s, view, rf, cap, d_offsets, d_loc, d_ray_idx, d_tri_idx, ray_base);
+    TR_HIP_TRY(hipGetLastError());
+    return TR_OK;
+}
+
+int tr_compact_closest(const uint8_t* d_hit, const int64_t* d_offsets, int64_t n,
+                       const uint8_t* d_front, const int32_t* d_tri, const float* d_loc,
+                       const float* d_uv, int64_t ray_base, uint8_t* d_front_out,
+                       int32_t* d_ray_idx_out, int32_t* d_tri_out, float* d_loc_out,
+                       float* d_uv_out, void* stream) {
+    if (n < 0) return tr_fail(TR_ERR_INVALID_ARG, "n < 0");
+    if (n == 0) return TR_OK;
+    if (!d_hit || !d_offsets) return tr_fail(TR_ERR_INVALID_ARG, "null mask/offsets");
+    if ((d_front_out && !d_front) || (d_tri_out && !d_tri) || (d_loc_out && !d_loc) || (d_uv_out && !d_uv))
+        return tr_fail(TR_ERR_INVALID_ARG, "output requested without its input");
+    hipLaunchKernelGGL(k_compact_closest, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       d_hit, d_offsets, n, d_front, d_tri, d_loc, d_uv, ray_base, d_front_out,
+                       d_ray_idx_out, d_tri_out, d_loc_out, d_uv_out);
+    TR_HIP_TRY(hipGetLastError());
+    return TR_OK;
+}
+
+int tr_trace_stats_closest(const tr_bvh* bvh, const tr_rays* rays, tr_trace_stats* h_stats,
+                           void* stream) {
+    if (!bvh || !rays || !h_stats) return tr_fail(TR_ERR_INVALID_ARG, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    int64_t n = rays->nray;
+    unsigned long long* d_stats = nullptr;
+    uint8_t *hit = nullptr;
+    size_t per_ray = 1 + 1 + 4 + 12 + 8;
+    TR_HIP_TRY(hipMalloc((void**)&d_stats, 64));
+    hipError_t e = hipMalloc((void**)&hit, per_ray * (size_t)(n > 0 ? n : 1) + 64);
+    if (e != hipSuccess) { (void)hipFree(d_stats); return tr_fail(TR_ERR_OUT_OF_MEMORY, "stats outputs"); }
+    // carve 4-byte aligned outputs
+    size_t nn = (size_t)(n > 0 ? n : 1);
+    float* loc = (float*)hit;                       // 12 n
+    float* uv = loc + 3 * nn;                       // 8 n
+    int32_t* tri = (int32_t*)(uv + 2 * nn);         // 4 n
+    uint8_t* hitp = (uint8_t*)(tri + nn);           // n
+    uint8_t* front = hitp + nn;                     // n
+    int status = TR_OK;
+    if (hipMemsetAsync(d_stats, 0, 64, s) != hipSuccess) status = tr_fail(TR_ERR_HIP, "memset stats");
+    if (status == TR_OK) {
+        QueryOut out = {hitp, front, tri, loc, uv, nullptr};
+        status = launch_query<TR_Q_CLOSEST, true>(bvh, rays, out, d_stats, s);
+    }
+    unsigned long long h[4] = {0, 0, 0, 0};
+    if (status == TR_OK && hipMemcpyAsync(h, d_stats, 32, hipMemcpyDeviceToHost, s) != hipSuccess)
+        status = tr_fail(TR_ERR_HIP, "memcpy stats");
+    if (hipStreamSynchronize(s) != hipSuccess && status == TR_OK) status = tr_fail(TR_ERR_HIP, "sync stats");
+    (void)hipFree(d_stats);
+    (void)hipFree(hit);
+    h_stats->rays = (uint64_t)n; h_stats->node_visits = h[1]; h_stats->tri_tests = h[2]; h_stats->climb_steps = h[3];
+    return status;
+}
+
+}  // extern "C"

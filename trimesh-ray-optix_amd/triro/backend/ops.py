@@ -1,0 +1,304 @@
+"""Python op shims over the C ABI of libtriro_hip.so (include/triro_hip.h).
+
+Mirrors triro/backend/ops.py of the reference function for function:
+
+  get_module()                                   ops.py:12-46   (JIT build + import of the
+                                                 pybind11 module) -> ctypes load of the
+                                                 PREBUILT library; no JIT, no pybind11
+  init_optix ... build_sbts                      ops.py:49-81   -> tr_init (idempotent)
+  intersects_any/first/closest/count/location    ops.py:84-192  -> tr_intersects_*
+
+Differences that are deliberate: inputs are validated and errors raise
+(ValueError / RuntimeError) instead of printing and returning undefined tensors
+(ray.cpp:104-123,164-165); float32 is enforced (the reference silently reinterprets other
+dtypes); work is enqueued on torch's CURRENT stream of the tensors' device instead of a
+private stream (base.cpp:34); outputs are allocated here with torch.empty and handed to the
+library as raw pointers.
+
+There is no CPU fallback: without the library or without a GPU every query raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Tuple
+
+import torch
+
+_INT64_MAX = (1 << 63) - 1
+MAX_ANYHIT_SIZE = 8   # LaunchParams.h:8
+MAX_SIZE_LENGTH = 4   # LaunchParams.h:9
+
+_LIB_NAME = "libtriro_hip.so"
+_lib = None
+_lib_error = None
+
+
+class TrRays(C.Structure):
+    """tr_rays (include/triro_hip.h) == RayInput of LaunchParams.h:11-28."""
+    _fields_ = [("d_origins", C.c_void_p), ("d_directions", C.c_void_p), ("nray", C.c_int64),
+                ("shape", C.c_int64 * 4), ("ostride", C.c_int64 * 4), ("dstride", C.c_int64 * 4)]
+
+
+class TrBvhInfo(C.Structure):
+    _fields_ = [("device", C.c_int32), ("num_tris", C.c_int64), ("num_nodes", C.c_int64),
+                ("depth", C.c_int32), ("key_mode", C.c_int32), ("arena_bytes", C.c_int64),
+                ("node_bytes", C.c_int64), ("tri_bytes", C.c_int64),
+                ("aabb_min", C.c_float * 3), ("aabb_max", C.c_float * 3)]
+
+
+class TrTraceStats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64),
+                ("climb_steps", C.c_uint64)]
+
+
+def library_path() -> str:
+    env = os.environ.get("TRIRO_HIP_LIBRARY")
+    if env:
+        return env
+    return os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))),
+                        "lib", _LIB_NAME)
+
+
+# every symbol include/triro_hip.h declares: (restype, argtypes)
+_vp, _i64, _i32, _int = C.c_void_p, C.c_int64, C.c_int32, C.c_int
+ABI = {
+    "tr_init": (_int, [_int]),
+    "tr_abi_version": (_int, []),
+    "tr_last_error": (C.c_char_p, []),
+    "tr_bvh_build": (_int, [_vp, _i64, _vp, _i64, _vp, C.POINTER(_vp)]),
+    "tr_bvh_update": (_int, [_vp, _vp, _i64, _vp, _i64, _vp]),
+    "tr_bvh_destroy": (_int, [_vp]),
+    "tr_bvh_get_info": (_int, [_vp, C.POINTER(TrBvhInfo)]),
+    "tr_bvh_download": (_int, [_vp, _vp, _vp, _vp, _vp]),
+    "tr_intersects_any": (_int, [_vp, C.POINTER(TrRays), _vp, _vp]),
+    "tr_intersects_first": (_int, [_vp, C.POINTER(TrRays), _vp, _vp]),
+    "tr_intersects_closest": (_int, [_vp, C.POINTER(TrRays), _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tr_intersects_count": (_int, [_vp, C.POINTER(TrRays), _vp, _vp]),
+    "tr_hits_scan": (_int, [_vp, _i64, _i32, _vp, _vp, C.POINTER(_i64), _vp]),
+    "tr_intersects_location_fill": (_int, [_vp, C.POINTER(TrRays), _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "tr_mask_scan": (_int, [_vp, _i64, _vp, _vp, C.POINTER(_i64), _vp]),
+    "tr_compact_closest": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tr_trace_stats_closest": (_int, [_vp, C.POINTER(TrRays), C.POINTER(TrTraceStats), _vp]),
+    "tr_set_option": (_int, [C.c_char_p, _i64]),
+}
+
+
+def get_module():
+    """Load libtriro_hip.so (the counterpart of ops.py:12-46's JIT build + import)."""
+    global _lib, _lib_error
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        _lib_error = (f"{path} not found: build it with `make -C trimesh-ray-optix_amd/csrc` "
+                      f"(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+                      f"There is no CPU fallback.")
+        raise RuntimeError(_lib_error)
+    lib = C.CDLL(path)
+    for name, (res, args) in ABI.items():
+        fn = getattr(lib, name)   # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.tr_abi_version() != 1:
+        raise RuntimeError("libtriro_hip.so ABI version mismatch")
+    _lib = lib
+    return _lib
+
+
+def _check(status: int):
+    if status != 0:
+        msg = get_module().tr_last_error().decode("utf-8", "replace")
+        if status == 1:
+            raise ValueError(f"triro_hip: {msg}")
+        raise RuntimeError(f"triro_hip (status {status}): {msg}")
+
+
+# --- the five bring-up shims of ops.py:49-81 --------------------------------------------------
+def init_optix():
+    """ops.py:49-53.  Loads the library; initialises the current GPU if there is one."""
+    try:
+        lib = get_module()
+    except RuntimeError:
+        return   # import must not fail without the library; queries will
+    if torch.cuda.is_available():
+        _check(lib.tr_init(torch.cuda.current_device()))
+
+
+def create_optix_context():
+    """ops.py:56-60 -- nothing left to do (no OptiX context on gfx950)."""
+
+
+def create_optix_module():
+    """ops.py:63-67 -- kernels are linked into libtriro_hip.so."""
+
+
+def create_optix_pipelines():
+    """ops.py:70-74 -- the five pipelines are five kernel instantiations."""
+
+
+def build_sbts():
+    """ops.py:77-81 -- no shader binding tables."""
+
+
+# --- marshaling -------------------------------------------------------------------------------
+def _stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _fill4(vals, default):
+    """fillArray of ray.cpp:151-159: right-align into MAX_SIZE_LENGTH slots."""
+    vals = list(vals)
+    return (C.c_int64 * 4)(*([default] * (MAX_SIZE_LENGTH - len(vals)) + vals))
+
+
+def check_rays(origins: torch.Tensor, dirs: torch.Tensor):
+    """tensorInputCheck (ray.cpp:104-123) plus the checks the reference forgets."""
+    for name, t in (("origins", origins), ("directions", dirs)):
+        if not isinstance(t, torch.Tensor):
+            raise ValueError(f"{name} must be a torch.Tensor")
+        if not t.is_cuda:
+            raise ValueError(f"{name} must reside on a GPU (cuda/HIP) device")
+        if t.layout != torch.strided:
+            raise ValueError(f"{name} layout must be torch.strided")
+        if t.dtype != torch.float32:
+            raise ValueError(f"{name} must be float32, got {t.dtype}")
+        if t.dim() < 1 or t.dim() > MAX_SIZE_LENGTH or t.shape[-1] != 3:
+            raise ValueError(f"{name} must have shape [*b, 3] with at most 3 batch dims, got {tuple(t.shape)}")
+    if origins.shape != dirs.shape:
+        raise ValueError(f"origins {tuple(origins.shape)} and directions {tuple(dirs.shape)} differ in shape")
+    if origins.device != dirs.device:
+        raise ValueError("origins and directions are on different devices")
+
+
+def make_rays(origins: torch.Tensor, dirs: torch.Tensor) -> TrRays:
+    """LaunchParams marshaling of ray.cpp:173-179."""
+    r = TrRays()
+    r.d_origins = origins.data_ptr()
+    r.d_directions = dirs.data_ptr()
+    r.nray = origins.numel() // 3
+    r.shape = _fill4(origins.shape, _INT64_MAX)
+    r.ostride = _fill4(origins.stride(), 0)
+    r.dstride = _fill4(dirs.stride(), 0)
+    return r
+
+
+def _handle(accel_structure):
+    h = accel_structure._inner
+    if not h:
+        raise RuntimeError("acceleration structure has not been built")
+    return h
+
+
+# --- queries (ops.py:84-192) ----------------------------------------------------------------------
+def intersects_any(accel_structure, origins, dirs) -> torch.Tensor:
+    """ops.py:84-100 / ray.cpp:161-189.  Bool[*b]."""
+    check_rays(origins, dirs)
+    out = torch.empty(origins.shape[:-1], dtype=torch.bool, device=origins.device)
+    with torch.cuda.device(origins.device):
+        _check(get_module().tr_intersects_any(_handle(accel_structure), C.byref(make_rays(origins, dirs)),
+                                              out.data_ptr(), _stream_ptr(origins.device)))
+    return out
+
+
+def intersects_first(accel_structure, origins, dirs) -> torch.Tensor:
+    """ops.py:103-119 / ray.cpp:191-219.  Int32[*b], -1 on miss."""
+    check_rays(origins, dirs)
+    out = torch.empty(origins.shape[:-1], dtype=torch.int32, device=origins.device)
+    with torch.cuda.device(origins.device):
+        _check(get_module().tr_intersects_first(_handle(accel_structure), C.byref(make_rays(origins, dirs)),
+                                                out.data_ptr(), _stream_ptr(origins.device)))
+    return out
+
+
+def intersects_closest(accel_structure, origins, dirs) -> Tuple[torch.Tensor, ...]:
+    """ops.py:122-149 / ray.cpp:231-289.  (hit, front, tri_idx, loc, uv)."""
+    check_rays(origins, dirs)
+    b, dev = origins.shape[:-1], origins.device
+    hit = torch.empty(b, dtype=torch.bool, device=dev)
+    front = torch.empty(b, dtype=torch.bool, device=dev)
+    tri = torch.empty(b, dtype=torch.int32, device=dev)
+    loc = torch.empty((*b, 3), dtype=torch.float32, device=dev)
+    uv = torch.empty((*b, 2), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _check(get_module().tr_intersects_closest(
+            _handle(accel_structure), C.byref(make_rays(origins, dirs)), hit.data_ptr(), front.data_ptr(),
+            tri.data_ptr(), loc.data_ptr(), uv.data_ptr(), _stream_ptr(dev)))
+    return hit, front, tri, loc, uv
+
+
+def intersects_count(accel_structure, origins, dirs) -> torch.Tensor:
+    """ops.py:152-168 / ray.cpp:291-322.  Int32[*b]."""
+    check_rays(origins, dirs)
+    out = torch.empty(origins.shape[:-1], dtype=torch.int32, device=origins.device)
+    with torch.cuda.device(origins.device):
+        _check(get_module().tr_intersects_count(_handle(accel_structure), C.byref(make_rays(origins, dirs)),
+                                                out.data_ptr(), _stream_ptr(origins.device)))
+    return out
+
+
+def intersects_location(accel_structure, origins, dirs, ray_base: int = 0) -> Tuple[torch.Tensor, ...]:
+    """ops.py:171-192 / ray.cpp:324-378.  (loc[h,3], ray_idx[h], tri_idx[h]); at most
+    MAX_ANYHIT_SIZE hits per ray, grouped by ray; within a ray ordered by distance (the
+    reference leaves that order unspecified)."""
+    check_rays(origins, dirs)
+    dev = origins.device
+    lib = get_module()
+    n = origins.numel() // 3
+    with torch.cuda.device(dev):
+        stream = _stream_ptr(dev)
+        rays = make_rays(origins, dirs)
+        count = torch.empty(n, dtype=torch.int32, device=dev)
+        _check(lib.tr_intersects_count(_handle(accel_structure), C.byref(rays), count.data_ptr(), stream))
+        offsets = torch.empty(n, dtype=torch.int64, device=dev)
+        total_d = torch.empty(1, dtype=torch.int64, device=dev)
+        total = C.c_int64(0)
+        _check(lib.tr_hits_scan(count.data_ptr(), n, MAX_ANYHIT_SIZE, offsets.data_ptr(), total_d.data_ptr(),
+                                C.byref(total), stream))   # host sync == ray.cpp:339 .item<int>()
+        nhits = int(total.value)
+        loc = torch.empty((nhits, 3), dtype=torch.float32, device=dev)
+        tri = torch.empty(nhits, dtype=torch.int32, device=dev)
+        ray = torch.empty(nhits, dtype=torch.int32, device=dev)
+        _check(lib.tr_intersects_location_fill(_handle(accel_structure), C.byref(rays), MAX_ANYHIT_SIZE,
+                                               offsets.data_ptr(), loc.data_ptr(), ray.data_ptr(),
+                                               tri.data_ptr(), ray_base, stream))
+    return loc, ray, tri
+
+
+def compact_closest(hit, front, tri, loc, uv, ray_base: int = 0):
+    """Fused stream compaction (ray_optix.py:142-144: five boolean-mask gathers, one host
+    sync each) -> one scan + one gather kernel, one host sync for the size.
+    Returns (front[h], ray_idx[h], tri[h], loc[h,3], uv[h,2])."""
+    dev = hit.device
+    lib = get_module()
+    n = hit.numel()
+    with torch.cuda.device(dev):
+        stream = _stream_ptr(dev)
+        offsets = torch.empty(n, dtype=torch.int64, device=dev)
+        total_d = torch.empty(1, dtype=torch.int64, device=dev)
+        total = C.c_int64(0)
+        _check(lib.tr_mask_scan(hit.data_ptr(), n, offsets.data_ptr(), total_d.data_ptr(), C.byref(total), stream))
+        h = int(total.value)
+        front_o = torch.empty(h, dtype=torch.bool, device=dev) if front is not None else None
+        ray_o = torch.empty(h, dtype=torch.int32, device=dev)
+        tri_o = torch.empty(h, dtype=torch.int32, device=dev) if tri is not None else None
+        loc_o = torch.empty((h, 3), dtype=torch.float32, device=dev) if loc is not None else None
+        uv_o = torch.empty((h, 2), dtype=torch.float32, device=dev) if uv is not None else None
+        p = lambda t: t.data_ptr() if t is not None else None
+        _check(lib.tr_compact_closest(hit.data_ptr(), offsets.data_ptr(), n, p(front), p(tri), p(loc), p(uv),
+                                      ray_base, p(front_o), ray_o.data_ptr(), p(tri_o), p(loc_o), p(uv_o), stream))
+    return front_o, ray_o, tri_o, loc_o, uv_o
+
+
+def trace_stats_closest(accel_structure, origins, dirs) -> dict:
+    """Diagnostic: per-launch traversal counters of the instrumented closest-hit kernel."""
+    check_rays(origins, dirs)
+    st = TrTraceStats()
+    with torch.cuda.device(origins.device):
+        _check(get_module().tr_trace_stats_closest(_handle(accel_structure), C.byref(make_rays(origins, dirs)),
+                                                   C.byref(st), _stream_ptr(origins.device)))
+    return dict(rays=st.rays, node_visits=st.node_visits, tri_tests=st.tri_tests, climb_steps=st.climb_steps)
+
+
+def set_option(name: str, value: int):
+    _check(get_module().tr_set_option(name.encode(), int(value)))

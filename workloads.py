@@ -1,0 +1,226 @@
+"""Synthetic meshes and ray batches for tests and bench.py (NOT product code).
+
+Everything is a deterministic function of its arguments (no network, no files):
+  * icosphere(subdivisions)           -- trimesh.creation.icosphere's construction
+    (icosahedron of Andreas Kahler's ordering, midpoint subdivision, renormalise);
+    80 tris at 1 subdivision (BASELINE.json config 1), 1 310 720 at 8 (headline)
+  * displaced(...)                    -- smooth radial displacement ("noise", seed)
+  * nested_shells(...)                -- BASELINE.md config C4 (<= 8 hits per ray)
+  * ortho_grid / readme_perspective   -- README.md:35-39, test/test.py:17-24 inputs
+  * pinhole_grid                      -- BASELINE.md C2/C5(i): 40 deg vFOV, raster order
+  * hash_rays                         -- BASELINE.md C3/C5(ii): pure function of the
+    global ray index; numpy and torch versions produce identical bits
+"""
+from __future__ import annotations
+
+import numpy as np
+
+# ----------------------------------------------------------------------------
+# meshes
+# ----------------------------------------------------------------------------
+
+
+def icosahedron():
+    t = (1.0 + 5.0 ** 0.5) / 2.0
+    v = np.array([-1, t, 0, 1, t, 0, -1, -t, 0, 1, -t, 0,
+                  0, -1, t, 0, 1, t, 0, -1, -t, 0, 1, -t,
+                  t, 0, -1, t, 0, 1, -t, 0, -1, -t, 0, 1], dtype=np.float64).reshape(-1, 3)
+    f = np.array([0, 11, 5, 0, 5, 1, 0, 1, 7, 0, 7, 10, 0, 10, 11,
+                  1, 5, 9, 5, 11, 4, 11, 10, 2, 10, 7, 6, 7, 1, 8,
+                  3, 9, 4, 3, 4, 2, 3, 2, 6, 3, 6, 8, 3, 8, 9,
+                  4, 9, 5, 2, 4, 11, 6, 2, 10, 8, 6, 7, 9, 8, 1], dtype=np.int64).reshape(-1, 3)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    return v, f
+
+
+def _subdivide(v, f):
+    e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]], 0)
+    e.sort(axis=1)
+    key = e[:, 0] * np.int64(len(v)) + e[:, 1]
+    uniq, inv = np.unique(key, return_inverse=True)
+    a, b = uniq // len(v), uniq % len(v)
+    mid = 0.5 * (v[a] + v[b])
+    nf = len(f)
+    m01 = inv[:nf] + len(v)
+    m12 = inv[nf:2 * nf] + len(v)
+    m20 = inv[2 * nf:] + len(v)
+    v2 = np.concatenate([v, mid], 0)
+    f2 = np.concatenate([
+        np.stack([f[:, 0], m01, m20], 1),
+        np.stack([f[:, 1], m12, m01], 1),
+        np.stack([f[:, 2], m20, m12], 1),
+        np.stack([m01, m12, m20], 1)], 0)
+    return v2, f2
+
+
+def icosphere(subdivisions: int = 3, radius: float = 1.0):
+    """Unit icosphere, outward-wound (CCW seen from outside): 20*4^s faces."""
+    v, f = icosahedron()
+    for _ in range(subdivisions):
+        v, f = _subdivide(v, f)
+        v /= np.linalg.norm(v, axis=1, keepdims=True)
+    return (v * radius).astype(np.float32), f.astype(np.int32)
+
+
+def displaced(v, seed: int = 0, amplitude: float = 0.08, octaves: int = 3):
+    """Smooth deterministic radial displacement of a star-shaped mesh about 0."""
+    rng = np.random.default_rng(seed)
+    v64 = v.astype(np.float64)
+    r = np.linalg.norm(v64, axis=1, keepdims=True)
+    n = v64 / r
+    disp = np.zeros(len(v64))
+    for k in range(octaves):
+        for _ in range(4):
+            axis = rng.normal(size=3)
+            axis /= np.linalg.norm(axis)
+            freq = (3.0 * 2 ** k) * (0.75 + 0.5 * rng.random())
+            phase = rng.random() * 2 * np.pi
+            disp += (0.5 ** k) * np.sin(freq * (n @ axis) * np.pi + phase) / 4.0
+    return (v64 * (1.0 + amplitude * disp[:, None])).astype(np.float32)
+
+
+def bunny_standin():
+    """BASELINE.md C2 stand-in (no Stanford bunny file in this image): icosphere(6)
+    = 81 920 tris with 3-octave displacement, seed 0.  Always labelled 'stand-in'."""
+    v, f = icosphere(6)
+    return displaced(v, seed=0, amplitude=0.12), f
+
+
+def headline_mesh(subdivisions: int = 8):
+    """icosphere(8) = 1 310 720 tris + displacement, seed 0."""
+    v, f = icosphere(subdivisions)
+    return displaced(v, seed=0, amplitude=0.08), f
+
+
+def nested_shells(subdivisions: int = 7, radii=(1.0, 0.8, 0.6, 0.4)):
+    """concentric icospheres; central rays have 2*len(radii) hits."""
+    v0, f0 = icosphere(subdivisions)
+    vs, fs = [], []
+    for i, r in enumerate(radii):
+        vs.append(v0 * np.float32(r))
+        fs.append(f0 + np.int32(i * len(v0)))
+    return np.concatenate(vs, 0), np.concatenate(fs, 0)
+
+
+def two_triangles():
+    """test/test.py:47-58 geometry."""
+    v = np.array([[0.5, -0.5, 0], [0, 0.5, 0], [-0.5, -0.5, 0],
+                  [0.5, -0.5, -1], [0, 0.5, -1], [-0.5, -0.5, -1]], np.float32)
+    f = np.array([[0, 1, 2], [3, 4, 5]], np.int32)
+    return v, f
+
+
+def random_soup(n_tris: int, seed: int = 0, extent: float = 1.0, size: float = 0.2):
+    """Unstructured triangle soup (overlapping, arbitrary winding)."""
+    rng = np.random.default_rng(seed)
+    c = (rng.random((n_tris, 1, 3)) * 2 - 1) * extent
+    v = (c + (rng.random((n_tris, 3, 3)) * 2 - 1) * size).reshape(-1, 3).astype(np.float32)
+    f = np.arange(3 * n_tris, dtype=np.int32).reshape(-1, 3)
+    return v, f
+
+
+def deep_tree_mesh(reps: int = 4000):
+    """Adversarial input for the builder: 63 tiny triangles whose Morton codes are the single
+    bits 1<<j plus a run of `reps` identical triangles at the origin -> a Karras tree of
+    height 63 + log2(reps) > 64 with plain Morton keys (forces the depth-bounded key mode)."""
+    tri = np.array([[0, 0, 0], [1e-9, 0, 0], [0, 1e-9, 0]], np.float32)
+    cs = [np.ones(3)]
+    for j in range(63):
+        c = np.zeros(3)
+        c[2 - (j % 3)] = 2.0 ** (j // 3 - 21)
+        cs.append(c)
+    vs = [tri + c.astype(np.float32) for c in cs] + [tri.copy() for _ in range(reps)]
+    v = np.concatenate(vs).astype(np.float32)
+    return v, np.arange(len(v), dtype=np.int32).reshape(-1, 3)
+
+
+# ----------------------------------------------------------------------------
+# rays (numpy; float32)
+# ----------------------------------------------------------------------------
+
+
+def ortho_grid(n: int = 800, z: float = 3.0):
+    """BASELINE config 1: origins (x, y, z), x in linspace(-1,1,n), y in linspace(1,-1,n),
+    direction (0,0,-1).  Shapes [n,n,3]."""
+    y, x = np.meshgrid(np.linspace(1, -1, n, dtype=np.float32),
+                       np.linspace(-1, 1, n, dtype=np.float32), indexing="ij")
+    o = np.stack([x, y, np.full_like(x, z)], -1)
+    d = np.broadcast_to(np.array([0, 0, -1], np.float32), o.shape)
+    return o, d
+
+
+def readme_perspective(n: int = 800):
+    """README.md:35-39: stride-0 origin (0,0,3), un-normalised directions (x,y,-1)."""
+    y, x = np.meshgrid(np.linspace(1, -1, n, dtype=np.float32),
+                       np.linspace(-1, 1, n, dtype=np.float32), indexing="ij")
+    d = np.stack([x, y, -np.ones_like(x)], -1)
+    o = np.broadcast_to(np.array([0, 0, 3], np.float32), d.shape)
+    return o, d
+
+
+def pinhole_grid(width: int = 1024, height: int = 1024, vfov_deg: float = 40.0,
+                 distance: float = 2.5, center=(0.0, 0.0, 0.0)):
+    """Camera on +z at `distance` from `center`, looking down -z; unit directions,
+    raster order (row 0 = top).  Origins are a stride-0 broadcast like the README."""
+    f = 0.5 * height / np.tan(np.radians(vfov_deg) / 2)
+    ys, xs = np.meshgrid(np.arange(height, dtype=np.float64), np.arange(width, dtype=np.float64),
+                         indexing="ij")
+    x = xs - (width - 1) / 2
+    y = (height - 1) / 2 - ys
+    d = np.stack([x, y, -np.full_like(x, f)], -1)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    c = np.asarray(center, np.float64)
+    o = np.broadcast_to((c + np.array([0, 0, distance])).astype(np.float32), d.shape)
+    return o, d.astype(np.float32)
+
+
+_M32 = 0xFFFFFFFF
+
+
+def _hash32_np(x):
+    x = x & _M32
+    x ^= x >> 16
+    x = (x * 0x7FEB352D) & _M32
+    x ^= x >> 15
+    x = (x * 0x846CA68B) & _M32
+    x ^= x >> 16
+    return x
+
+
+def hash_rays(n: int, seed: int, lo, hi, start: int = 0):
+    """n rays from an integer hash of (global index, seed, channel).
+    origins uniform in [lo,hi]^3 (per-axis arrays), directions uniform in [-1,1)^3,
+    NOT normalised.  Value = (h >> 8) * 2^-24 mapped affinely, all in float32."""
+    idx = np.arange(start, start + n, dtype=np.uint64)
+    lo = np.asarray(lo, np.float32)
+    hi = np.asarray(hi, np.float32)
+    out = []
+    for ch in range(6):
+        h = _hash32_np(idx * np.uint64(6) + np.uint64(ch) + (np.uint64(seed) << np.uint64(20)))
+        out.append(((h >> np.uint64(8)).astype(np.float32)) * np.float32(2.0 ** -24))
+    o = np.stack([lo[i] + out[i] * (hi[i] - lo[i]) for i in range(3)], -1).astype(np.float32)
+    d = np.stack([out[3 + i] * np.float32(2.0) - np.float32(1.0) for i in range(3)], -1)
+    return o, d.astype(np.float32)
+
+
+def hash_rays_torch(n: int, seed: int, lo, hi, start: int = 0, device="cuda"):
+    """Same bits as hash_rays, generated on `device` with torch (int64 arithmetic)."""
+    import torch
+    idx = torch.arange(start, start + n, dtype=torch.int64, device=device)
+
+    def h32(x):
+        x = x & _M32
+        x = x ^ (x >> 16)
+        x = (x * 0x7FEB352D) & _M32
+        x = x ^ (x >> 15)
+        x = (x * 0x846CA68B) & _M32
+        x = x ^ (x >> 16)
+        return x
+
+    lo_t = torch.as_tensor(np.asarray(lo, np.float32), device=device)
+    hi_t = torch.as_tensor(np.asarray(hi, np.float32), device=device)
+    u = [((h32(idx * 6 + ch + (seed << 20)) >> 8).to(torch.float32)) * (2.0 ** -24)
+         for ch in range(6)]
+    o = torch.stack([lo_t[i] + u[i] * (hi_t[i] - lo_t[i]) for i in range(3)], -1)
+    d = torch.stack([u[3 + i] * 2.0 - 1.0 for i in range(3)], -1)
+    return o.contiguous(), d.contiguous()
