@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Summarise a gpurun_out/prof_<tag>/ directory (scripts/profile_bench.sh) into
+profiles/<tag>_summary.md + .json: per-kernel stats from --kernel-trace --stats and per-launch
+PMC averages for the query kernel.  FETCH_SIZE/WRITE_SIZE are in KiB (rocprofv3); on gfx950
+FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md, HBM) -- both the raw
+and the x2 figure are recorded."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+tag = sys.argv[1]
+kernel_key = sys.argv[2] if len(sys.argv) > 2 else "k_query"
+root = os.path.join("gpurun_out", f"prof_{tag}")
+out = {"tag": tag, "kernel_filter": kernel_key}
+
+
+def short_name(name):
+    head = name
+    if "<" in name and name.index("<") < name.index("("):
+        head = name[:name.index("(", name.index(">"))]
+    else:
+        head = name.split("(")[0] if not name.startswith("(") else name
+        head = name[:name.index("(", 5)] if "(" in name[5:] else name
+    return head.replace("void ", "").replace("(anonymous namespace)::", "")[:90]
+
+
+stats = glob.glob(os.path.join(root, "trace", "*", "*_kernel_stats.csv"))
+if stats:
+    out["kernel_stats"] = []
+    for r in csv.DictReader(open(stats[0])):
+        out["kernel_stats"].append({"name": short_name(r["Name"]), "calls": int(r["Calls"]),
+                                    "avg_ns": float(r["AverageNs"]), "min_ns": int(r["MinNs"]),
+                                    "max_ns": int(r["MaxNs"]), "pct": float(r["Percentage"])})
+pmc = defaultdict(list)
+meta = {}
+for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
+    if not os.path.isdir(d):
+        continue
+    for fcsv in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(fcsv)):
+            if kernel_key in r["Kernel_Name"]:
+                pmc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                meta = {"grid": int(r["Grid_Size"]), "wg": int(r["Workgroup_Size"]), "vgpr": int(r["VGPR_Count"]),
+                        "sgpr": int(r["SGPR_Count"]), "lds": int(r["LDS_Block_Size"]), "scratch": int(r["Scratch_Size"])}
+out["launch"] = meta
+out["pmc_avg_per_launch"] = {k: sum(v) / len(v) for k, v in pmc.items()}
+p = out["pmc_avg_per_launch"]
+d = {}
+if "FETCH_SIZE" in p:
+    d["fetch_bytes_raw"] = p["FETCH_SIZE"] * 1024
+    d["fetch_bytes_x2_gfx950"] = p["FETCH_SIZE"] * 2048
+if "WRITE_SIZE" in p:
+    d["write_bytes"] = p["WRITE_SIZE"] * 1024
+if "TCC_HIT_sum" in p and "TCC_MISS_sum" in p:
+    d["l2_hit_rate"] = p["TCC_HIT_sum"] / max(1.0, p["TCC_HIT_sum"] + p["TCC_MISS_sum"])
+if "SQ_INSTS_VALU" in p and "SQ_WAVES" in p:
+    d["valu_insts_per_wave"] = p["SQ_INSTS_VALU"] / max(1.0, p["SQ_WAVES"])
+if "SQ_THREAD_CYCLES_VALU" in p and "SQ_ACTIVE_INST_VALU" in p:
+    d["valu_thread_cycles_per_active_inst_cycle"] = p["SQ_THREAD_CYCLES_VALU"] / max(1.0, p["SQ_ACTIVE_INST_VALU"])
+if "SQ_WAIT_ANY" in p and "SQ_WAVE_CYCLES" in p:
+    d["wait_any_frac"] = p["SQ_WAIT_ANY"] / max(1.0, p["SQ_WAVE_CYCLES"])
+    d["active_inst_frac"] = p.get("SQ_ACTIVE_INST_ANY", 0) / max(1.0, p["SQ_WAVE_CYCLES"])
+    d["wait_inst_frac"] = p.get("SQ_WAIT_INST_ANY", 0) / max(1.0, p["SQ_WAVE_CYCLES"])
+out["derived"] = d
+os.makedirs("profiles", exist_ok=True)
+json.dump(out, open(os.path.join("profiles", f"{tag}_summary.json"), "w"), indent=1)
+with open(os.path.join("profiles", f"{tag}_summary.md"), "w") as f:
+    f.write(f"# rocprofv3 summary `{tag}` (bench.py --steps 20 --warmup 3, MI355X)\n\n")
+    f.write("## kernel-trace --stats\n\n| kernel | calls | avg us | min us | max us | % |\n|---|---|---|---|---|---|\n")
+    for k in out.get("kernel_stats", []):
+        f.write(f"| `{k['name']}` | {k['calls']} | {k['avg_ns']/1e3:.1f} | {k['min_ns']/1e3:.1f} | {k['max_ns']/1e3:.1f} | {k['pct']:.2f} |\n")
+    f.write(f"\n## PMC (separate passes), kernel filter `{kernel_key}`, averages per launch\n\nlaunch: {meta}\n\n| counter | value |\n|---|---|\n")
+    for k, v in sorted(p.items()):
+        f.write(f"| {k} | {v:.6g} |\n")
+    f.write("\n## derived\n\n")
+    for k, v in d.items():
+        f.write(f"- {k}: {v:.6g}\n")
+print(json.dumps(out["launch"]))
+print(json.dumps(out["pmc_avg_per_launch"], indent=0))
+print(json.dumps(d, indent=0))

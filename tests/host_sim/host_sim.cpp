@@ -141,6 +141,8 @@ static tr_bvh_view view_of(const tr_node* nodes, const tr_link* links, const tr_
     tr_bvh_view v; v.nodes = nodes; v.links = links; v.tris = tris; v.num_tris = nf; return v;
 }
 
+static int g_use_ring = 1;
+
 template <int Q>
 static void run_query(const tr_bvh_view& v, const float* o, const float* d, int64_t n, uint8_t* hit,
                       uint8_t* front, int32_t* tri, float* loc, float* uv, int32_t* count, uint64_t* stats) {
@@ -152,7 +154,9 @@ static void run_query(const tr_bvh_view& v, const float* o, const float* d, int6
         tr_result res;
         tr_topk<1> top;
         cnt.nodes = cnt.tris = cnt.climbs = 0;
-        if (v.num_tris >= 2) tr_traverse<Q, 1, true>(v, r, valid, res, top, &cnt);
+        int32_t ring_mem[TR_RING];
+        tr_ring ring = {g_use_ring ? ring_mem : nullptr, 1};
+        if (v.num_tris >= 2) tr_traverse<Q, 1, true>(v, r, valid, res, top, &cnt, ring);
         else {
             res.best_face = -1; res.count = 0; res.best_t = TR_TMAX;
             if (valid && v.num_tris == 1) {
@@ -182,6 +186,7 @@ static void run_query(const tr_bvh_view& v, const float* o, const float* d, int6
 }
 
 extern "C" {
+void sim_use_ring(int on) { g_use_ring = on; }
 void sim_query(int q, const void* nodes, const void* links, const void* tris, int64_t nf, const float* o,
                const float* d, int64_t n, uint8_t* hit, uint8_t* front, int32_t* tri, float* loc, float* uv,
                int32_t* count, uint64_t* stats) {
@@ -202,7 +207,9 @@ void sim_location(const void* nodes, const void* links, const void* tris, int64_
         tr_ray r;
         bool valid = tr_ray_setup(r, o[3 * i], o[3 * i + 1], o[3 * i + 2], d[3 * i], d[3 * i + 1], d[3 * i + 2]);
         tr_result res; tr_topk<8> top; tr_counters cnt;
-        tr_traverse<TR_Q_LOCATION, 8, false>(v, r, valid, res, top, &cnt);
+        int32_t ring_mem[TR_RING];
+        tr_ring ring = {g_use_ring ? ring_mem : nullptr, 1};
+        tr_traverse<TR_Q_LOCATION, 8, false>(v, r, valid, res, top, &cnt, ring);
         count[i] = res.count;
         for (int k = 0; k < 8 && k < cap; k++) { tri_out[i * cap + k] = k < res.count ? top.face[k] : -1; t_out[i * cap + k] = top.t[k]; }
     }

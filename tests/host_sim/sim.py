@@ -32,6 +32,7 @@ def lib():
         L.sim_get.argtypes = [C.c_void_p] * 4
         L.sim_query.argtypes = [C.c_int] + [C.c_void_p] * 3 + [C.c_int64, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p] * 7
         L.sim_location.argtypes = [C.c_void_p] * 3 + [C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 3
+        L.sim_use_ring.argtypes = [C.c_int]
         _LIB = L
     return _LIB
 
@@ -81,3 +82,7 @@ class SimBVH:
         lib().sim_location(self.nodes.ctypes.data, self.links.ctypes.data, self.tris.ctypes.data, self.nf,
                            o.ctypes.data, d.ctypes.data, n, cap, cnt.ctypes.data, tri.ctypes.data, t.ctypes.data)
         return cnt, tri, t
+
+
+def use_ring(on: bool):
+    lib().sim_use_ring(1 if on else 0)

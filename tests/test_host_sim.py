@@ -61,10 +61,18 @@ def compare_all(v, f, o, d, **kw):
     return B
 
 
-def test_icosphere_perspective_and_ortho():
-    v, f = W.icosphere(4)
-    compare_all(v, f, *W.readme_perspective(160))
-    compare_all(v, f, *W.ortho_grid(160))
+@pytest.mark.parametrize("ring", [True, False])
+def test_icosphere_perspective_and_ortho(ring):
+    import sim
+    sim.use_ring(ring)
+    try:
+        v, f = W.icosphere(4)
+        B = compare_all(v, f, *W.readme_perspective(160))
+        compare_all(v, f, *W.ortho_grid(160))
+        st = B.query(Q_CLOSEST, *W.ortho_grid(160))["stats"]
+        assert (st[3] == 0) == ring or not ring     # with the ring, climbs only happen past 16 levels
+    finally:
+        sim.use_ring(True)
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(force_mode=1), dict(morton_shift=40), dict(morton_shift=63)])

@@ -135,10 +135,22 @@ TR_HD bool tr_visit_leaf(const tr_bvh_view& b, const tr_ray& r, int32_t slot, fl
     return false;
 }
 
+// Far-child ring: the far child pushed at depth k is remembered in slot k % TR_RING of a
+// per-lane ring (LDS on the GPU: slot s of lane t lives at base[s * stride], stride = block
+// size, so a wave's accesses are bank-conflict free whatever the per-lane depths are).  A
+// 64-bit `valid` mask says which depths still own their slot; backtracking reads the slot
+// (one LDS read) when valid and falls back to climbing the parent links otherwise.
+#define TR_RING 16
+#define TR_RING_MASK 0x0001000100010001ull
+struct tr_ring {
+    int32_t* base;   // nullptr = no ring (always climb)
+    int32_t stride;
+};
+
 // Full traversal of one ray.  `valid` = tr_ray_setup's result.
 template <int Q, int K, bool STATS>
 TR_HD void tr_traverse(const tr_bvh_view& b, const tr_ray& r, bool valid, tr_result& res,
-                       tr_topk<K>& top, tr_counters* cnt) {
+                       tr_topk<K>& top, tr_counters* cnt, const tr_ring ring = tr_ring{nullptr, 0}) {
     res.best_t = TR_TMAX; res.best_face = -1; res.best_slot = -1;
     res.U = 0.f; res.V = 0.f; res.det = 1.f; res.count = 0;
     if (Q == TR_Q_LOCATION) top.init();
@@ -148,6 +160,7 @@ TR_HD void tr_traverse(const tr_bvh_view& b, const tr_ray& r, bool valid, tr_res
     int32_t node = 0;
     uint32_t depth = 0;
     uint64_t trail = 0;
+    uint64_t owned = 0;   // depths whose far child is still in the ring
     for (;;) {
         const tr_f4* np = reinterpret_cast<const tr_f4*>(b.nodes + node);
         tr_f4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
@@ -180,7 +193,13 @@ TR_HD void tr_traverse(const tr_bvh_view& b, const tr_ray& r, bool valid, tr_res
         if (h0 | h1) {
             if (h0 & h1) {
                 trail |= (1ull << depth);
-                node = (tn1 < tn0) ? c1 : c0;
+                const bool swap = tn1 < tn0;
+                node = swap ? c1 : c0;
+                if (ring.base) {
+                    const uint32_t slot = depth & (TR_RING - 1);
+                    ring.base[slot * ring.stride] = swap ? c0 : c1;
+                    owned = (owned & ~(TR_RING_MASK << slot)) | (1ull << depth);
+                }
             } else {
                 node = h0 ? c0 : c1;
             }
@@ -191,6 +210,11 @@ TR_HD void tr_traverse(const tr_bvh_view& b, const tr_ray& r, bool valid, tr_res
         if (trail == 0) return;
         const uint32_t j = 63u - (uint32_t)__builtin_clzll(trail);
         trail &= ~(1ull << j);
+        if (ring.base && ((owned >> j) & 1ull)) {
+            node = ring.base[(j & (TR_RING - 1)) * ring.stride];
+            depth = j + 1;
+            continue;
+        }
         while (depth > j + 1) {   // climb; `node` is at `depth`, (parent, sibling) are its links
             node = parent;
             const tr_link l = b.links[node];

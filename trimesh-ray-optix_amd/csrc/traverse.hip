@@ -101,14 +101,15 @@ __device__ __forceinline__ void brute_one(const tr_bvh_view& b, const tr_ray& r,
 
 template <int Q, bool STATS>
 __device__ __forceinline__ void process_ray(const tr_bvh_view& b, const RayFetch& rf,
-                                            const QueryOut& out, int64_t i, tr_counters* cnt) {
+                                            const QueryOut& out, int64_t i, tr_counters* cnt,
+                                            const tr_ring ring) {
     float o[3], d[3];
     fetch_ray(rf, i, o, d);
     tr_ray r;
     bool valid = tr_ray_setup(r, o[0], o[1], o[2], d[0], d[1], d[2]);
     tr_result res;
     tr_topk<1> top;
-    if (b.num_tris >= 2) tr_traverse<Q, 1, STATS>(b, r, valid, res, top, cnt);
+    if (b.num_tris >= 2) tr_traverse<Q, 1, STATS>(b, r, valid, res, top, cnt, ring);
     else brute_one<Q>(b, r, valid, res);
     write_result<Q>(b, out, i, res);
 }
@@ -129,9 +130,11 @@ __device__ __forceinline__ void flush_stats(const tr_counters& c, unsigned long 
 template <int Q, bool STATS>
 __global__ __launch_bounds__(256) void k_query_direct(tr_bvh_view b, RayFetch rf, QueryOut out,
                                                       unsigned long long* stats) {
+    __shared__ int32_t ring_lds[TR_RING * 256];
+    const tr_ring ring = {ring_lds + threadIdx.x, 256};
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     tr_counters cnt = {0, 0, 0};
-    if (i < rf.n) process_ray<Q, STATS>(b, rf, out, i, &cnt);
+    if (i < rf.n) process_ray<Q, STATS>(b, rf, out, i, &cnt, ring);
     flush_stats<STATS>(cnt, stats);
 }
 
@@ -139,6 +142,8 @@ template <int Q, bool STATS>
 __global__ __launch_bounds__(256) void k_query_persistent(tr_bvh_view b, RayFetch rf, QueryOut out,
                                                           unsigned long long* counter,
                                                           unsigned long long* stats) {
+    __shared__ int32_t ring_lds[TR_RING * 256];
+    const tr_ring ring = {ring_lds + threadIdx.x, 256};
     const int lane = threadIdx.x & 63;
     tr_counters cnt = {0, 0, 0};
     for (;;) {
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(256) void k_query_persistent(tr_bvh_view b, RayFetc
         base = __shfl(base, 0);
         if ((int64_t)base >= rf.n) break;
         int64_t i = (int64_t)base + lane;
-        if (i < rf.n) process_ray<Q, STATS>(b, rf, out, i, &cnt);
+        if (i < rf.n) process_ray<Q, STATS>(b, rf, out, i, &cnt, ring);
     }
     flush_stats<STATS>(cnt, stats);
 }
@@ -159,6 +164,8 @@ __global__ __launch_bounds__(256) void k_location(tr_bvh_view b, RayFetch rf, in
                                                   float* __restrict__ loc,
                                                   int32_t* __restrict__ ray_idx,
                                                   int32_t* __restrict__ tri_idx, int64_t ray_base) {
+    __shared__ int32_t ring_lds[TR_RING * 256];
+    const tr_ring ring = {ring_lds + threadIdx.x, 256};
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= rf.n) return;
     float o[3], d[3];
@@ -169,7 +176,7 @@ __global__ __launch_bounds__(256) void k_location(tr_bvh_view b, RayFetch rf, in
     tr_topk<K> top;
     tr_counters* nc = nullptr;
     if (b.num_tris >= 2) {
-        tr_traverse<TR_Q_LOCATION, K, false>(b, r, valid, res, top, nc);
+        tr_traverse<TR_Q_LOCATION, K, false>(b, r, valid, res, top, nc, ring);
     } else {
         top.init();
         brute_one<TR_Q_LOCATION>(b, r, valid, res);
