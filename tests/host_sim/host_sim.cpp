@@ -199,6 +199,21 @@ void sim_query(int q, const void* nodes, const void* links, const void* tris, in
     }
 }
 
+// per-ray node-visit / leaf-test counts of the closest-hit traversal (divergence studies)
+void sim_steps(const void* nodes, const void* links, const void* tris, int64_t nf, const float* o,
+               const float* d, int64_t n, int32_t* node_visits, int32_t* tri_tests) {
+    tr_bvh_view v = view_of((const tr_node*)nodes, (const tr_link*)links, (const tr_tri*)tris, nf);
+    for (int64_t i = 0; i < n; i++) {
+        tr_ray r;
+        bool valid = tr_ray_setup(r, o[3 * i], o[3 * i + 1], o[3 * i + 2], d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+        tr_result res; tr_topk<1> top; tr_counters cnt = {0, 0, 0};
+        int32_t ring_mem[TR_RING];
+        tr_ring ring = {ring_mem, 1};
+        tr_traverse<TR_Q_CLOSEST, 1, true>(v, r, valid, res, top, &cnt, ring);
+        node_visits[i] = (int32_t)cnt.nodes; tri_tests[i] = (int32_t)cnt.tris;
+    }
+}
+
 // multi-hit: counts[i] hits (uncapped), first min(count,cap) nearest written at i*cap
 void sim_location(const void* nodes, const void* links, const void* tris, int64_t nf, const float* o,
                   const float* d, int64_t n, int32_t cap, int32_t* count, int32_t* tri_out, float* t_out) {

@@ -33,6 +33,7 @@ def lib():
         L.sim_query.argtypes = [C.c_int] + [C.c_void_p] * 3 + [C.c_int64, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p] * 7
         L.sim_location.argtypes = [C.c_void_p] * 3 + [C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 3
         L.sim_use_ring.argtypes = [C.c_int]
+        L.sim_steps.argtypes = [C.c_void_p] * 3 + [C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -73,6 +74,15 @@ class SimBVH:
                         loc.ctypes.data, uv.ctypes.data, cnt.ctypes.data, stats.ctypes.data)
         return dict(hit=hit.astype(bool), front=front.astype(bool), tri=tri, loc=loc, uv=uv, count=cnt,
                     stats=stats)
+
+    def steps(self, o, d):
+        o = np.ascontiguousarray(o, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)
+        n = len(o)
+        nv = np.zeros(n, np.int32); tt = np.zeros(n, np.int32)
+        lib().sim_steps(self.nodes.ctypes.data, self.links.ctypes.data, self.tris.ctypes.data, self.nf,
+                        o.ctypes.data, d.ctypes.data, n, nv.ctypes.data, tt.ctypes.data)
+        return nv, tt
 
     def location(self, o, d, cap=8):
         o = np.ascontiguousarray(o, np.float32).reshape(-1, 3)

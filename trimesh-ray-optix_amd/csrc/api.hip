@@ -179,6 +179,12 @@ int tr_set_option(const char* name, int64_t value) {
         return TR_OK;
     }
     if (!strcmp(name, "refill")) { g_options.refill = value != 0; return TR_OK; }
+    if (!strcmp(name, "xcd_segments")) { g_options.xcd_segments = value != 0; return TR_OK; }
+    if (!strcmp(name, "refill_min")) {
+        if (value < 1 || value > 64) return tr_fail(TR_ERR_INVALID_ARG, "refill_min out of range");
+        g_options.refill_min = (int)value;
+        return TR_OK;
+    }
     return tr_fail(TR_ERR_INVALID_ARG, std::string("unknown option: ") + name);
 }
 

@@ -147,81 +147,112 @@ struct tr_ring {
     int32_t stride;
 };
 
+// Per-lane traversal state between two node visits.
+struct tr_state {
+    int32_t node;
+    uint32_t depth;
+    uint64_t trail;   // bit k: the node at depth k on the current path still owes its far child
+    uint64_t owned;   // bit k: that far child is still in ring slot k % TR_RING
+};
+
+TR_HD void tr_result_init(tr_result& res) {
+    res.best_t = TR_TMAX; res.best_face = -1; res.best_slot = -1;
+    res.U = 0.f; res.V = 0.f; res.det = 1.f; res.count = 0;
+}
+
+TR_HD void tr_state_init(tr_state& st) {
+    st.node = 0; st.depth = 0; st.trail = 0; st.owned = 0;
+}
+
+// One node visit: fetch the 64-B node, test both child boxes, evaluate leaf children, then
+// move to the next node (near child, or the deepest owed far child).  Returns true when the
+// ray is finished.  Requires b.num_tris >= 2 and a valid ray.
+template <int Q, int K, bool STATS>
+TR_HD bool tr_step(const tr_bvh_view& b, const tr_ray& r, tr_state& st, tr_result& res,
+                   tr_topk<K>& top, tr_counters* cnt, const tr_ring ring) {
+    const bool ordered = (Q == TR_Q_FIRST || Q == TR_Q_CLOSEST);
+    const tr_f4* np = reinterpret_cast<const tr_f4*>(b.nodes + st.node);
+    tr_f4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+    if (STATS) cnt->nodes++;
+    // n0 = lo0.xyz hi0.x | n1 = hi0.yz lo1.xy | n2 = lo1.z hi1.xyz | n3 = c0 c1 parent sibling
+    float tn0, tf0, tn1, tf1;
+    tr_slab(r, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tn0, tf0);
+    tr_slab(r, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, tn1, tf1);
+    union { float f; int32_t i; } u0, u1, u2, u3;
+    u0.f = n3.x; u1.f = n3.y; u2.f = n3.z; u3.f = n3.w;
+    const int32_t c0 = u0.i, c1 = u1.i;
+    int32_t parent = u2.i, sibling = u3.i;
+    const float lim = ordered ? res.best_t : TR_TMAX;
+    bool h0 = tr_slab_hit(tn0, tf0, lim);
+    bool h1 = tr_slab_hit(tn1, tf1, lim);
+    // Single-exit structure on purpose: every path falls through to the end of the function so
+    // that the compiler keeps ONE loop with one back edge around it (early returns/continues
+    // made LLVM's structurizer nest the loop, serialising descending and backtracking lanes).
+    bool finished = false;
+    // leaves first (they can only shrink best_t)
+    if (h0 && c0 < 0) {
+        finished = tr_visit_leaf<Q, K, STATS>(b, r, ~c0, tn0, tf0, res, top, cnt);
+        h0 = false;
+    }
+    if (h1 && c1 < 0) {
+        if (!finished && (!ordered || tn1 <= res.best_t))
+            finished = tr_visit_leaf<Q, K, STATS>(b, r, ~c1, tn1, tf1, res, top, cnt);
+        h1 = false;
+    }
+    if (ordered) {
+        h0 = h0 && (tn0 <= res.best_t);
+        h1 = h1 && (tn1 <= res.best_t);
+    }
+    if (!finished) {
+        if (h0 | h1) {
+            const bool both = h0 & h1;
+            const bool swap = both ? (tn1 < tn0) : h1;   // descend into c1?
+            const int32_t near = swap ? c1 : c0;
+            if (both) {
+                st.trail |= (1ull << st.depth);
+                if (ring.base) {
+                    const uint32_t slot = st.depth & (TR_RING - 1);
+                    ring.base[slot * ring.stride] = swap ? c0 : c1;
+                    st.owned = (st.owned & ~(TR_RING_MASK << slot)) | (1ull << st.depth);
+                }
+            }
+            st.node = near;
+            st.depth++;
+        } else if (st.trail == 0) {
+            finished = true;
+        } else {
+            // backtrack to the deepest ancestor that still owes its far child
+            const uint32_t j = 63u - (uint32_t)__builtin_clzll(st.trail);
+            st.trail &= ~(1ull << j);
+            if (ring.base && ((st.owned >> j) & 1ull)) {
+                st.node = ring.base[(j & (TR_RING - 1)) * ring.stride];
+            } else {
+                int32_t node = st.node;
+                uint32_t depth = st.depth;
+                while (depth > j + 1) {   // climb; `node` is at `depth`, (parent, sibling) its links
+                    node = parent;
+                    const tr_link l = b.links[node];
+                    parent = l.parent; sibling = l.sibling;
+                    depth--;
+                    if (STATS) cnt->climbs++;
+                }
+                st.node = sibling;        // far child at depth j+1 (internal by construction)
+            }
+            st.depth = j + 1;
+        }
+    }
+    TR_CONVERGE();
+    return finished;
+}
+
 // Full traversal of one ray.  `valid` = tr_ray_setup's result.
 template <int Q, int K, bool STATS>
 TR_HD void tr_traverse(const tr_bvh_view& b, const tr_ray& r, bool valid, tr_result& res,
                        tr_topk<K>& top, tr_counters* cnt, const tr_ring ring = tr_ring{nullptr, 0}) {
-    res.best_t = TR_TMAX; res.best_face = -1; res.best_slot = -1;
-    res.U = 0.f; res.V = 0.f; res.det = 1.f; res.count = 0;
+    tr_result_init(res);
     if (Q == TR_Q_LOCATION) top.init();
     if (!valid || b.num_tris < 2) return;   // F < 2 is handled by the brute-force kernel
-
-    const bool ordered = (Q == TR_Q_FIRST || Q == TR_Q_CLOSEST);
-    int32_t node = 0;
-    uint32_t depth = 0;
-    uint64_t trail = 0;
-    uint64_t owned = 0;   // depths whose far child is still in the ring
-    for (;;) {
-        const tr_f4* np = reinterpret_cast<const tr_f4*>(b.nodes + node);
-        tr_f4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
-        if (STATS) cnt->nodes++;
-        // n0 = lo0.xyz hi0.x | n1 = hi0.yz lo1.xy | n2 = lo1.z hi1.xyz | n3 = c0 c1 parent sibling
-        float tn0, tf0, tn1, tf1;
-        tr_slab(r, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tn0, tf0);
-        tr_slab(r, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, tn1, tf1);
-        union { float f; int32_t i; } u0, u1, u2, u3;
-        u0.f = n3.x; u1.f = n3.y; u2.f = n3.z; u3.f = n3.w;
-        const int32_t c0 = u0.i, c1 = u1.i;
-        int32_t parent = u2.i, sibling = u3.i;
-        const float lim = ordered ? res.best_t : TR_TMAX;
-        bool h0 = tr_slab_hit(tn0, tf0, lim);
-        bool h1 = tr_slab_hit(tn1, tf1, lim);
-        // leaves first (they can only shrink best_t)
-        if (h0 && c0 < 0) {
-            if (tr_visit_leaf<Q, K, STATS>(b, r, ~c0, tn0, tf0, res, top, cnt)) return;
-            h0 = false;
-        }
-        if (h1 && c1 < 0) {
-            if (!ordered || tn1 <= res.best_t)
-                if (tr_visit_leaf<Q, K, STATS>(b, r, ~c1, tn1, tf1, res, top, cnt)) return;
-            h1 = false;
-        }
-        if (ordered) {
-            h0 = h0 && (tn0 <= res.best_t);
-            h1 = h1 && (tn1 <= res.best_t);
-        }
-        if (h0 | h1) {
-            if (h0 & h1) {
-                trail |= (1ull << depth);
-                const bool swap = tn1 < tn0;
-                node = swap ? c1 : c0;
-                if (ring.base) {
-                    const uint32_t slot = depth & (TR_RING - 1);
-                    ring.base[slot * ring.stride] = swap ? c0 : c1;
-                    owned = (owned & ~(TR_RING_MASK << slot)) | (1ull << depth);
-                }
-            } else {
-                node = h0 ? c0 : c1;
-            }
-            depth++;
-            continue;
-        }
-        // backtrack to the deepest ancestor that still owes its far child
-        if (trail == 0) return;
-        const uint32_t j = 63u - (uint32_t)__builtin_clzll(trail);
-        trail &= ~(1ull << j);
-        if (ring.base && ((owned >> j) & 1ull)) {
-            node = ring.base[(j & (TR_RING - 1)) * ring.stride];
-            depth = j + 1;
-            continue;
-        }
-        while (depth > j + 1) {   // climb; `node` is at `depth`, (parent, sibling) are its links
-            node = parent;
-            const tr_link l = b.links[node];
-            parent = l.parent; sibling = l.sibling;
-            depth--;
-            if (STATS) cnt->climbs++;
-        }
-        node = sibling;           // far child at depth j+1 (internal by construction)
-    }
+    tr_state st;
+    tr_state_init(st);
+    while (!tr_step<Q, K, STATS>(b, r, st, res, top, cnt, ring)) {}
 }

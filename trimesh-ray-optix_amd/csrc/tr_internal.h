@@ -68,5 +68,7 @@ struct tr_options {
     int persistent = 1;
     int blocks_per_cu = 8;
     int refill = 1;
+    int refill_min = 16;
+    int xcd_segments = 1;
 };
 tr_options& tr_opts();

@@ -16,7 +16,16 @@
 #if defined(__HIPCC__)
 #define TR_HD __host__ __device__ __forceinline__
 #define TR_HDM __host__ __device__ __forceinline__
+#if defined(__HIP_DEVICE_COMPILE__)
+// A convergent no-op: marks a point where all control-flow paths of a loop body must merge,
+// so that jump threading cannot give the loop several back edges (LLVM then nests the loop
+// and lanes on different paths serialise).  Emits no instruction.
+#define TR_CONVERGE() __builtin_amdgcn_wave_barrier()
 #else
+#define TR_CONVERGE() ((void)0)
+#endif
+#else
+#define TR_CONVERGE() ((void)0)
 #define TR_HD static inline
 #define TR_HDM inline
 #endif

@@ -157,6 +157,111 @@ __global__ __launch_bounds__(256) void k_query_persistent(tr_bvh_view b, RayFetc
     flush_stats<STATS>(cnt, stats);
 }
 
+// Persistent threads with per-lane refill ("active-ray repacking"): as soon as at least
+// `refill_min` lanes of a wave are idle, the wave stores their finished results together and
+// claims exactly that many new, consecutive rays with ONE atomic on a work counter, so lanes do
+// not wait for the slowest ray of a 64-ray batch and the launch has no tail of half-empty
+// waves.  There are 8 work counters: the ray range is cut into `nseg` contiguous segments and
+// a wave first drains the segment of the XCD it runs on (HW_REG_XCC_ID), so one XCD's L2 sees
+// one compact part of the image / BVH; when its segment is empty it steals from the next.
+// XCD placement only affects speed, never results.
+__device__ __forceinline__ uint32_t xcc_id() {
+    // s_getreg_b32 hwreg(HW_REG_XCC_ID = 20), bits [3:0]
+    return __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;
+}
+
+template <int Q, bool STATS>
+__global__ __launch_bounds__(256) void k_query_refill(tr_bvh_view b, RayFetch rf, QueryOut out,
+                                                      unsigned long long* counters,   // [8]
+                                                      int refill_min, int nseg,
+                                                      unsigned long long* stats) {
+    __shared__ int32_t ring_lds[TR_RING * 256];
+    const tr_ring ring = {ring_lds + threadIdx.x, 256};
+    const int lane = threadIdx.x & 63;
+    tr_counters cnt = {0, 0, 0};
+    const int64_t n = rf.n;
+    const int64_t seg_len = (n + nseg - 1) / nseg;
+    uint32_t seg = xcc_id() % (uint32_t)nseg;
+    int segs_tried = 0;       // wave-uniform
+    bool exhausted = false;   // wave-uniform
+    bool active = false;
+    bool unwritten = false;   // lane holds a finished result that has not been stored yet
+    int64_t rid = 0;
+    tr_ray r;
+    tr_state st;
+    tr_result res;
+    tr_topk<1> top;
+    tr_state_init(st);
+    tr_result_init(res);
+    for (;;) {
+        unsigned long long idle = __ballot(!active);
+        int nidle = __popcll(idle);
+        const bool refill_now = !exhausted && (nidle >= refill_min || nidle == 64);
+        if (refill_now || (exhausted && nidle == 64)) {
+            // write-back of all finished lanes together (one divergent pass, not one per ray)
+            if (unwritten) {
+                write_result<Q>(b, out, rid, res);
+                unwritten = false;
+            }
+        }
+        if (refill_now) {
+            int rank = (int)__popcll(idle & ((1ull << lane) - 1ull));   // rank among idle lanes
+            int64_t my = -1;
+            while (nidle > 0 && segs_tried < nseg) {
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(&counters[seg], (unsigned long long)nidle);
+                base = __shfl(base, 0);
+                const int64_t seg_start = (int64_t)seg * seg_len;
+                int64_t seg_end = seg_start + seg_len;
+                if (seg_end > n) seg_end = n;
+                int64_t got = seg_end - (seg_start + (int64_t)base);   // rays this claim yields
+                if (got > nidle) got = nidle;
+                if (got > 0) {
+                    if (!active && my < 0 && rank >= 0 && rank < got) my = seg_start + (int64_t)base + rank;
+                    rank -= (int)got;
+                    nidle -= (int)got;
+                }
+                if (nidle > 0) {   // segment drained: steal from the next one
+                    seg = (seg + 1) % (uint32_t)nseg;
+                    segs_tried++;
+                }
+            }
+            if (segs_tried >= nseg) exhausted = true;
+            if (my >= 0) {
+                float o[3], d[3];
+                fetch_ray(rf, my, o, d);
+                const bool valid = tr_ray_setup(r, o[0], o[1], o[2], d[0], d[1], d[2]);
+                rid = my;
+                tr_state_init(st);
+                tr_result_init(res);
+                if (valid && b.num_tris >= 2) {
+                    active = true;
+                } else {
+                    if (b.num_tris < 2) brute_one<Q>(b, r, valid, res);
+                    unwritten = true;   // stored at the next refill point
+                }
+            }
+        }
+        if (__ballot(active) == 0ull) {
+            if (exhausted && __ballot(unwritten) == 0ull) break;
+            continue;
+        }
+        // traverse until enough lanes have gone idle to make a refill worthwhile
+        for (;;) {
+            if (active) {
+                if (tr_step<Q, 1, STATS>(b, r, st, res, top, &cnt, ring)) {
+                    active = false;
+                    unwritten = true;
+                }
+            }
+            const unsigned long long act = __ballot(active);
+            if (act == 0ull) break;
+            if (!exhausted && (64 - (int)__popcll(act)) >= refill_min) break;
+        }
+    }
+    flush_stats<STATS>(cnt, stats);
+}
+
 // ---- multi-hit second pass (shaders.cu:196-246) ----------------------------------------------
 template <int K>
 __global__ __launch_bounds__(256) void k_location(tr_bvh_view b, RayFetch rf, int32_t cap,
@@ -360,12 +465,30 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
     const tr_options& opt = tr_opts();
     const int64_t nblocks_direct = (rf.n + 255) / 256;
     int64_t pgrid = (int64_t)st->num_cus * opt.blocks_per_cu;
+    if (opt.persistent) {
+        // size the persistent grid by what is actually resident (4 waves per block = 1 per SIMD)
+        static int occ_refill = 0, occ_plain = 0;   // per instantiation <Q, STATS>
+        int& occ = opt.refill ? occ_refill : occ_plain;
+        if (occ == 0) {
+            int nb = 0;
+            hipError_t e = opt.refill
+                ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_query_refill<Q, STATS>, 256, 0)
+                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_query_persistent<Q, STATS>, 256, 0);
+            occ = (e == hipSuccess && nb > 0) ? nb : 4;
+        }
+        int bpc = opt.blocks_per_cu < occ ? opt.blocks_per_cu : occ;
+        pgrid = (int64_t)st->num_cus * bpc;
+    }
     if (opt.persistent && nblocks_direct > pgrid) {
-        unsigned slot = __atomic_fetch_add(&st->next_counter, 1u, __ATOMIC_RELAXED) % TR_NUM_COUNTERS;
-        unsigned long long* counter = reinterpret_cast<unsigned long long*>(st->counters) + slot;
-        TR_HIP_TRY(hipMemsetAsync(counter, 0, sizeof(unsigned long long), stream));
-        hipLaunchKernelGGL((k_query_persistent<Q, STATS>), dim3((unsigned)pgrid), dim3(256), 0, stream,
-                           view, rf, out, counter, d_stats);
+        unsigned slot = __atomic_fetch_add(&st->next_counter, 1u, __ATOMIC_RELAXED) % (TR_NUM_COUNTERS / 8);
+        unsigned long long* counter = reinterpret_cast<unsigned long long*>(st->counters) + 8 * slot;
+        TR_HIP_TRY(hipMemsetAsync(counter, 0, 8 * sizeof(unsigned long long), stream));
+        if (opt.refill)
+            hipLaunchKernelGGL((k_query_refill<Q, STATS>), dim3((unsigned)pgrid), dim3(256), 0, stream,
+                               view, rf, out, counter, opt.refill_min, opt.xcd_segments ? 8 : 1, d_stats);
+        else
+            hipLaunchKernelGGL((k_query_persistent<Q, STATS>), dim3((unsigned)pgrid), dim3(256), 0, stream,
+                               view, rf, out, counter, d_stats);
     } else {
         hipLaunchKernelGGL((k_query_direct<Q, STATS>), dim3((unsigned)nblocks_direct), dim3(256), 0, stream,
                            view, rf, out, d_stats);
