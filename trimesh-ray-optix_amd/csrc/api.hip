@@ -180,6 +180,11 @@ int tr_set_option(const char* name, int64_t value) {
     }
     if (!strcmp(name, "refill")) { g_options.refill = value != 0; return TR_OK; }
     if (!strcmp(name, "xcd_segments")) { g_options.xcd_segments = value != 0; return TR_OK; }
+    if (!strcmp(name, "leaf_min")) {
+        if (value < 0 || value > 64) return tr_fail(TR_ERR_INVALID_ARG, "leaf_min out of range");
+        g_options.leaf_min = (int)value;
+        return TR_OK;
+    }
     if (!strcmp(name, "refill_min")) {
         if (value < 1 || value > 64) return tr_fail(TR_ERR_INVALID_ARG, "refill_min out of range");
         g_options.refill_min = (int)value;

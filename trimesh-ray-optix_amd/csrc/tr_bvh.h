@@ -109,25 +109,23 @@ TR_HD tr_tri tr_load_tri(const tr_bvh_view& b, int32_t slot, tr_counters* cnt) {
     return t;
 }
 
-// One leaf: evaluate the predicate with the slab interval already computed from the parent's
-// child box and fold the result into the per-query state.
-// returns true when the ray is finished (ANY query, first accepted hit)
-template <int Q, int K, bool STATS>
-TR_HD bool tr_visit_leaf(const tr_bvh_view& b, const tr_ray& r, int32_t slot, float tn, float tf,
-                         tr_result& res, tr_topk<K>& top, tr_counters* cnt) {
-    tr_tri t = tr_load_tri<STATS>(b, slot, cnt);
+// Fold one accepted/rejected leaf test into the per-query state.  `live` = the lane really
+// owns this leaf (the code runs unpredicated for the whole wave).  Returns true when the ray
+// is finished (ANY query, first accepted hit).
+template <int Q, int K>
+TR_HD bool tr_fold_leaf(bool live, const tr_ray& r, const tr_tri& t, int32_t slot, float tn, float tf,
+                        tr_result& res, tr_topk<K>& top) {
     tr_hit h;
-    if (!tr_tri_mt(r, t.ax, t.ay, t.az, t.bx, t.by, t.bz, t.cx, t.cy, t.cz, tn, tf, h)) return false;
+    const bool hit = tr_tri_mt(r, t.ax, t.ay, t.az, t.bx, t.by, t.bz, t.cx, t.cy, t.cz, tn, tf, h) && live;
     if (Q == TR_Q_ANY) {
-        res.best_face = t.face;
-        return true;
+        if (hit) res.best_face = t.face;
+        return hit;
     } else if (Q == TR_Q_COUNT) {
-        res.count++;
+        res.count += hit ? 1 : 0;
     } else if (Q == TR_Q_LOCATION) {
-        res.count++;
-        top.insert(h.t, t.face, slot);
+        if (hit) { res.count++; top.insert(h.t, t.face, slot); }
     } else {
-        if (tr_closer(h.t, t.face, res.best_t, res.best_face < 0 ? 0x7fffffff : res.best_face)) {
+        if (hit && tr_closer(h.t, t.face, res.best_t, res.best_face < 0 ? 0x7fffffff : res.best_face)) {
             res.best_t = h.t; res.best_face = t.face; res.best_slot = slot;
             res.U = h.U; res.V = h.V; res.det = h.det;
         }
@@ -138,8 +136,8 @@ TR_HD bool tr_visit_leaf(const tr_bvh_view& b, const tr_ray& r, int32_t slot, fl
 // Far-child ring: the far child pushed at depth k is remembered in slot k % TR_RING of a
 // per-lane ring (LDS on the GPU: slot s of lane t lives at base[s * stride], stride = block
 // size, so a wave's accesses are bank-conflict free whatever the per-lane depths are).  A
-// 64-bit `valid` mask says which depths still own their slot; backtracking reads the slot
-// (one LDS read) when valid and falls back to climbing the parent links otherwise.
+// 64-bit `owned` mask says which depths still own their slot; backtracking reads the slot
+// (one LDS read) when owned and falls back to climbing the parent links otherwise.
 #define TR_RING 16
 #define TR_RING_MASK 0x0001000100010001ull
 struct tr_ring {
@@ -147,12 +145,16 @@ struct tr_ring {
     int32_t stride;
 };
 
-// Per-lane traversal state between two node visits.
+// Per-lane traversal state between two iterations.
 struct tr_state {
-    int32_t node;
+    int32_t node;     // next internal node to visit, -1 = hierarchy exhausted
     uint32_t depth;
     uint64_t trail;   // bit k: the node at depth k on the current path still owes its far child
     uint64_t owned;   // bit k: that far child is still in ring slot k % TR_RING
+    // leaves found by the previous node visit, tested one iteration later so that their
+    // triangle loads overlap the next node's load (one memory round trip per iteration)
+    int32_t p0, p1;   // tri slots, -1 = none
+    float p0n, p0f, p1n, p1f;   // their slab intervals
 };
 
 TR_HD void tr_result_init(tr_result& res) {
@@ -162,17 +164,21 @@ TR_HD void tr_result_init(tr_result& res) {
 
 TR_HD void tr_state_init(tr_state& st) {
     st.node = 0; st.depth = 0; st.trail = 0; st.owned = 0;
+    st.p0 = -1; st.p1 = -1; st.p0n = st.p0f = st.p1n = st.p1f = 0.f;
 }
 
-// One node visit: fetch the 64-B node, test both child boxes, evaluate leaf children, then
-// move to the next node (near child, or the deepest owed far child).  Returns true when the
-// ray is finished.  Requires b.num_tris >= 2 and a valid ray.
-template <int Q, int K, bool STATS>
-TR_HD bool tr_step(const tr_bvh_view& b, const tr_ray& r, tr_state& st, tr_result& res,
-                   tr_topk<K>& top, tr_counters* cnt, const tr_ring ring) {
+TR_HD bool tr_pending(const tr_state& st) { return st.p0 >= 0 || st.p1 >= 0; }
+TR_HD bool tr_done(const tr_state& st) { return st.node < 0 && st.p0 < 0 && st.p1 < 0; }
+
+// NODE PHASE: visit st.node (lane must have a node and no queued leaf): fetch the 64-B node,
+// test both child boxes, queue hit leaf children in (p0, p1), then move to the next node
+// (near child, or the deepest owed far child; -1 when the hierarchy is exhausted).
+template <int Q, bool STATS>
+TR_HD void tr_node_step(const tr_bvh_view& b, const tr_ray& r, tr_state& st, const tr_result& res,
+                        tr_counters* cnt, const tr_ring ring) {
     const bool ordered = (Q == TR_Q_FIRST || Q == TR_Q_CLOSEST);
     const tr_f4* np = reinterpret_cast<const tr_f4*>(b.nodes + st.node);
-    tr_f4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+    const tr_f4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
     if (STATS) cnt->nodes++;
     // n0 = lo0.xyz hi0.x | n1 = hi0.yz lo1.xy | n2 = lo1.z hi1.xyz | n3 = c0 c1 parent sibling
     float tn0, tf0, tn1, tf1;
@@ -185,29 +191,118 @@ TR_HD bool tr_step(const tr_bvh_view& b, const tr_ray& r, tr_state& st, tr_resul
     const float lim = ordered ? res.best_t : TR_TMAX;
     bool h0 = tr_slab_hit(tn0, tf0, lim);
     bool h1 = tr_slab_hit(tn1, tf1, lim);
-    // Single-exit structure on purpose: every path falls through to the end of the function so
-    // that the compiler keeps ONE loop with one back edge around it (early returns/continues
-    // made LLVM's structurizer nest the loop, serialising descending and backtracking lanes).
-    bool finished = false;
-    // leaves first (they can only shrink best_t)
-    if (h0 && c0 < 0) {
-        finished = tr_visit_leaf<Q, K, STATS>(b, r, ~c0, tn0, tf0, res, top, cnt);
-        h0 = false;
+    // leaf children are queued for the leaf phase
+    if (h0 && c0 < 0) { st.p0 = ~c0; st.p0n = tn0; st.p0f = tf0; h0 = false; }
+    if (h1 && c1 < 0) { st.p1 = ~c1; st.p1n = tn1; st.p1f = tf1; h1 = false; }
+    if (h0 | h1) {
+        const bool both = h0 & h1;
+        const bool swap = both ? (tn1 < tn0) : h1;   // descend into c1?
+        if (both) {
+            st.trail |= (1ull << st.depth);
+            if (ring.base) {
+                const uint32_t slot = st.depth & (TR_RING - 1);
+                ring.base[slot * ring.stride] = swap ? c0 : c1;
+                st.owned = (st.owned & ~(TR_RING_MASK << slot)) | (1ull << st.depth);
+            }
+        }
+        st.node = swap ? c1 : c0;
+        st.depth++;
+    } else if (st.trail == 0) {
+        st.node = -1;
+    } else {
+        // backtrack to the deepest ancestor that still owes its far child
+        const uint32_t j = 63u - (uint32_t)__builtin_clzll(st.trail);
+        st.trail &= ~(1ull << j);
+        if (ring.base && ((st.owned >> j) & 1ull)) {
+            st.node = ring.base[(j & (TR_RING - 1)) * ring.stride];
+        } else {
+            int32_t node = st.node;
+            uint32_t depth = st.depth;
+            while (depth > j + 1) {   // climb; `node` is at `depth`, (parent, sibling) its links
+                node = parent;
+                const tr_link l = b.links[node];
+                parent = l.parent; sibling = l.sibling;
+                depth--;
+                if (STATS) cnt->climbs++;
+            }
+            st.node = sibling;        // far child at depth j+1 (internal by construction)
+        }
+        st.depth = j + 1;
     }
-    if (h1 && c1 < 0) {
-        if (!finished && (!ordered || tn1 <= res.best_t))
-            finished = tr_visit_leaf<Q, K, STATS>(b, r, ~c1, tn1, tf1, res, top, cnt);
-        h1 = false;
+}
+
+// LEAF PHASE: test the queued leaves (both triangle loads are issued before either test).
+// Runs unpredicated for the calling lanes; lanes without a queued leaf in a slot compute on
+// triangle 0 and discard.  Sets st.node = -1 when an ANY query is satisfied.
+template <int Q, int K, bool STATS>
+TR_HD void tr_leaf_step(const tr_bvh_view& b, const tr_ray& r, tr_state& st, tr_result& res,
+                        tr_topk<K>& top, tr_counters* cnt) {
+    const bool ordered = (Q == TR_Q_FIRST || Q == TR_Q_CLOSEST);
+    const int32_t q0 = st.p0, q1 = st.p1;
+    tr_counters* nc = nullptr;
+    const bool any1 = TR_WAVE_ANY(q1 >= 0);
+    const tr_tri t0 = tr_load_tri<false>(b, q0 >= 0 ? q0 : 0, nc);
+    tr_tri t1 = t0;
+    if (any1) t1 = tr_load_tri<false>(b, q1 >= 0 ? q1 : 0, nc);
+    if (STATS && q0 >= 0) cnt->tris++;
+    bool fin = tr_fold_leaf<Q, K>(q0 >= 0, r, t0, q0, st.p0n, st.p0f, res, top);
+    if (any1) {
+        const bool live = q1 >= 0 && !fin && (!ordered || st.p1n <= res.best_t);
+        if (STATS && live) cnt->tris++;
+        fin = tr_fold_leaf<Q, K>(live, r, t1, q1, st.p1n, st.p1f, res, top) || fin;
     }
-    if (ordered) {
-        h0 = h0 && (tn0 <= res.best_t);
-        h1 = h1 && (tn1 <= res.best_t);
+    st.p0 = -1; st.p1 = -1;
+    if (Q == TR_Q_ANY && fin) st.node = -1;
+}
+
+// FUSED STEP (software-pipelined schedule): one trip = node fetch for every lane that has a
+// node + leaf tests for the leaves queued by the PREVIOUS trip.  The node loads are issued
+// first, so the triangle loads and the node loads are in flight together: one memory round
+// trip per trip.  Lanes never sit out.
+template <int Q, int K, bool STATS>
+TR_HD void tr_fused_step(const tr_bvh_view& b, const tr_ray& r, tr_state& st, tr_result& res,
+                         tr_topk<K>& top, tr_counters* cnt, const tr_ring ring) {
+    const bool ordered = (Q == TR_Q_FIRST || Q == TR_Q_CLOSEST);
+    const bool has_node = st.node >= 0;
+    const tr_f4* np = reinterpret_cast<const tr_f4*>(b.nodes + (has_node ? st.node : 0));
+    const tr_f4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+    if (STATS && has_node) cnt->nodes++;
+    bool fin = false;
+    const int32_t q0 = st.p0, q1 = st.p1;
+    if (TR_WAVE_ANY(q0 >= 0 || q1 >= 0)) {
+        tr_counters* nc = nullptr;
+        const bool any1 = TR_WAVE_ANY(q1 >= 0);
+        const tr_tri t0 = tr_load_tri<false>(b, q0 >= 0 ? q0 : 0, nc);
+        tr_tri t1 = t0;
+        if (any1) t1 = tr_load_tri<false>(b, q1 >= 0 ? q1 : 0, nc);
+        if (STATS && q0 >= 0) cnt->tris++;
+        fin = tr_fold_leaf<Q, K>(q0 >= 0, r, t0, q0, st.p0n, st.p0f, res, top);
+        if (any1) {
+            const bool live = q1 >= 0 && !fin && (!ordered || st.p1n <= res.best_t);
+            if (STATS && live) cnt->tris++;
+            fin = tr_fold_leaf<Q, K>(live, r, t1, q1, st.p1n, st.p1f, res, top) || fin;
+        }
     }
-    if (!finished) {
+    st.p0 = -1; st.p1 = -1;
+    if (Q == TR_Q_ANY && fin) st.node = -1;
+    // n0 = lo0.xyz hi0.x | n1 = hi0.yz lo1.xy | n2 = lo1.z hi1.xyz | n3 = c0 c1 parent sibling
+    float tn0, tf0, tn1, tf1;
+    tr_slab(r, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tn0, tf0);
+    tr_slab(r, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, tn1, tf1);
+    union { float f; int32_t i; } u0, u1, u2, u3;
+    u0.f = n3.x; u1.f = n3.y; u2.f = n3.z; u3.f = n3.w;
+    const int32_t c0 = u0.i, c1 = u1.i;
+    int32_t parent = u2.i, sibling = u3.i;
+    const float lim = ordered ? res.best_t : TR_TMAX;
+    const bool go = has_node && st.node >= 0;
+    bool h0 = tr_slab_hit(tn0, tf0, lim) && go;
+    bool h1 = tr_slab_hit(tn1, tf1, lim) && go;
+    if (h0 && c0 < 0) { st.p0 = ~c0; st.p0n = tn0; st.p0f = tf0; h0 = false; }
+    if (h1 && c1 < 0) { st.p1 = ~c1; st.p1n = tn1; st.p1f = tf1; h1 = false; }
+    if (go) {
         if (h0 | h1) {
             const bool both = h0 & h1;
-            const bool swap = both ? (tn1 < tn0) : h1;   // descend into c1?
-            const int32_t near = swap ? c1 : c0;
+            const bool swap = both ? (tn1 < tn0) : h1;
             if (both) {
                 st.trail |= (1ull << st.depth);
                 if (ring.base) {
@@ -216,12 +311,11 @@ TR_HD bool tr_step(const tr_bvh_view& b, const tr_ray& r, tr_state& st, tr_resul
                     st.owned = (st.owned & ~(TR_RING_MASK << slot)) | (1ull << st.depth);
                 }
             }
-            st.node = near;
+            st.node = swap ? c1 : c0;
             st.depth++;
         } else if (st.trail == 0) {
-            finished = true;
+            st.node = -1;
         } else {
-            // backtrack to the deepest ancestor that still owes its far child
             const uint32_t j = 63u - (uint32_t)__builtin_clzll(st.trail);
             st.trail &= ~(1ull << j);
             if (ring.base && ((st.owned >> j) & 1ull)) {
@@ -229,23 +323,22 @@ TR_HD bool tr_step(const tr_bvh_view& b, const tr_ray& r, tr_state& st, tr_resul
             } else {
                 int32_t node = st.node;
                 uint32_t depth = st.depth;
-                while (depth > j + 1) {   // climb; `node` is at `depth`, (parent, sibling) its links
+                while (depth > j + 1) {
                     node = parent;
                     const tr_link l = b.links[node];
                     parent = l.parent; sibling = l.sibling;
                     depth--;
                     if (STATS) cnt->climbs++;
                 }
-                st.node = sibling;        // far child at depth j+1 (internal by construction)
+                st.node = sibling;
             }
             st.depth = j + 1;
         }
     }
-    TR_CONVERGE();
-    return finished;
 }
 
-// Full traversal of one ray.  `valid` = tr_ray_setup's result.
+// Full traversal of one ray (generic schedule: leaf phase whenever something is queued).
+// The wave-level kernels run the two phases under votes instead (traverse.hip).
 template <int Q, int K, bool STATS>
 TR_HD void tr_traverse(const tr_bvh_view& b, const tr_ray& r, bool valid, tr_result& res,
                        tr_topk<K>& top, tr_counters* cnt, const tr_ring ring = tr_ring{nullptr, 0}) {
@@ -254,5 +347,9 @@ TR_HD void tr_traverse(const tr_bvh_view& b, const tr_ray& r, bool valid, tr_res
     if (!valid || b.num_tris < 2) return;   // F < 2 is handled by the brute-force kernel
     tr_state st;
     tr_state_init(st);
-    while (!tr_step<Q, K, STATS>(b, r, st, res, top, cnt, ring)) {}
+    while (!tr_done(st)) {
+        if (tr_pending(st)) tr_leaf_step<Q, K, STATS>(b, r, st, res, top, cnt);
+        else tr_node_step<Q, STATS>(b, r, st, res, cnt, ring);
+        TR_CONVERGE();
+    }
 }

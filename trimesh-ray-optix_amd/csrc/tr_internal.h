@@ -65,10 +65,11 @@ int tr_build_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_
 
 // options ---------------------------------------------------------------------------------
 struct tr_options {
-    int persistent = 1;
+    int persistent = 0;
     int blocks_per_cu = 8;
     int refill = 1;
     int refill_min = 16;
     int xcd_segments = 1;
+    int leaf_min = 0;     // 0 = fused (software-pipelined) schedule, >0 = while-while vote threshold
 };
 tr_options& tr_opts();

@@ -21,11 +21,15 @@
 // so that jump threading cannot give the loop several back edges (LLVM then nests the loop
 // and lanes on different paths serialise).  Emits no instruction.
 #define TR_CONVERGE() __builtin_amdgcn_wave_barrier()
+// true when the predicate holds in any active lane of the wave (wave-uniform branch)
+#define TR_WAVE_ANY(x) (__ballot(x) != 0ull)
 #else
 #define TR_CONVERGE() ((void)0)
+#define TR_WAVE_ANY(x) (x)
 #endif
 #else
 #define TR_CONVERGE() ((void)0)
+#define TR_WAVE_ANY(x) (x)
 #define TR_HD static inline
 #define TR_HDM inline
 #endif
@@ -84,7 +88,9 @@ struct tr_hit {
     float det;   // > 0 : front face (CCW from the ray origin)
 };
 
-// Moller-Trumbore given the triangle's own slab interval [tn, tf].
+// Moller-Trumbore given the triangle's own slab interval [tn, tf].  Early exits are kept: in
+// a wave most candidate triangles fail on det / U / V, and the compiler skips the rest of the
+// test when no lane is left (s_cbranch_execz).
 TR_HD bool tr_tri_mt(const tr_ray& r, float ax, float ay, float az, float bx, float by, float bz,
                      float cx, float cy, float cz, float tn, float tf, tr_hit& h) {
     float e1x = bx - ax, e1y = by - ay, e1z = bz - az;

@@ -6,7 +6,7 @@
 //                work counter (Aila & Laine style persistent threads) -- no tail of
 //                half-empty workgroups, and the counter ring lets launches overlap.
 //   direct     : grid = ceil(n/256), ray = global thread id.
-// The per-ray state machine is tr_traverse (tr_bvh.h): stackless trail + parent links.
+// The per-ray state machine is tr_node_step / tr_leaf_step (tr_bvh.h): stackless trail + ring.
 // Kernel parameters travel by value (no per-call malloc/memcpy/free as in ray.cpp:279-287).
 #include "tr_internal.h"
 
@@ -99,17 +99,53 @@ __device__ __forceinline__ void brute_one(const tr_bvh_view& b, const tr_ray& r,
     }
 }
 
+// Wave-level "while-while" schedule (Aila & Laine 2009 adapted to wave64): each loop trip runs
+// EITHER the node phase (lanes that have a node and no queued leaf) OR the leaf phase (lanes
+// with queued leaves), chosen by a wave vote, so the long triangle-test code runs rarely and
+// with many lanes instead of on every trip for a few lanes.  The leaf phase fires when at
+// least `leaf_min` lanes have a queued leaf or no lane can take a node step.  Lanes with a
+// queued leaf sit out node trips (their traversal resumes after the leaf phase); results do
+// not depend on the schedule (the hit predicate is order-independent, tr_math.h).
+template <int Q, int K, bool STATS>
+__device__ __forceinline__ void wave_traverse(const tr_bvh_view& b, const tr_ray& r, bool go,
+                                              tr_result& res, tr_topk<K>& top, tr_counters* cnt,
+                                              const tr_ring ring, int leaf_min) {
+    tr_state st;
+    tr_state_init(st);
+    tr_result_init(res);
+    if (Q == TR_Q_LOCATION) top.init();
+    if (!go) st.node = -1;
+    if (leaf_min <= 0) {   // fused, software-pipelined schedule: every lane advances on every trip
+        while (!tr_done(st)) {
+            tr_fused_step<Q, K, STATS>(b, r, st, res, top, cnt, ring);
+            TR_CONVERGE();
+        }
+        return;
+    }
+    for (;;) {
+        const bool pend = tr_pending(st);
+        const bool can_node = !pend && st.node >= 0;
+        const unsigned long long ml = __ballot(pend), mn = __ballot(can_node);
+        if ((ml | mn) == 0ull) break;
+        if (ml != 0ull && (mn == 0ull || (int)__popcll(ml) >= leaf_min)) {
+            if (pend) tr_leaf_step<Q, K, STATS>(b, r, st, res, top, cnt);
+        } else {
+            if (can_node) tr_node_step<Q, STATS>(b, r, st, res, cnt, ring);
+        }
+    }
+}
+
 template <int Q, bool STATS>
 __device__ __forceinline__ void process_ray(const tr_bvh_view& b, const RayFetch& rf,
                                             const QueryOut& out, int64_t i, tr_counters* cnt,
-                                            const tr_ring ring) {
+                                            const tr_ring ring, int leaf_min) {
     float o[3], d[3];
     fetch_ray(rf, i, o, d);
     tr_ray r;
     bool valid = tr_ray_setup(r, o[0], o[1], o[2], d[0], d[1], d[2]);
     tr_result res;
     tr_topk<1> top;
-    if (b.num_tris >= 2) tr_traverse<Q, 1, STATS>(b, r, valid, res, top, cnt, ring);
+    if (b.num_tris >= 2) wave_traverse<Q, 1, STATS>(b, r, valid, res, top, cnt, ring, leaf_min);
     else brute_one<Q>(b, r, valid, res);
     write_result<Q>(b, out, i, res);
 }
@@ -129,18 +165,18 @@ __device__ __forceinline__ void flush_stats(const tr_counters& c, unsigned long 
 
 template <int Q, bool STATS>
 __global__ __launch_bounds__(256) void k_query_direct(tr_bvh_view b, RayFetch rf, QueryOut out,
-                                                      unsigned long long* stats) {
+                                                      int leaf_min, unsigned long long* stats) {
     __shared__ int32_t ring_lds[TR_RING * 256];
     const tr_ring ring = {ring_lds + threadIdx.x, 256};
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     tr_counters cnt = {0, 0, 0};
-    if (i < rf.n) process_ray<Q, STATS>(b, rf, out, i, &cnt, ring);
+    if (i < rf.n) process_ray<Q, STATS>(b, rf, out, i, &cnt, ring, leaf_min);
     flush_stats<STATS>(cnt, stats);
 }
 
 template <int Q, bool STATS>
 __global__ __launch_bounds__(256) void k_query_persistent(tr_bvh_view b, RayFetch rf, QueryOut out,
-                                                          unsigned long long* counter,
+                                                          unsigned long long* counter, int leaf_min,
                                                           unsigned long long* stats) {
     __shared__ int32_t ring_lds[TR_RING * 256];
     const tr_ring ring = {ring_lds + threadIdx.x, 256};
@@ -152,7 +188,7 @@ __global__ __launch_bounds__(256) void k_query_persistent(tr_bvh_view b, RayFetc
         base = __shfl(base, 0);
         if ((int64_t)base >= rf.n) break;
         int64_t i = (int64_t)base + lane;
-        if (i < rf.n) process_ray<Q, STATS>(b, rf, out, i, &cnt, ring);
+        if (i < rf.n) process_ray<Q, STATS>(b, rf, out, i, &cnt, ring, leaf_min);
     }
     flush_stats<STATS>(cnt, stats);
 }
@@ -173,7 +209,7 @@ __device__ __forceinline__ uint32_t xcc_id() {
 template <int Q, bool STATS>
 __global__ __launch_bounds__(256) void k_query_refill(tr_bvh_view b, RayFetch rf, QueryOut out,
                                                       unsigned long long* counters,   // [8]
-                                                      int refill_min, int nseg,
+                                                      int refill_min, int nseg, int leaf_min,
                                                       unsigned long long* stats) {
     __shared__ int32_t ring_lds[TR_RING * 256];
     const tr_ring ring = {ring_lds + threadIdx.x, 256};
@@ -248,11 +284,17 @@ __global__ __launch_bounds__(256) void k_query_refill(tr_bvh_view b, RayFetch rf
         }
         // traverse until enough lanes have gone idle to make a refill worthwhile
         for (;;) {
-            if (active) {
-                if (tr_step<Q, 1, STATS>(b, r, st, res, top, &cnt, ring)) {
-                    active = false;
-                    unwritten = true;
-                }
+            const bool pend = active && tr_pending(st);
+            const bool can_node = active && !pend && st.node >= 0;
+            const unsigned long long ml = __ballot(pend), mn = __ballot(can_node);
+            if (ml != 0ull && (mn == 0ull || (int)__popcll(ml) >= leaf_min)) {
+                if (pend) tr_leaf_step<Q, 1, STATS>(b, r, st, res, top, &cnt);
+            } else {
+                if (can_node) tr_node_step<Q, STATS>(b, r, st, res, &cnt, ring);
+            }
+            if (active && tr_done(st)) {
+                active = false;
+                unwritten = true;
             }
             const unsigned long long act = __ballot(active);
             if (act == 0ull) break;
@@ -281,7 +323,7 @@ __global__ __launch_bounds__(256) void k_location(tr_bvh_view b, RayFetch rf, in
     tr_topk<K> top;
     tr_counters* nc = nullptr;
     if (b.num_tris >= 2) {
-        tr_traverse<TR_Q_LOCATION, K, false>(b, r, valid, res, top, nc, ring);
+        wave_traverse<TR_Q_LOCATION, K, false>(b, r, valid, res, top, nc, ring, 16);
     } else {
         top.init();
         brute_one<TR_Q_LOCATION>(b, r, valid, res);
@@ -485,13 +527,13 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
         TR_HIP_TRY(hipMemsetAsync(counter, 0, 8 * sizeof(unsigned long long), stream));
         if (opt.refill)
             hipLaunchKernelGGL((k_query_refill<Q, STATS>), dim3((unsigned)pgrid), dim3(256), 0, stream,
-                               view, rf, out, counter, opt.refill_min, opt.xcd_segments ? 8 : 1, d_stats);
+                               view, rf, out, counter, opt.refill_min, opt.xcd_segments ? 8 : 1, opt.leaf_min, d_stats);
         else
             hipLaunchKernelGGL((k_query_persistent<Q, STATS>), dim3((unsigned)pgrid), dim3(256), 0, stream,
-                               view, rf, out, counter, d_stats);
+                               view, rf, out, counter, opt.leaf_min, d_stats);
     } else {
         hipLaunchKernelGGL((k_query_direct<Q, STATS>), dim3((unsigned)nblocks_direct), dim3(256), 0, stream,
-                           view, rf, out, d_stats);
+                           view, rf, out, opt.leaf_min, d_stats);
     }
     TR_HIP_TRY(hipGetLastError());
     return TR_OK;
