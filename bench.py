@@ -198,7 +198,7 @@ def main():
                        "hit_fraction": round(float(out[0].float().mean().item()), 4)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                         "kernel": "k_query_persistent<CLOSEST>", "kernel_avg_ms": round(kernel_avg_ms, 4),
+                         "kernel": "k_query_direct<CLOSEST>", "kernel_avg_ms": round(kernel_avg_ms, 4),
                          "kernel_min_ms": round(kernel_ms[0], 4),
                          "algorithmic_bytes": int(algo_bytes),
                          "note": "50 B/ray compulsory I/O + one read of the BVH arena per launch; the path "

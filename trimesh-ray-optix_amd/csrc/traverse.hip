@@ -135,19 +135,21 @@ __device__ __forceinline__ void wave_traverse(const tr_bvh_view& b, const tr_ray
     }
 }
 
+// All 64 lanes of a wave must call this together (`in_range` = the lane owns ray i): the
+// cooperative heavy-ray pass uses every lane.
 template <int Q, bool STATS>
 __device__ __forceinline__ void process_ray(const tr_bvh_view& b, const RayFetch& rf,
-                                            const QueryOut& out, int64_t i, tr_counters* cnt,
-                                            const tr_ring ring, int leaf_min) {
-    float o[3], d[3];
-    fetch_ray(rf, i, o, d);
+                                            const QueryOut& out, int64_t i, bool in_range,
+                                            tr_counters* cnt, const tr_ring ring, int leaf_min) {
+    float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
+    if (in_range) fetch_ray(rf, i, o, d);
     tr_ray r;
-    bool valid = tr_ray_setup(r, o[0], o[1], o[2], d[0], d[1], d[2]);
+    const bool valid = tr_ray_setup(r, o[0], o[1], o[2], d[0], d[1], d[2]) && in_range;
     tr_result res;
     tr_topk<1> top;
     if (b.num_tris >= 2) wave_traverse<Q, 1, STATS>(b, r, valid, res, top, cnt, ring, leaf_min);
     else brute_one<Q>(b, r, valid, res);
-    write_result<Q>(b, out, i, res);
+    if (in_range) write_result<Q>(b, out, i, res);
 }
 
 template <bool STATS>
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(256) void k_query_direct(tr_bvh_view b, RayFetch rf
     const tr_ring ring = {ring_lds + threadIdx.x, 256};
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     tr_counters cnt = {0, 0, 0};
-    if (i < rf.n) process_ray<Q, STATS>(b, rf, out, i, &cnt, ring, leaf_min);
+    process_ray<Q, STATS>(b, rf, out, i, i < rf.n, &cnt, ring, leaf_min);
     flush_stats<STATS>(cnt, stats);
 }
 
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(256) void k_query_persistent(tr_bvh_view b, RayFetc
         base = __shfl(base, 0);
         if ((int64_t)base >= rf.n) break;
         int64_t i = (int64_t)base + lane;
-        if (i < rf.n) process_ray<Q, STATS>(b, rf, out, i, &cnt, ring, leaf_min);
+        process_ray<Q, STATS>(b, rf, out, i, i < rf.n, &cnt, ring, leaf_min);
     }
     flush_stats<STATS>(cnt, stats);
 }
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(256) void k_location(tr_bvh_view b, RayFetch rf, in
     tr_topk<K> top;
     tr_counters* nc = nullptr;
     if (b.num_tris >= 2) {
-        wave_traverse<TR_Q_LOCATION, K, false>(b, r, valid, res, top, nc, ring, 16);
+        wave_traverse<TR_Q_LOCATION, K, false>(b, r, valid, res, top, nc, ring, 0);
     } else {
         top.init();
         brute_one<TR_Q_LOCATION>(b, r, valid, res);
