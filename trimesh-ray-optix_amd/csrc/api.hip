@@ -179,6 +179,11 @@ int tr_set_option(const char* name, int64_t value) {
         return TR_OK;
     }
     if (!strcmp(name, "refill")) { g_options.refill = value != 0; return TR_OK; }
+    if (!strcmp(name, "xcd_chunk")) {
+        if (value < 0 || value > 65536) return tr_fail(TR_ERR_INVALID_ARG, "xcd_chunk out of range");
+        g_options.xcd_chunk = (int)value;
+        return TR_OK;
+    }
     if (!strcmp(name, "xcd_segments")) { g_options.xcd_segments = value != 0; return TR_OK; }
     if (!strcmp(name, "leaf_min")) {
         if (value < 0 || value > 64) return tr_fail(TR_ERR_INVALID_ARG, "leaf_min out of range");

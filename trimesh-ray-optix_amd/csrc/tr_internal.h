@@ -69,7 +69,8 @@ struct tr_options {
     int blocks_per_cu = 8;
     int refill = 1;
     int refill_min = 16;
-    int xcd_segments = 1;
+    int xcd_segments = 1;   // refill kernel: per-XCD work counters
+    int xcd_chunk = 256;    // direct kernel: blocks per XCD-local chunk (0 = identity map)
     int leaf_min = 0;     // 0 = fused (software-pipelined) schedule, >0 = while-while vote threshold
 };
 tr_options& tr_opts();

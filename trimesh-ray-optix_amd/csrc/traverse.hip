@@ -167,10 +167,25 @@ __device__ __forceinline__ void flush_stats(const tr_counters& c, unsigned long 
 
 template <int Q, bool STATS>
 __global__ __launch_bounds__(256) void k_query_direct(tr_bvh_view b, RayFetch rf, QueryOut out,
-                                                      int leaf_min, unsigned long long* stats) {
+                                                      int leaf_min, int xcd_map,
+                                                      unsigned long long* stats) {
     __shared__ int32_t ring_lds[TR_RING * 256];
     const tr_ring ring = {ring_lds + threadIdx.x, 256};
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    // XCD-aware block -> ray-tile map: workgroups are dealt round-robin over the 8 XCDs
+    // (blocks b and b+8 share one).  The ray range is cut into chunks of `xcd_map` blocks and
+    // chunk c goes to XCD c % 8, so each XCD's private L2 works on compact pieces of the image
+    // (and of the BVH) while expensive regions are still spread over all XCDs.  Placement only
+    // affects speed.
+    int64_t blk = blockIdx.x;
+    if (xcd_map > 0) {
+        const int64_t T = xcd_map, span = 8 * T;
+        const int64_t nfull = (int64_t)gridDim.x / span * span;   // blocks covered by whole spans
+        if (blk < nfull) {
+            const int64_t x = blk & 7, k = blk >> 3;              // XCD label, index within it
+            blk = ((k / T) * 8 + x) * T + (k % T);
+        }
+    }
+    int64_t i = blk * 256 + threadIdx.x;
     tr_counters cnt = {0, 0, 0};
     process_ray<Q, STATS>(b, rf, out, i, i < rf.n, &cnt, ring, leaf_min);
     flush_stats<STATS>(cnt, stats);
@@ -535,7 +550,7 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
                                view, rf, out, counter, opt.leaf_min, d_stats);
     } else {
         hipLaunchKernelGGL((k_query_direct<Q, STATS>), dim3((unsigned)nblocks_direct), dim3(256), 0, stream,
-                           view, rf, out, opt.leaf_min, d_stats);
+                           view, rf, out, opt.leaf_min, opt.xcd_chunk, d_stats);
     }
     TR_HIP_TRY(hipGetLastError());
     return TR_OK;
