@@ -90,7 +90,7 @@ def main():
     if args.blocks_per_cu is not None:
         hops.set_option("blocks_per_cu", args.blocks_per_cu)
     for kv in args.opt:
-        k, v_ = kv.split("=")
+        k, v_ = kv.split("=", 1)
         hops.set_option(k, int(v_))
 
     # ---- workload (synthetic, deterministic) -------------------------------------------------
