@@ -74,7 +74,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist_on = world > 1
+    dist_on = "RANK" in os.environ and "WORLD_SIZE" in os.environ   # launched by torch.distributed.run
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
