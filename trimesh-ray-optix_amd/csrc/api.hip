@@ -179,6 +179,7 @@ int tr_set_option(const char* name, int64_t value) {
         return TR_OK;
     }
     if (!strcmp(name, "refill")) { g_options.refill = value != 0; return TR_OK; }
+    if (!strcmp(name, "compact")) { g_options.compact = value != 0; return TR_OK; }
     if (!strcmp(name, "xcd_chunk")) {
         if (value < 0 || value > 65536) return tr_fail(TR_ERR_INVALID_ARG, "xcd_chunk out of range");
         g_options.xcd_chunk = (int)value;

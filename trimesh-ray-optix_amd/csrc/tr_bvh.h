@@ -93,9 +93,29 @@ struct tr_result {
     int32_t count;
 };
 
-template <bool STATS>
+// COMPACT addressing: byte offsets fit 32 bits (nodes*64 and tris*48 below 4 GiB), so the
+// loads use an SGPR base + 32-bit VGPR offset instead of 64-bit per-lane address arithmetic
+template <bool COMPACT>
+TR_HD const tr_f4* tr_node_ptr(const tr_bvh_view& b, int32_t node) {
+    if (COMPACT)
+        return reinterpret_cast<const tr_f4*>(reinterpret_cast<const char*>(b.nodes) + ((uint32_t)node << 6));
+    return reinterpret_cast<const tr_f4*>(b.nodes + node);
+}
+template <bool COMPACT>
+TR_HD const tr_f4* tr_tri_ptr(const tr_bvh_view& b, int32_t slot) {
+    if (COMPACT)
+        return reinterpret_cast<const tr_f4*>(reinterpret_cast<const char*>(b.tris) + (uint32_t)slot * 48u);
+    return reinterpret_cast<const tr_f4*>(b.tris + slot);
+}
+
+TR_HD void tr_result_init(tr_result& res) {
+    res.best_t = TR_TMAX; res.best_face = -1; res.best_slot = -1;
+    res.U = 0.f; res.V = 0.f; res.det = 1.f; res.count = 0;
+}
+
+template <bool STATS, bool COMPACT = false>
 TR_HD tr_tri tr_load_tri(const tr_bvh_view& b, int32_t slot, tr_counters* cnt) {
-    const tr_f4* p = reinterpret_cast<const tr_f4*>(b.tris + slot);
+    const tr_f4* p = tr_tri_ptr<COMPACT>(b, slot);
     tr_f4 q0 = p[0], q1 = p[1], q2 = p[2];
     tr_tri t;
     t.ax = q0.x; t.ay = q0.y; t.az = q0.z; t.bx = q0.w;
@@ -145,30 +165,37 @@ struct tr_ring {
     int32_t stride;
 };
 
-// Per-lane traversal state between two iterations.
-struct tr_state {
+// Per-lane traversal state between two iterations.  W = uint64_t in general; uint32_t when
+// the hierarchy is at most 32 levels high (halves the 64-bit shift/clz work per trip).
+template <typename W>
+struct tr_state_t {
     int32_t node;     // next internal node to visit, -1 = hierarchy exhausted
     uint32_t depth;
-    uint64_t trail;   // bit k: the node at depth k on the current path still owes its far child
-    uint64_t owned;   // bit k: that far child is still in ring slot k % TR_RING
+    W trail;          // bit k: the node at depth k on the current path still owes its far child
+    W owned;          // bit k: that far child is still in ring slot k % TR_RING
     // leaves found by the previous node visit, tested one iteration later so that their
     // triangle loads overlap the next node's load (one memory round trip per iteration)
     int32_t p0, p1;   // tri slots, -1 = none
     float p0n, p0f, p1n, p1f;   // their slab intervals
 };
+typedef tr_state_t<uint64_t> tr_state;
+typedef tr_state_t<uint32_t> tr_state32;
 
-TR_HD void tr_result_init(tr_result& res) {
-    res.best_t = TR_TMAX; res.best_face = -1; res.best_slot = -1;
-    res.U = 0.f; res.V = 0.f; res.det = 1.f; res.count = 0;
-}
+TR_HD uint32_t tr_top_bit(uint64_t x) { return 63u - (uint32_t)__builtin_clzll(x); }
+TR_HD uint32_t tr_top_bit(uint32_t x) { return 31u - (uint32_t)__builtin_clz(x); }
+TR_HD uint64_t tr_ring_mask(uint64_t) { return TR_RING_MASK; }
+TR_HD uint32_t tr_ring_mask(uint32_t) { return 0x00010001u; }
 
-TR_HD void tr_state_init(tr_state& st) {
+template <typename W>
+TR_HD void tr_state_init(tr_state_t<W>& st) {
     st.node = 0; st.depth = 0; st.trail = 0; st.owned = 0;
     st.p0 = -1; st.p1 = -1; st.p0n = st.p0f = st.p1n = st.p1f = 0.f;
 }
 
-TR_HD bool tr_pending(const tr_state& st) { return st.p0 >= 0 || st.p1 >= 0; }
-TR_HD bool tr_done(const tr_state& st) { return st.node < 0 && st.p0 < 0 && st.p1 < 0; }
+template <typename W>
+TR_HD bool tr_pending(const tr_state_t<W>& st) { return st.p0 >= 0 || st.p1 >= 0; }
+template <typename W>
+TR_HD bool tr_done(const tr_state_t<W>& st) { return st.node < 0 && st.p0 < 0 && st.p1 < 0; }
 
 // NODE PHASE: visit st.node (lane must have a node and no queued leaf): fetch the 64-B node,
 // test both child boxes, queue hit leaf children in (p0, p1), then move to the next node
@@ -259,12 +286,12 @@ TR_HD void tr_leaf_step(const tr_bvh_view& b, const tr_ray& r, tr_state& st, tr_
 // node + leaf tests for the leaves queued by the PREVIOUS trip.  The node loads are issued
 // first, so the triangle loads and the node loads are in flight together: one memory round
 // trip per trip.  Lanes never sit out.
-template <int Q, int K, bool STATS>
-TR_HD void tr_fused_step(const tr_bvh_view& b, const tr_ray& r, tr_state& st, tr_result& res,
+template <int Q, int K, bool STATS, bool COMPACT = false, typename W = uint64_t>
+TR_HD void tr_fused_step(const tr_bvh_view& b, const tr_ray& r, tr_state_t<W>& st, tr_result& res,
                          tr_topk<K>& top, tr_counters* cnt, const tr_ring ring) {
     const bool ordered = (Q == TR_Q_FIRST || Q == TR_Q_CLOSEST);
     const bool has_node = st.node >= 0;
-    const tr_f4* np = reinterpret_cast<const tr_f4*>(b.nodes + (has_node ? st.node : 0));
+    const tr_f4* np = tr_node_ptr<COMPACT>(b, has_node ? st.node : 0);
     const tr_f4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
     if (STATS && has_node) cnt->nodes++;
     bool fin = false;
@@ -272,9 +299,9 @@ TR_HD void tr_fused_step(const tr_bvh_view& b, const tr_ray& r, tr_state& st, tr
     if (TR_WAVE_ANY(q0 >= 0 || q1 >= 0)) {
         tr_counters* nc = nullptr;
         const bool any1 = TR_WAVE_ANY(q1 >= 0);
-        const tr_tri t0 = tr_load_tri<false>(b, q0 >= 0 ? q0 : 0, nc);
+        const tr_tri t0 = tr_load_tri<false, COMPACT>(b, q0 >= 0 ? q0 : 0, nc);
         tr_tri t1 = t0;
-        if (any1) t1 = tr_load_tri<false>(b, q1 >= 0 ? q1 : 0, nc);
+        if (any1) t1 = tr_load_tri<false, COMPACT>(b, q1 >= 0 ? q1 : 0, nc);
         if (STATS && q0 >= 0) cnt->tris++;
         fin = tr_fold_leaf<Q, K>(q0 >= 0, r, t0, q0, st.p0n, st.p0f, res, top);
         if (any1) {
@@ -304,11 +331,11 @@ TR_HD void tr_fused_step(const tr_bvh_view& b, const tr_ray& r, tr_state& st, tr
             const bool both = h0 & h1;
             const bool swap = both ? (tn1 < tn0) : h1;
             if (both) {
-                st.trail |= (1ull << st.depth);
+                st.trail |= (W(1) << st.depth);
                 if (ring.base) {
                     const uint32_t slot = st.depth & (TR_RING - 1);
                     ring.base[slot * ring.stride] = swap ? c0 : c1;
-                    st.owned = (st.owned & ~(TR_RING_MASK << slot)) | (1ull << st.depth);
+                    st.owned = (st.owned & ~(tr_ring_mask(W(0)) << slot)) | (W(1) << st.depth);
                 }
             }
             st.node = swap ? c1 : c0;
@@ -316,9 +343,9 @@ TR_HD void tr_fused_step(const tr_bvh_view& b, const tr_ray& r, tr_state& st, tr
         } else if (st.trail == 0) {
             st.node = -1;
         } else {
-            const uint32_t j = 63u - (uint32_t)__builtin_clzll(st.trail);
-            st.trail &= ~(1ull << j);
-            if (ring.base && ((st.owned >> j) & 1ull)) {
+            const uint32_t j = tr_top_bit(st.trail);
+            st.trail &= ~(W(1) << j);
+            if (ring.base && ((st.owned >> j) & W(1))) {
                 st.node = ring.base[(j & (TR_RING - 1)) * ring.stride];
             } else {
                 int32_t node = st.node;

@@ -68,6 +68,7 @@ struct tr_options {
     int persistent = 0;
     int blocks_per_cu = 8;
     int refill = 1;
+    int compact = 1;      // allow the 32-bit trail / 32-bit offset kernels when the BVH permits
     int refill_min = 16;
     int xcd_segments = 1;   // refill kernel: per-XCD work counters
     int xcd_chunk = 256;    // direct kernel: blocks per XCD-local chunk (0 = identity map)

@@ -99,45 +99,34 @@ __device__ __forceinline__ void brute_one(const tr_bvh_view& b, const tr_ray& r,
     }
 }
 
-// Wave-level "while-while" schedule (Aila & Laine 2009 adapted to wave64): each loop trip runs
-// EITHER the node phase (lanes that have a node and no queued leaf) OR the leaf phase (lanes
-// with queued leaves), chosen by a wave vote, so the long triangle-test code runs rarely and
-// with many lanes instead of on every trip for a few lanes.  The leaf phase fires when at
-// least `leaf_min` lanes have a queued leaf or no lane can take a node step.  Lanes with a
-// queued leaf sit out node trips (their traversal resumes after the leaf phase); results do
-// not depend on the schedule (the hit predicate is order-independent, tr_math.h).
-template <int Q, int K, bool STATS>
+// Wave-level traversal of one ray per lane with the fused, software-pipelined trip
+// (tr_fused_step): every lane advances on every trip; results do not depend on the schedule
+// (the hit predicate is order-independent, tr_math.h).
+template <bool C> struct tr_word { typedef uint64_t T; };
+template <> struct tr_word<true> { typedef uint32_t T; };
+
+// COMPACT = the hierarchy is at most 32 levels high and both arrays are below 4 GiB: 32-bit
+// trail/owned words and SGPR-base + 32-bit-offset loads (chosen on the host per BVH).
+template <int Q, int K, bool STATS, bool COMPACT = false>
 __device__ __forceinline__ void wave_traverse(const tr_bvh_view& b, const tr_ray& r, bool go,
                                               tr_result& res, tr_topk<K>& top, tr_counters* cnt,
                                               const tr_ring ring, int leaf_min) {
-    tr_state st;
-    tr_state_init(st);
     tr_result_init(res);
     if (Q == TR_Q_LOCATION) top.init();
-    if (!go) st.node = -1;
-    if (leaf_min <= 0) {   // fused, software-pipelined schedule: every lane advances on every trip
-        while (!tr_done(st)) {
-            tr_fused_step<Q, K, STATS>(b, r, st, res, top, cnt, ring);
-            TR_CONVERGE();
-        }
-        return;
+    // fused, software-pipelined schedule: every lane advances on every trip
+    typedef typename tr_word<COMPACT>::T W;
+    tr_state_t<W> fs;
+    tr_state_init(fs);
+    if (!go) fs.node = -1;
+    while (!tr_done(fs)) {
+        tr_fused_step<Q, K, STATS, COMPACT, W>(b, r, fs, res, top, cnt, ring);
+        TR_CONVERGE();
     }
-    for (;;) {
-        const bool pend = tr_pending(st);
-        const bool can_node = !pend && st.node >= 0;
-        const unsigned long long ml = __ballot(pend), mn = __ballot(can_node);
-        if ((ml | mn) == 0ull) break;
-        if (ml != 0ull && (mn == 0ull || (int)__popcll(ml) >= leaf_min)) {
-            if (pend) tr_leaf_step<Q, K, STATS>(b, r, st, res, top, cnt);
-        } else {
-            if (can_node) tr_node_step<Q, STATS>(b, r, st, res, cnt, ring);
-        }
-    }
+    (void)leaf_min;
 }
 
-// All 64 lanes of a wave must call this together (`in_range` = the lane owns ray i): the
-// cooperative heavy-ray pass uses every lane.
-template <int Q, bool STATS>
+// All 64 lanes of a wave call this together (`in_range` = the lane owns ray i).
+template <int Q, bool STATS, bool COMPACT = false>
 __device__ __forceinline__ void process_ray(const tr_bvh_view& b, const RayFetch& rf,
                                             const QueryOut& out, int64_t i, bool in_range,
                                             tr_counters* cnt, const tr_ring ring, int leaf_min) {
@@ -147,7 +136,7 @@ __device__ __forceinline__ void process_ray(const tr_bvh_view& b, const RayFetch
     const bool valid = tr_ray_setup(r, o[0], o[1], o[2], d[0], d[1], d[2]) && in_range;
     tr_result res;
     tr_topk<1> top;
-    if (b.num_tris >= 2) wave_traverse<Q, 1, STATS>(b, r, valid, res, top, cnt, ring, leaf_min);
+    if (b.num_tris >= 2) wave_traverse<Q, 1, STATS, COMPACT>(b, r, valid, res, top, cnt, ring, leaf_min);
     else brute_one<Q>(b, r, valid, res);
     if (in_range) write_result<Q>(b, out, i, res);
 }
@@ -165,7 +154,7 @@ __device__ __forceinline__ void flush_stats(const tr_counters& c, unsigned long 
     }
 }
 
-template <int Q, bool STATS>
+template <int Q, bool STATS, bool COMPACT>
 __global__ __launch_bounds__(256) void k_query_direct(tr_bvh_view b, RayFetch rf, QueryOut out,
                                                       int leaf_min, int xcd_map,
                                                       unsigned long long* stats) {
@@ -187,7 +176,7 @@ __global__ __launch_bounds__(256) void k_query_direct(tr_bvh_view b, RayFetch rf
     }
     int64_t i = blk * 256 + threadIdx.x;
     tr_counters cnt = {0, 0, 0};
-    process_ray<Q, STATS>(b, rf, out, i, i < rf.n, &cnt, ring, leaf_min);
+    process_ray<Q, STATS, COMPACT>(b, rf, out, i, i < rf.n, &cnt, ring, leaf_min);
     flush_stats<STATS>(cnt, stats);
 }
 
@@ -549,8 +538,15 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
             hipLaunchKernelGGL((k_query_persistent<Q, STATS>), dim3((unsigned)pgrid), dim3(256), 0, stream,
                                view, rf, out, counter, opt.leaf_min, d_stats);
     } else {
-        hipLaunchKernelGGL((k_query_direct<Q, STATS>), dim3((unsigned)nblocks_direct), dim3(256), 0, stream,
-                           view, rf, out, opt.leaf_min, opt.xcd_chunk, d_stats);
+        const bool compact = opt.compact && bvh->depth <= 32 &&
+                             bvh->num_nodes * (int64_t)sizeof(tr_node) < ((int64_t)1 << 32) &&
+                             bvh->num_tris * (int64_t)sizeof(tr_tri) < ((int64_t)1 << 32);
+        if (compact)
+            hipLaunchKernelGGL((k_query_direct<Q, STATS, true>), dim3((unsigned)nblocks_direct), dim3(256), 0, stream,
+                               view, rf, out, opt.leaf_min, opt.xcd_chunk, d_stats);
+        else
+            hipLaunchKernelGGL((k_query_direct<Q, STATS, false>), dim3((unsigned)nblocks_direct), dim3(256), 0, stream,
+                               view, rf, out, opt.leaf_min, opt.xcd_chunk, d_stats);
     }
     TR_HIP_TRY(hipGetLastError());
     return TR_OK;
