@@ -146,7 +146,8 @@ int tr_trace_stats_closest(const tr_bvh *bvh, const tr_rays *rays, tr_trace_stat
                            void *stream);
 
 /* -- tuning knob (process-wide): kernel variant for the query launchers.
- *    name = "persistent" (0/1), "refill" (0/1), "refill_min" (1..64 idle lanes that
+ *    name = "adaptive" (0/1: learn the launch order from the previous launch), "compact",
+ *    "xcd_chunk", "persistent" (0/1), "refill" (0/1), "refill_min" (1..64 idle lanes that
  *    trigger a refill), "blocks_per_cu" (int).  Returns TR_ERR_INVALID_ARG for unknown names.                                                                   */
 int tr_set_option(const char *name, int64_t value);
 

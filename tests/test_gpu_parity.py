@@ -344,3 +344,43 @@ def test_launch_shapes_agree(device):
     assert torch.allclose(rec, loc[hit], rtol=1e-5, atol=2e-6)
     stats = hops.trace_stats_closest(r.as_wrapper, ot[:100000], dt[:100000])
     assert stats["rays"] == 100000 and stats["node_visits"] > 0
+
+
+def test_adaptive_launch_order_never_changes_results(device):
+    """the launch order learned from the previous launch (per handle and stream) is a pure
+    scheduling hint: repeated calls, other batch sizes, other streams and a rebuild in between
+    return what the non-adaptive launch returns"""
+    import triro.backend.ops as hops
+    v, f = W.bunny_standin()
+    r = make(v, f, device)
+    o, d = W.pinhole_grid(512, 512, distance=2.5 * 1.12)
+    ot, dt = T(o, device), T(d, device)
+    try:
+        hops.set_option("adaptive", 0)
+        ref = r.intersects_closest(ot, dt)
+        ref_cnt = r.intersects_count(ot, dt)
+        hops.set_option("adaptive", 1)
+        for _ in range(4):                                   # call 1 measures, calls 2.. use the order
+            got = r.intersects_closest(ot, dt)
+            for a, b in zip(got, ref):
+                assert torch.equal(a, b)
+        assert torch.equal(r.intersects_count(ot, dt), ref_cnt)
+        sub = r.intersects_first(ot[:200], dt[:200])         # different block count in between
+        assert torch.equal(sub, ref[2][:200])
+        s1, s2 = torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)
+        torch.cuda.synchronize()
+        outs = []
+        for _ in range(3):                                   # two streams interleaved on one handle
+            for st in (s1, s2):
+                with torch.cuda.stream(st):
+                    outs.append(r.intersects_first(ot, dt))
+        torch.cuda.synchronize()
+        for x in outs:
+            assert torch.equal(x, ref[2])
+        v2, f2 = W.icosphere(5)
+        r.update_raw(T(v2, device), T(f2, device))           # rebuild invalidates the hints
+        R = OracleIntersector(v2, f2, 1)
+        for _ in range(2):
+            assert np.array_equal(r.intersects_first(ot, dt).cpu().numpy(), R.intersects_first(o, d))
+    finally:
+        hops.set_option("adaptive", 1)

@@ -110,9 +110,11 @@ int tr_bvh_build(const float* d_vertices, int64_t nv, const int32_t* d_faces, in
     tr_bvh* bvh = new (std::nothrow) tr_bvh();
     if (!bvh) return tr_fail(TR_ERR_OUT_OF_MEMORY, "host allocation failed");
     bvh->device = device;
+    bvh->sched_mutex = new (std::nothrow) std::mutex();
     int s = tr_build_impl(bvh, d_vertices, nv, d_faces, nf, (hipStream_t)stream);
     if (s != TR_OK) {
         if (bvh->arena) (void)hipFree(bvh->arena);
+        delete bvh->sched_mutex;
         delete bvh;
         return s;
     }
@@ -135,8 +137,11 @@ int tr_bvh_destroy(tr_bvh* bvh) {
         DeviceGuard g;
         if (g.enter(bvh->device) == TR_OK && bvh->arena) {
             if (hipFree(bvh->arena) != hipSuccess) status = tr_fail(TR_ERR_HIP, "hipFree(arena)");
+            for (int k = 0; k < TR_SCHED_SLOTS; k++)
+                if (bvh->sched[k].buf && hipFree(bvh->sched[k].buf) != hipSuccess) status = tr_fail(TR_ERR_HIP, "hipFree(sched)");
         }
     }
+    delete bvh->sched_mutex;
     delete bvh;
     return status;
 }
@@ -179,6 +184,7 @@ int tr_set_option(const char* name, int64_t value) {
         return TR_OK;
     }
     if (!strcmp(name, "refill")) { g_options.refill = value != 0; return TR_OK; }
+    if (!strcmp(name, "adaptive")) { g_options.adaptive = value != 0; return TR_OK; }
     if (!strcmp(name, "compact")) { g_options.compact = value != 0; return TR_OK; }
     if (!strcmp(name, "xcd_chunk")) {
         if (value < 0 || value > 65536) return tr_fail(TR_ERR_INVALID_ARG, "xcd_chunk out of range");

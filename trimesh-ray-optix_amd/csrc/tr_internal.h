@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 #include <string>
 
 #include "../../include/triro_hip.h"
@@ -27,6 +28,17 @@ int tr_fail(int code, const std::string& msg);
         if (_s != TR_OK) return _s; \
     } while (0)
 
+// adaptive launch order: per (handle, stream) measured block costs and the order derived from
+// them.  buf = cost[TR_SCHED_MAX] | order[TR_SCHED_MAX]
+constexpr int TR_SCHED_MAX = 131072;  // blocks (x256 rays) up to which the order is learned
+constexpr int TR_SCHED_SLOTS = 8;
+struct tr_sched_slot {
+    hipStream_t stream = nullptr;
+    uint32_t* buf = nullptr;
+    int64_t nblocks = 0;    // block count the current order was measured for (0 = none)
+    bool used = false;
+};
+
 // the opaque handle ---------------------------------------------------------------------
 struct tr_bvh {
     int device = 0;
@@ -42,6 +54,10 @@ struct tr_bvh {
     tr_tri* tris = nullptr;
     float aabb_min[3] = {0, 0, 0};
     float aabb_max[3] = {0, 0, 0};
+    // adaptive launch order (speed only, see traverse.hip).  One slot per stream that has
+    // queried this handle, so launches on different streams never share hint buffers.
+    tr_sched_slot sched[TR_SCHED_SLOTS];
+    std::mutex* sched_mutex = nullptr;
 };
 
 // per-device runtime state (tr_init) ------------------------------------------------------
@@ -68,10 +84,11 @@ struct tr_options {
     int persistent = 0;
     int blocks_per_cu = 8;
     int refill = 1;
+    int adaptive = 1;     // start the blocks that were most expensive in the previous launch first
     int compact = 1;      // allow the 32-bit trail / 32-bit offset kernels when the BVH permits
     int refill_min = 16;
     int xcd_segments = 1;   // refill kernel: per-XCD work counters
     int xcd_chunk = 256;    // direct kernel: blocks per XCD-local chunk (0 = identity map)
-    int leaf_min = 0;     // 0 = fused (software-pipelined) schedule, >0 = while-while vote threshold
+    int leaf_min = 0;     // trips after which a wave raises its issue priority (0 = never)
 };
 tr_options& tr_opts();

@@ -118,11 +118,18 @@ __device__ __forceinline__ void wave_traverse(const tr_bvh_view& b, const tr_ray
     tr_state_t<W> fs;
     tr_state_init(fs);
     if (!go) fs.node = -1;
+    // Waves that are still traversing after `prio_after` trips hold the longest rays of the
+    // launch (mean ~35 node visits, tail > 300): give them issue priority so the critical
+    // path of a 1M-ray batch is not slowed down by the short rays sharing its SIMD.
+    const int prio_after = leaf_min;
+    int trips = 0;
     while (!tr_done(fs)) {
         tr_fused_step<Q, K, STATS, COMPACT, W>(b, r, fs, res, top, cnt, ring);
+        trips++;
+        if (prio_after > 0 && __builtin_amdgcn_readfirstlane(trips) == prio_after) __builtin_amdgcn_s_setprio(3);
         TR_CONVERGE();
     }
-    (void)leaf_min;
+    if (prio_after > 0) __builtin_amdgcn_s_setprio(0);
 }
 
 // All 64 lanes of a wave call this together (`in_range` = the lane owns ray i).
@@ -157,7 +164,10 @@ __device__ __forceinline__ void flush_stats(const tr_counters& c, unsigned long 
 template <int Q, bool STATS, bool COMPACT>
 __global__ __launch_bounds__(256) void k_query_direct(tr_bvh_view b, RayFetch rf, QueryOut out,
                                                       int leaf_min, int xcd_map,
+                                                      const uint32_t* __restrict__ order,
+                                                      uint32_t* __restrict__ cost,
                                                       unsigned long long* stats) {
+    const unsigned long long t_start = cost ? wall_clock64() : 0ull;
     __shared__ int32_t ring_lds[TR_RING * 256];
     const tr_ring ring = {ring_lds + threadIdx.x, 256};
     // XCD-aware block -> ray-tile map: workgroups are dealt round-robin over the 8 XCDs
@@ -166,7 +176,9 @@ __global__ __launch_bounds__(256) void k_query_direct(tr_bvh_view b, RayFetch rf
     // (and of the BVH) while expensive regions are still spread over all XCDs.  Placement only
     // affects speed.
     int64_t blk = blockIdx.x;
-    if (xcd_map > 0) {
+    if (order) {
+        blk = order[blockIdx.x];          // measured order: most expensive blocks first
+    } else if (xcd_map > 0) {
         const int64_t T = xcd_map, span = 8 * T;
         const int64_t nfull = (int64_t)gridDim.x / span * span;   // blocks covered by whole spans
         if (blk < nfull) {
@@ -177,7 +189,43 @@ __global__ __launch_bounds__(256) void k_query_direct(tr_bvh_view b, RayFetch rf
     int64_t i = blk * 256 + threadIdx.x;
     tr_counters cnt = {0, 0, 0};
     process_ray<Q, STATS, COMPACT>(b, rf, out, i, i < rf.n, &cnt, ring, leaf_min);
+    if (cost && (threadIdx.x & 63) == 0) {
+        const unsigned long long dt = wall_clock64() - t_start;     // 100 MHz ticks
+        atomicMax(&cost[blk], (uint32_t)(dt > 0x7ffffull ? 0x7ffffull : dt));
+    }
     flush_stats<STATS>(cnt, stats);
+}
+
+// Order the blocks of the last launch by measured cost, most expensive first: one workgroup,
+// counting sort on the cost quantised to 256 levels (max-reduce, LDS histogram, scan, scatter;
+// the order inside a level is arbitrary -- any permutation is a correct launch order).
+// Resets the cost array for the next measurement.
+__global__ __launch_bounds__(1024) void k_sched_sort(uint32_t* __restrict__ cost,
+                                                      uint32_t* __restrict__ order, int nblocks) {
+    __shared__ uint32_t bins[256];
+    __shared__ uint32_t smax;
+    const int tid = threadIdx.x;
+    if (tid < 256) bins[tid] = 0;
+    if (tid == 0) smax = 1;
+    __syncthreads();
+    uint32_t m = 0;
+    for (int i = tid; i < nblocks; i += 1024) { const uint32_t c = cost[i]; m = c > m ? c : m; }
+    atomicMax(&smax, m);
+    __syncthreads();
+    const uint32_t mx = smax;
+    for (int i = tid; i < nblocks; i += 1024)
+        atomicAdd(&bins[255u - (uint32_t)(((unsigned long long)cost[i] * 255ull) / mx)], 1u);   // 0 = most expensive
+    __syncthreads();
+    if (tid == 0) {   // exclusive scan of 256 bins
+        uint32_t run = 0;
+        for (int k = 0; k < 256; k++) { const uint32_t v = bins[k]; bins[k] = run; run += v; }
+    }
+    __syncthreads();
+    for (int i = tid; i < nblocks; i += 1024) {
+        const uint32_t q = 255u - (uint32_t)(((unsigned long long)cost[i] * 255ull) / mx);
+        order[atomicAdd(&bins[q], 1u)] = (uint32_t)i;
+        cost[i] = 0u;
+    }
 }
 
 template <int Q, bool STATS>
@@ -541,12 +589,41 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
         const bool compact = opt.compact && bvh->depth <= 32 &&
                              bvh->num_nodes * (int64_t)sizeof(tr_node) < ((int64_t)1 << 32) &&
                              bvh->num_tris * (int64_t)sizeof(tr_tri) < ((int64_t)1 << 32);
+        // Adaptive launch order: the blocks of the previous launch on the same (handle, stream)
+        // with the same block count are started most-expensive-first, so the longest rays of a
+        // batch -- its critical path -- do not start last.  Hints never affect results; each
+        // stream has its own buffers, so overlapping launches cannot see a half-written order.
+        const uint32_t* order = nullptr;
+        uint32_t* cost = nullptr;
+        tr_sched_slot* slot = nullptr;
+        tr_bvh* mb = const_cast<tr_bvh*>(bvh);
+        if (opt.adaptive && !STATS && mb->sched_mutex && nblocks_direct >= 64 && nblocks_direct <= TR_SCHED_MAX) {
+            std::lock_guard<std::mutex> lock(*mb->sched_mutex);
+            for (int k = 0; k < TR_SCHED_SLOTS && !slot; k++)
+                if (mb->sched[k].used && mb->sched[k].stream == stream) slot = &mb->sched[k];
+            for (int k = 0; k < TR_SCHED_SLOTS && !slot; k++)
+                if (!mb->sched[k].used) {
+                    uint32_t* buf = nullptr;
+                    if (hipMalloc((void**)&buf, sizeof(uint32_t) * 2 * TR_SCHED_MAX) != hipSuccess) { (void)hipGetLastError(); break; }
+                    if (hipMemsetAsync(buf, 0, sizeof(uint32_t) * 2 * TR_SCHED_MAX, stream) != hipSuccess) { (void)hipFree(buf); break; }
+                    mb->sched[k].used = true; mb->sched[k].stream = stream; mb->sched[k].buf = buf; mb->sched[k].nblocks = 0;
+                    slot = &mb->sched[k];
+                }
+            if (slot) {
+                cost = slot->buf;
+                if (slot->nblocks == nblocks_direct) order = slot->buf + TR_SCHED_MAX;
+                slot->nblocks = nblocks_direct;   // the sort enqueued below makes it valid for the next launch
+            }
+        }
         if (compact)
             hipLaunchKernelGGL((k_query_direct<Q, STATS, true>), dim3((unsigned)nblocks_direct), dim3(256), 0, stream,
-                               view, rf, out, opt.leaf_min, opt.xcd_chunk, d_stats);
+                               view, rf, out, opt.leaf_min, opt.xcd_chunk, order, cost, d_stats);
         else
             hipLaunchKernelGGL((k_query_direct<Q, STATS, false>), dim3((unsigned)nblocks_direct), dim3(256), 0, stream,
-                               view, rf, out, opt.leaf_min, opt.xcd_chunk, d_stats);
+                               view, rf, out, opt.leaf_min, opt.xcd_chunk, order, cost, d_stats);
+        if (cost)
+            hipLaunchKernelGGL(k_sched_sort, dim3(1), dim3(1024), 0, stream, cost, cost + TR_SCHED_MAX,
+                               (int)nblocks_direct);
     }
     TR_HIP_TRY(hipGetLastError());
     return TR_OK;
