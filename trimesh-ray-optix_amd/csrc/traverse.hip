@@ -118,18 +118,11 @@ __device__ __forceinline__ void wave_traverse(const tr_bvh_view& b, const tr_ray
     tr_state_t<W> fs;
     tr_state_init(fs);
     if (!go) fs.node = -1;
-    // Waves that are still traversing after `prio_after` trips hold the longest rays of the
-    // launch (mean ~35 node visits, tail > 300): give them issue priority so the critical
-    // path of a 1M-ray batch is not slowed down by the short rays sharing its SIMD.
-    const int prio_after = leaf_min;
-    int trips = 0;
     while (!tr_done(fs)) {
         tr_fused_step<Q, K, STATS, COMPACT, W>(b, r, fs, res, top, cnt, ring);
-        trips++;
-        if (prio_after > 0 && __builtin_amdgcn_readfirstlane(trips) == prio_after) __builtin_amdgcn_s_setprio(3);
         TR_CONVERGE();
     }
-    if (prio_after > 0) __builtin_amdgcn_s_setprio(0);
+    (void)leaf_min;
 }
 
 // All 64 lanes of a wave call this together (`in_range` = the lane owns ray i).
