@@ -18,13 +18,19 @@ out = {"tag": tag, "kernel_filter": kernel_key}
 
 
 def short_name(name):
-    head = name
-    if "<" in name and name.index("<") < name.index("("):
-        head = name[:name.index("(", name.index(">"))]
-    else:
-        head = name.split("(")[0] if not name.startswith("(") else name
-        head = name[:name.index("(", 5)] if "(" in name[5:] else name
-    return head.replace("void ", "").replace("(anonymous namespace)::", "")[:90]
+    n = name.replace("(anonymous namespace)::", "")
+    if n.startswith("void "):
+        n = n[5:]
+    depth, out = 0, []
+    for ch in n:
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            break
+        out.append(ch)
+    return "".join(out)[:90]
 
 
 stats = glob.glob(os.path.join(root, "trace", "*", "*_kernel_stats.csv"))
