@@ -94,7 +94,17 @@ int tr_bvh_build(const float *d_vertices, int64_t nv, const int32_t *d_faces, in
 /*    rebuild in place for RayMeshIntersector.update_raw (ray_optix.py:55-69)             */
 int tr_bvh_update(tr_bvh *bvh, const float *d_vertices, int64_t nv, const int32_t *d_faces,
                   int64_t nf, void *stream);
+/*    refit: same faces (topology), new vertex positions -- keeps the hierarchy and recomputes
+ *    every box (cheaper than a rebuild for deforming meshes; the reference always rebuilds,
+ *    ray_optix.py:55-69).  d_faces must be the array the BVH was built from.               */
+int tr_bvh_refit(tr_bvh *bvh, const float *d_vertices, int64_t nv, const int32_t *d_faces,
+                 int64_t nf, void *stream);
 int tr_bvh_destroy(tr_bvh *bvh);
+/*    (de)serialisation to a HOST buffer: header + the traversal arena (the reference rebuilds
+ *    its GAS in every process).  Both calls synchronise `stream`.                          */
+int64_t tr_bvh_serialized_size(const tr_bvh *bvh);
+int tr_bvh_serialize(const tr_bvh *bvh, void *h_buffer, int64_t size, void *stream);
+int tr_bvh_deserialize(const void *h_buffer, int64_t size, void *stream, tr_bvh **out);
 int tr_bvh_get_info(const tr_bvh *bvh, tr_bvh_info *info);
 /*    test hook: copy the traversal arrays to HOST buffers (any may be NULL).
  *    nodes: num_nodes*16 words (64 B), links: num_nodes*2 int32, tris: num_tris*12 words. */

@@ -384,3 +384,43 @@ def test_adaptive_launch_order_never_changes_results(device):
             assert np.array_equal(r.intersects_first(ot, dt).cpu().numpy(), R.intersects_first(o, d))
     finally:
         hops.set_option("adaptive", 1)
+
+
+def test_refit_and_serialization(device, tmp_path):
+    """refit for unchanged topology, BVH (de)serialisation"""
+    from triro.ray.ray_optix import RayMeshIntersector
+    v, f = W.icosphere(5)
+    r = make(v, f, device)
+    o, d = W.pinhole_grid(200, 200)
+    ot, dt = T(o, device), T(d, device)
+    # deform: anisotropic scale + smooth displacement, same faces
+    v2 = (W.displaced(v, seed=3, amplitude=0.2) * np.array([1.0, 0.7, 1.3], np.float32)).astype(np.float32)
+    r.refit(T(v2, device))
+    R2 = OracleIntersector(v2, f, 1)
+    assert_closest_equal(r.intersects_closest(ot, dt), R2.closest_raw(o, d))
+    assert np.array_equal(r.intersects_count(ot, dt).cpu().numpy(), R2.intersects_count(o, d))
+    info = r.bvh_info()
+    assert np.all(np.float32(info["aabb_min"]) <= v2.min(0)) and np.all(np.float32(info["aabb_max"]) >= v2.max(0))
+    rb = make(v2, f, device)                      # a fresh build of the deformed mesh agrees
+    for a, b in zip(r.intersects_closest(ot, dt), rb.intersects_closest(ot, dt)):
+        assert torch.equal(a, b)
+    with pytest.raises(ValueError):
+        r.refit(T(v2[:-1], device))
+    # save / load round trip: identical arena, identical answers, no rebuild
+    path = str(tmp_path / "mesh_bvh.npz")
+    r.save(path)
+    r3 = RayMeshIntersector.load(path, device=device)
+    n1, l1, t1 = r.as_wrapper.download()
+    n3, l3, t3 = r3.as_wrapper.download()
+    assert np.array_equal(n1, n3) and np.array_equal(l1, l3) and np.array_equal(t1, t3)
+    assert r3.bvh_info()["depth"] == info["depth"]
+    for a, b in zip(r3.intersects_closest(ot, dt), r.intersects_closest(ot, dt)):
+        assert torch.equal(a, b)
+    lo, ra, tr_ = r3.intersects_location(ot, dt)
+    lo2, ra2, tr2 = r.intersects_location(ot, dt)
+    assert torch.equal(ra, ra2) and torch.equal(tr_, tr2)
+    blob = r.as_wrapper.serialize().copy()
+    blob[0] ^= 0xFF
+    from triro.ray.ray_optix import OptixAccelStructureWrapper
+    with pytest.raises(ValueError):
+        OptixAccelStructureWrapper().deserialize(blob, device)

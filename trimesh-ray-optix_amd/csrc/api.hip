@@ -130,6 +130,97 @@ int tr_bvh_update(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_
     return tr_build_impl(bvh, d_vertices, nv, d_faces, nf, (hipStream_t)stream);
 }
 
+int tr_bvh_refit(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_t* d_faces,
+                 int64_t nf, void* stream) {
+    if (!bvh) return tr_fail(TR_ERR_INVALID_ARG, "bvh == NULL");
+    DeviceGuard g;
+    if (g.enter(bvh->device) != TR_OK) return tr_fail(TR_ERR_NO_DEVICE, "hipSetDevice failed");
+    return tr_refit_impl(bvh, d_vertices, nv, d_faces, nf, (hipStream_t)stream);
+}
+
+// ---- (de)serialisation: header + the arena, byte for byte -------------------------------------
+namespace {
+struct tr_blob_header {
+    char magic[8];          // "TRBVH\0\0\1"
+    int64_t num_tris, num_nodes, arena_bytes;
+    int32_t depth, key_mode;
+    float aabb_min[3], aabb_max[3];
+    uint32_t sizeof_node, sizeof_tri, sizeof_link, pad;
+};
+const char TR_MAGIC[8] = {'T', 'R', 'B', 'V', 'H', 0, 0, 1};
+}  // namespace
+
+int64_t tr_bvh_serialized_size(const tr_bvh* bvh) {
+    if (!bvh) return -1;
+    return (int64_t)sizeof(tr_blob_header) + (bvh->num_tris > 0 ? bvh->arena_bytes : 0);
+}
+
+int tr_bvh_serialize(const tr_bvh* bvh, void* h_buffer, int64_t size, void* stream) {
+    if (!bvh || !h_buffer) return tr_fail(TR_ERR_INVALID_ARG, "null argument");
+    if (size < tr_bvh_serialized_size(bvh)) return tr_fail(TR_ERR_INVALID_ARG, "buffer too small");
+    DeviceGuard g;
+    if (g.enter(bvh->device) != TR_OK) return tr_fail(TR_ERR_NO_DEVICE, "hipSetDevice failed");
+    tr_blob_header h;
+    memset(&h, 0, sizeof h);
+    memcpy(h.magic, TR_MAGIC, 8);
+    h.num_tris = bvh->num_tris; h.num_nodes = bvh->num_nodes; h.arena_bytes = bvh->num_tris > 0 ? bvh->arena_bytes : 0;
+    h.depth = bvh->depth; h.key_mode = bvh->key_mode;
+    for (int k = 0; k < 3; k++) { h.aabb_min[k] = bvh->aabb_min[k]; h.aabb_max[k] = bvh->aabb_max[k]; }
+    h.sizeof_node = sizeof(tr_node); h.sizeof_tri = sizeof(tr_tri); h.sizeof_link = sizeof(tr_link);
+    memcpy(h_buffer, &h, sizeof h);
+    if (h.arena_bytes > 0) {
+        TR_HIP_TRY(hipMemcpyAsync((char*)h_buffer + sizeof h, bvh->arena, (size_t)h.arena_bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+        TR_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    }
+    return TR_OK;
+}
+
+int tr_bvh_deserialize(const void* h_buffer, int64_t size, void* stream, tr_bvh** out) {
+    if (!h_buffer || !out) return tr_fail(TR_ERR_INVALID_ARG, "null argument");
+    *out = nullptr;
+    if (size < (int64_t)sizeof(tr_blob_header)) return tr_fail(TR_ERR_INVALID_ARG, "blob too small");
+    tr_blob_header h;
+    memcpy(&h, h_buffer, sizeof h);
+    if (memcmp(h.magic, TR_MAGIC, 8) != 0) return tr_fail(TR_ERR_INVALID_ARG, "not a triro BVH blob (bad magic/version)");
+    if (h.sizeof_node != sizeof(tr_node) || h.sizeof_tri != sizeof(tr_tri) || h.sizeof_link != sizeof(tr_link))
+        return tr_fail(TR_ERR_INVALID_ARG, "blob was written with a different record layout");
+    if (h.num_tris < 0 || h.num_nodes != (h.num_tris >= 2 ? h.num_tris - 1 : 0) || h.depth < 0 || h.depth > 64 ||
+        size < (int64_t)sizeof h + h.arena_bytes)
+        return tr_fail(TR_ERR_INVALID_ARG, "inconsistent blob header");
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess)
+        return tr_fail(TR_ERR_NO_DEVICE, "no HIP device available (libtriro_hip has no CPU fallback)");
+    tr_device_state* st;
+    TR_TRY(tr_get_device_state(device, &st));
+    tr_bvh* bvh = new (std::nothrow) tr_bvh();
+    if (!bvh) return tr_fail(TR_ERR_OUT_OF_MEMORY, "host allocation failed");
+    bvh->device = device;
+    bvh->sched_mutex = new (std::nothrow) std::mutex();
+    // an empty build gives the handle a correctly carved arena of the right capacity
+    int s = tr_build_impl(bvh, nullptr, 0, nullptr, 0, (hipStream_t)stream);
+    if (s == TR_OK && h.num_tris > 0) {
+        s = tr_arena_alloc(bvh, h.num_tris);
+        if (s == TR_OK && bvh->arena_bytes != h.arena_bytes) s = tr_fail(TR_ERR_INVALID_ARG, "arena size mismatch");
+        if (s == TR_OK) {
+            if (hipMemcpyAsync(bvh->arena, (const char*)h_buffer + sizeof h, (size_t)h.arena_bytes, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess ||
+                hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
+                s = tr_fail(TR_ERR_HIP, "upload of the BVH arena failed");
+        }
+        if (s == TR_OK) {
+            bvh->num_tris = h.num_tris; bvh->num_nodes = h.num_nodes; bvh->depth = h.depth; bvh->key_mode = h.key_mode;
+            for (int k = 0; k < 3; k++) { bvh->aabb_min[k] = h.aabb_min[k]; bvh->aabb_max[k] = h.aabb_max[k]; }
+        }
+    }
+    if (s != TR_OK) {
+        if (bvh->arena) (void)hipFree(bvh->arena);
+        delete bvh->sched_mutex;
+        delete bvh;
+        return s;
+    }
+    *out = bvh;
+    return TR_OK;
+}
+
 int tr_bvh_destroy(tr_bvh* bvh) {
     if (!bvh) return TR_OK;
     int status = TR_OK;

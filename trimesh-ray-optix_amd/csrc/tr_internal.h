@@ -79,6 +79,10 @@ int tr_scratch_reserve(tr_device_state* st, size_t bytes, void** out);
 int tr_build_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_t* d_faces,
                   int64_t nf, hipStream_t stream);
 
+int tr_arena_alloc(tr_bvh* bvh, int64_t nf);
+int tr_refit_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_t* d_faces,
+                  int64_t nf, hipStream_t stream);
+
 // options ---------------------------------------------------------------------------------
 struct tr_options {
     int persistent = 0;

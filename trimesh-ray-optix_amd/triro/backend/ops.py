@@ -68,7 +68,11 @@ ABI = {
     "tr_last_error": (C.c_char_p, []),
     "tr_bvh_build": (_int, [_vp, _i64, _vp, _i64, _vp, C.POINTER(_vp)]),
     "tr_bvh_update": (_int, [_vp, _vp, _i64, _vp, _i64, _vp]),
+    "tr_bvh_refit": (_int, [_vp, _vp, _i64, _vp, _i64, _vp]),
     "tr_bvh_destroy": (_int, [_vp]),
+    "tr_bvh_serialized_size": (_i64, [_vp]),
+    "tr_bvh_serialize": (_int, [_vp, _vp, _i64, _vp]),
+    "tr_bvh_deserialize": (_int, [_vp, _i64, _vp, C.POINTER(_vp)]),
     "tr_bvh_get_info": (_int, [_vp, C.POINTER(TrBvhInfo)]),
     "tr_bvh_download": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "tr_intersects_any": (_int, [_vp, C.POINTER(TrRays), _vp, _vp]),

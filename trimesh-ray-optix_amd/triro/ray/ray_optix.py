@@ -154,6 +154,39 @@ class RayMeshIntersector:
     def bvh_info(self) -> dict:
         return self.as_wrapper.info()
 
+    def refit(self, vertices):
+        """New vertex positions, SAME faces: keep the hierarchy and recompute every box
+        (tr_bvh_refit).  Cheaper than update_raw (which rebuilds, ray_optix.py:55-69) for
+        deforming meshes; results are exact for the new geometry, only the tree quality ages."""
+        v = _to_device_tensor(vertices, torch.float32, self.mesh_vertices.device)
+        if v.shape != self.mesh_vertices.shape:
+            raise ValueError("refit needs the same number of vertices as the current mesh")
+        self.mesh_vertices = v
+        self.mesh_aabb = (torch.min(v, dim=0)[0], torch.max(v, dim=0)[0])
+        self.as_wrapper.refit(self.mesh_vertices, self.mesh_faces)
+
+    def save(self, path: str):
+        """Serialise mesh + acceleration structure (tr_bvh_serialize) to an .npz file."""
+        np.savez(path, vertices=self.mesh_vertices.cpu().numpy(), faces=self.mesh_faces.cpu().numpy(),
+                 bvh=self.as_wrapper.serialize())
+
+    @classmethod
+    def load(cls, path: str, device=None):
+        """Counterpart of save(): no rebuild, the arena is uploaded as stored."""
+        z = np.load(path if str(path).endswith(".npz") else str(path) + ".npz")
+        self = cls.__new__(cls)
+        dev = torch.device(device) if device is not None else _default_device()
+        self.mesh_vertices = torch.from_numpy(z["vertices"]).to(dev)
+        self.mesh_faces = torch.from_numpy(z["faces"]).to(dev)
+        if self.mesh_vertices.shape[0] > 0:
+            self.mesh_aabb = (torch.min(self.mesh_vertices, dim=0)[0], torch.max(self.mesh_vertices, dim=0)[0])
+        else:
+            zz = torch.zeros(3, device=dev)
+            self.mesh_aabb = (zz, zz.clone())
+        self.as_wrapper = OptixAccelStructureWrapper()
+        self.as_wrapper.deserialize(np.ascontiguousarray(z["bvh"]), dev)
+        return self
+
 
 class OptixAccelStructureWrapper:
     """ray_optix.py:282-294: RAII owner of the native acceleration structure.  The name is
@@ -191,6 +224,30 @@ class OptixAccelStructureWrapper:
                 hops._check(lib.tr_bvh_build(vertices.data_ptr(), vertices.shape[0], faces.data_ptr(),
                                              faces.shape[0], stream, C.byref(handle)))
                 self._inner = handle.value
+
+    def refit(self, vertices: torch.Tensor, faces: torch.Tensor):
+        if not self._inner:
+            raise RuntimeError("acceleration structure has not been built")
+        with torch.cuda.device(vertices.device):
+            stream = torch.cuda.current_stream(vertices.device).cuda_stream
+            hops._check(hops.get_module().tr_bvh_refit(self._inner, vertices.data_ptr(), vertices.shape[0],
+                                                       faces.data_ptr(), faces.shape[0], stream))
+
+    def serialize(self) -> np.ndarray:
+        lib = hops.get_module()
+        size = lib.tr_bvh_serialized_size(self._inner)
+        buf = np.zeros(size, np.uint8)
+        with torch.cuda.device(self.info()["device"]):
+            hops._check(lib.tr_bvh_serialize(self._inner, buf.ctypes.data, size, torch.cuda.current_stream().cuda_stream))
+        return buf
+
+    def deserialize(self, blob: np.ndarray, device):
+        self.free()
+        handle = C.c_void_p()
+        with torch.cuda.device(device):
+            hops._check(hops.get_module().tr_bvh_deserialize(blob.ctypes.data, blob.nbytes,
+                                                             torch.cuda.current_stream(device).cuda_stream, C.byref(handle)))
+        self._inner = handle.value
 
     def info(self) -> dict:
         inf = hops.TrBvhInfo()
