@@ -142,6 +142,7 @@ static tr_bvh_view view_of(const tr_node* nodes, const tr_link* links, const tr_
 }
 
 static int g_use_ring = 1;
+static int g_fused = 0;   // 0 generic node/leaf schedule, 1 fused trip (64-bit state), 2 fused compact (32-bit)
 
 template <int Q>
 static void run_query(const tr_bvh_view& v, const float* o, const float* d, int64_t n, uint8_t* hit,
@@ -156,7 +157,18 @@ static void run_query(const tr_bvh_view& v, const float* o, const float* d, int6
         cnt.nodes = cnt.tris = cnt.climbs = 0;
         int32_t ring_mem[TR_RING];
         tr_ring ring = {g_use_ring ? ring_mem : nullptr, 1};
-        if (v.num_tris >= 2) tr_traverse<Q, 1, true>(v, r, valid, res, top, &cnt, ring);
+        if (v.num_tris >= 2 && (g_fused & 3)) {
+            tr_result_init(res);
+            if (valid) {
+                if ((g_fused & 3) == 1) {
+                    tr_state_t<uint64_t> fs; tr_state_init(fs);
+                    while (!tr_done(fs)) tr_fused_step<Q, 1, true, false, uint64_t>(v, r, fs, res, top, &cnt, ring);
+                } else {
+                    tr_state_t<uint32_t> fs; tr_state_init(fs);
+                    while (!tr_done(fs)) tr_fused_step<Q, 1, true, true, uint32_t>(v, r, fs, res, top, &cnt, ring);
+                }
+            }
+        } else if (v.num_tris >= 2) tr_traverse<Q, 1, true>(v, r, valid, res, top, &cnt, ring);
         else {
             res.best_face = -1; res.count = 0; res.best_t = TR_TMAX;
             if (valid && v.num_tris == 1) {
@@ -187,6 +199,7 @@ static void run_query(const tr_bvh_view& v, const float* o, const float* d, int6
 
 extern "C" {
 void sim_use_ring(int on) { g_use_ring = on; }
+void sim_use_fused(int mode) { g_fused = mode; }
 void sim_query(int q, const void* nodes, const void* links, const void* tris, int64_t nf, const float* o,
                const float* d, int64_t n, uint8_t* hit, uint8_t* front, int32_t* tri, float* loc, float* uv,
                int32_t* count, uint64_t* stats) {

@@ -33,6 +33,7 @@ def lib():
         L.sim_query.argtypes = [C.c_int] + [C.c_void_p] * 3 + [C.c_int64, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p] * 7
         L.sim_location.argtypes = [C.c_void_p] * 3 + [C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 3
         L.sim_use_ring.argtypes = [C.c_int]
+        L.sim_use_fused.argtypes = [C.c_int]
         L.sim_steps.argtypes = [C.c_void_p] * 3 + [C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         _LIB = L
     return _LIB
@@ -96,3 +97,8 @@ class SimBVH:
 
 def use_ring(on: bool):
     lib().sim_use_ring(1 if on else 0)
+
+
+def use_fused(mode: int):
+    """0 = generic node/leaf schedule, 1 = fused trip, 2 = fused trip with 32-bit state/offsets"""
+    lib().sim_use_fused(mode)

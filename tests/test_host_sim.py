@@ -100,6 +100,23 @@ def test_height_fallback_to_bounded_keys():
     assert R.intersects_count(o[:1], d[:1])[0] >= 4000
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+def test_fused_trip_variants(mode):
+    """the kernels' fused trip (64-bit and compact 32-bit state) == oracle"""
+    import sim
+    sim.use_fused(mode)
+    try:
+        v, f = W.icosphere(5)
+        compare_all(v, f, *W.pinhole_grid(128, 128))
+        v, f = W.random_soup(2500, seed=8)
+        o, d = W.hash_rays(12000, 4, v.min(0) * 1.5, v.max(0) * 1.5)
+        compare_all(v, f, o, d)
+        if mode == 1:                            # deep trees need the 64-bit trail
+            compare_all(v, f, o, d, morton_shift=63)
+    finally:
+        sim.use_fused(0)
+
+
 def test_nested_shells_multihit():
     v, f = W.nested_shells(3, radii=(1.0, 0.8, 0.6, 0.4, 0.3))
     o, d = W.pinhole_grid(96, 96)
