@@ -1,0 +1,107 @@
+"""GPU vs brute-force oracle on adversarial geometry: duplicates, zero-area and needle
+triangles, huge / tiny / far-from-origin coordinates, rays starting on and inside the mesh,
+axis-aligned rays on axis-aligned geometry.  Everything bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+import workloads as W
+from oracle.oracle import OracleIntersector
+
+pytestmark = pytest.mark.gpu
+
+
+def T(x, dev):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def check(v, f, o, d, dev, mode=0):
+    from triro.ray.ray_optix import RayMeshIntersector
+    r = RayMeshIntersector(vertices=T(v, dev), faces=T(f, dev))
+    R = OracleIntersector(v, f, mode)
+    ot, dt = T(o, dev), T(d, dev)
+    hit, front, tri, loc, uv = [x.cpu().numpy() for x in r.intersects_closest(ot, dt)]
+    eh, ef, et, el, eu, _ = R.closest_raw(o, d)
+    assert np.array_equal(hit, eh) and np.array_equal(front, ef) and np.array_equal(tri, et)
+    assert np.array_equal(loc, el) and np.array_equal(uv, eu)
+    cnt = R.intersects_count(o, d)
+    assert np.array_equal(r.intersects_count(ot, dt).cpu().numpy(), cnt)
+    assert np.array_equal(r.intersects_any(ot, dt).cpu().numpy(), cnt > 0)
+    lo, ra, tr_ = [x.cpu().numpy() for x in r.intersects_location(ot, dt)]
+    el2, er2, et2 = R.intersects_location(o, d)
+    assert np.array_equal(ra, er2) and np.array_equal(tr_, et2) and np.array_equal(lo, el2)
+    return hit
+
+
+def rays_for(v, n, seed):
+    lo, hi = v.min(0), v.max(0)
+    ext = np.maximum(hi - lo, 1e-3 * np.maximum(np.abs(hi), 1e-30))
+    return W.hash_rays(n, seed, lo - 0.5 * ext, hi + 0.5 * ext)
+
+
+def test_duplicates_and_degenerates(device):
+    rng = np.random.default_rng(0)
+    v, f = W.random_soup(300, seed=1)
+    f = np.concatenate([f, f[:100], f[:100]])                    # every triangle of the first 100 three times
+    v = np.concatenate([v, rng.random((30, 3)).astype(np.float32)])
+    zero_area = np.array([[900, 900, 901], [902, 902, 902], [903, 904, 903]], np.int32)   # repeated vertices
+    f = np.concatenate([f, zero_area])
+    o, d = rays_for(v, 20000, 3)
+    hit = check(v, f, o, d, device)
+    assert hit.any()
+    # collinear (zero-area) triangles with distinct vertices + needles
+    v2 = np.array([[0, 0, 0], [1, 1, 1], [2, 2, 2], [0, 0, 0], [1e-7, 0, 0], [0, 5, 0], [0, 0, 1], [3, 0, 1], [0, 1e-6, 1]], np.float32)
+    f2 = np.array([[0, 1, 2], [3, 4, 5], [6, 7, 8]], np.int32)
+    o2, d2 = rays_for(v2, 20000, 4)
+    check(v2, f2, o2, d2, device)
+
+
+@pytest.mark.parametrize("scale,offset", [(1e6, 0.0), (1e-6, 0.0), (1.0, 1e5), (1e3, -7e4)])
+def test_coordinate_ranges(device, scale, offset):
+    v, f = W.icosphere(3)
+    v = (v * np.float32(scale) + np.float32(offset)).astype(np.float32)
+    o, d = rays_for(v, 20000, 5)
+    check(v, f, o, d, device)
+    # camera far away from a mesh that sits far from the origin
+    c = v.mean(0)
+    oo = np.tile((c + np.float32(50 * scale) * np.array([0.3, 0.2, 1.0], np.float32)).astype(np.float32), (4096, 1))
+    tgt, _ = rays_for(v, 4096, 6)
+    check(v, f, oo, (tgt - oo).astype(np.float32), device)
+
+
+def test_rays_starting_on_and_inside(device):
+    v, f = W.icosphere(3)
+    rng = np.random.default_rng(2)
+    cen = v[f].mean(1)                                          # points ON the surface (triangle centroids)
+    d_out = (cen / np.linalg.norm(cen, axis=1, keepdims=True)).astype(np.float32)
+    o = np.concatenate([cen, cen, np.zeros((500, 3), np.float32), v[:300]]).astype(np.float32)
+    d = np.concatenate([d_out, -d_out, rng.normal(size=(500, 3)).astype(np.float32), -v[:300]]).astype(np.float32)
+    check(v, f, o, d, device)
+
+
+def test_axis_aligned_everything(device):
+    # a 6x6x6 block of axis-aligned quads; rays along +-x/y/z exactly on the grid lines,
+    # through vertices and edges, with zero direction components
+    g = np.arange(0, 7, dtype=np.float32)
+    vs, fs = [], []
+    for z in g[:4]:
+        base = len(vs) * 1
+        gx, gy = np.meshgrid(g, g, indexing="ij")
+        pts = np.stack([gx.ravel(), gy.ravel(), np.full(gx.size, z)], 1)
+        off = sum(len(p) for p in vs)
+        vs.append(pts)
+        idx = np.arange(49).reshape(7, 7)
+        a, b, c, dd = idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel(), idx[:-1, 1:].ravel()
+        fs.append(np.concatenate([np.stack([a, b, c], 1), np.stack([a, c, dd], 1)]) + off)
+    v = np.concatenate(vs).astype(np.float32)
+    f = np.concatenate(fs).astype(np.int32)
+    h = np.arange(-1, 8, 0.5, dtype=np.float32)
+    hx, hy = np.meshgrid(h, h, indexing="ij")
+    o = np.stack([hx.ravel(), hy.ravel(), np.full(hx.size, 9.0, np.float32)], 1)
+    d = np.tile(np.array([0, 0, -1], np.float32), (len(o), 1))
+    o2 = np.stack([np.full(hx.size, -3.0, np.float32), hx.ravel(), hy.ravel() * 0.5], 1)   # in-plane rays (z = k/2)
+    d2 = np.tile(np.array([1, 0, 0], np.float32), (len(o2), 1))
+    hit = check(v, f, np.concatenate([o, o2]), np.concatenate([d, d2]), device)
+    n1 = len(o)
+    inside = (o[:, 0] >= 0) & (o[:, 0] <= 6) & (o[:, 1] >= 0) & (o[:, 1] <= 6)
+    assert np.array_equal(hit[:n1], inside)                      # boundary lines included on all four sides
