@@ -93,6 +93,6 @@ struct tr_options {
     int refill_min = 16;
     int xcd_segments = 1;   // refill kernel: per-XCD work counters
     int xcd_chunk = 256;    // direct kernel: blocks per XCD-local chunk (0 = identity map)
-    int leaf_min = 0;     // trips after which a wave raises its issue priority (0 = never)
+    int leaf_min = 0;     // refill kernel only: lanes with a queued leaf that fire its leaf phase (0 = any)
 };
 tr_options& tr_opts();

@@ -110,7 +110,7 @@ template <> struct tr_word<true> { typedef uint32_t T; };
 template <int Q, int K, bool STATS, bool COMPACT = false>
 __device__ __forceinline__ void wave_traverse(const tr_bvh_view& b, const tr_ray& r, bool go,
                                               tr_result& res, tr_topk<K>& top, tr_counters* cnt,
-                                              const tr_ring ring, int leaf_min) {
+                                              const tr_ring ring) {
     tr_result_init(res);
     if (Q == TR_Q_LOCATION) top.init();
     // fused, software-pipelined schedule: every lane advances on every trip
@@ -122,21 +122,20 @@ __device__ __forceinline__ void wave_traverse(const tr_bvh_view& b, const tr_ray
         tr_fused_step<Q, K, STATS, COMPACT, W>(b, r, fs, res, top, cnt, ring);
         TR_CONVERGE();
     }
-    (void)leaf_min;
 }
 
 // All 64 lanes of a wave call this together (`in_range` = the lane owns ray i).
 template <int Q, bool STATS, bool COMPACT = false>
 __device__ __forceinline__ void process_ray(const tr_bvh_view& b, const RayFetch& rf,
                                             const QueryOut& out, int64_t i, bool in_range,
-                                            tr_counters* cnt, const tr_ring ring, int leaf_min) {
+                                            tr_counters* cnt, const tr_ring ring) {
     float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
     if (in_range) fetch_ray(rf, i, o, d);
     tr_ray r;
     const bool valid = tr_ray_setup(r, o[0], o[1], o[2], d[0], d[1], d[2]) && in_range;
     tr_result res;
     tr_topk<1> top;
-    if (b.num_tris >= 2) wave_traverse<Q, 1, STATS, COMPACT>(b, r, valid, res, top, cnt, ring, leaf_min);
+    if (b.num_tris >= 2) wave_traverse<Q, 1, STATS, COMPACT>(b, r, valid, res, top, cnt, ring);
     else brute_one<Q>(b, r, valid, res);
     if (in_range) write_result<Q>(b, out, i, res);
 }
@@ -156,7 +155,7 @@ __device__ __forceinline__ void flush_stats(const tr_counters& c, unsigned long 
 
 template <int Q, bool STATS, bool COMPACT>
 __global__ __launch_bounds__(256) void k_query_direct(tr_bvh_view b, RayFetch rf, QueryOut out,
-                                                      int leaf_min, int xcd_map,
+                                                      int xcd_map,
                                                       const uint32_t* __restrict__ order,
                                                       uint32_t* __restrict__ cost,
                                                       unsigned long long* stats) {
@@ -181,7 +180,7 @@ __global__ __launch_bounds__(256) void k_query_direct(tr_bvh_view b, RayFetch rf
     }
     int64_t i = blk * 256 + threadIdx.x;
     tr_counters cnt = {0, 0, 0};
-    process_ray<Q, STATS, COMPACT>(b, rf, out, i, i < rf.n, &cnt, ring, leaf_min);
+    process_ray<Q, STATS, COMPACT>(b, rf, out, i, i < rf.n, &cnt, ring);
     if (cost && (threadIdx.x & 63) == 0) {
         const unsigned long long dt = wall_clock64() - t_start;     // 100 MHz ticks
         atomicMax(&cost[blk], (uint32_t)(dt > 0x7ffffull ? 0x7ffffull : dt));
@@ -223,7 +222,7 @@ __global__ __launch_bounds__(1024) void k_sched_sort(uint32_t* __restrict__ cost
 
 template <int Q, bool STATS>
 __global__ __launch_bounds__(256) void k_query_persistent(tr_bvh_view b, RayFetch rf, QueryOut out,
-                                                          unsigned long long* counter, int leaf_min,
+                                                          unsigned long long* counter,
                                                           unsigned long long* stats) {
     __shared__ int32_t ring_lds[TR_RING * 256];
     const tr_ring ring = {ring_lds + threadIdx.x, 256};
@@ -235,7 +234,7 @@ __global__ __launch_bounds__(256) void k_query_persistent(tr_bvh_view b, RayFetc
         base = __shfl(base, 0);
         if ((int64_t)base >= rf.n) break;
         int64_t i = (int64_t)base + lane;
-        process_ray<Q, STATS>(b, rf, out, i, i < rf.n, &cnt, ring, leaf_min);
+        process_ray<Q, STATS>(b, rf, out, i, i < rf.n, &cnt, ring);
     }
     flush_stats<STATS>(cnt, stats);
 }
@@ -370,7 +369,7 @@ __global__ __launch_bounds__(256) void k_location(tr_bvh_view b, RayFetch rf, in
     tr_topk<K> top;
     tr_counters* nc = nullptr;
     if (b.num_tris >= 2) {
-        wave_traverse<TR_Q_LOCATION, K, false>(b, r, valid, res, top, nc, ring, 0);
+        wave_traverse<TR_Q_LOCATION, K, false>(b, r, valid, res, top, nc, ring);
     } else {
         top.init();
         brute_one<TR_Q_LOCATION>(b, r, valid, res);
@@ -577,7 +576,7 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
                                view, rf, out, counter, opt.refill_min, opt.xcd_segments ? 8 : 1, opt.leaf_min, d_stats);
         else
             hipLaunchKernelGGL((k_query_persistent<Q, STATS>), dim3((unsigned)pgrid), dim3(256), 0, stream,
-                               view, rf, out, counter, opt.leaf_min, d_stats);
+                               view, rf, out, counter, d_stats);
     } else {
         const bool compact = opt.compact && bvh->depth <= 32 &&
                              bvh->num_nodes * (int64_t)sizeof(tr_node) < ((int64_t)1 << 32) &&
@@ -610,10 +609,10 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
         }
         if (compact)
             hipLaunchKernelGGL((k_query_direct<Q, STATS, true>), dim3((unsigned)nblocks_direct), dim3(256), 0, stream,
-                               view, rf, out, opt.leaf_min, opt.xcd_chunk, order, cost, d_stats);
+                               view, rf, out, opt.xcd_chunk, order, cost, d_stats);
         else
             hipLaunchKernelGGL((k_query_direct<Q, STATS, false>), dim3((unsigned)nblocks_direct), dim3(256), 0, stream,
-                               view, rf, out, opt.leaf_min, opt.xcd_chunk, order, cost, d_stats);
+                               view, rf, out, opt.xcd_chunk, order, cost, d_stats);
         if (cost)
             hipLaunchKernelGGL(k_sched_sort, dim3(1), dim3(1024), 0, stream, cost, cost + TR_SCHED_MAX,
                                (int)nblocks_direct);
