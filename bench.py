@@ -53,6 +53,25 @@ def cpu_baseline(v, f, o, d, budget_s=20.0):
     """The oracle's BVH mode ("port": our CPU restatement, NOT Embree -- trimesh/pyembree are
     not installed in this image) on the host cores, same mesh, same rays, bounded time."""
     from oracle.oracle import OracleIntersector, num_threads
+    try:   # BASELINE.md 4(1): trimesh + Embree if the GPU box happens to have them
+        import trimesh  # noqa: F401
+        import embreex  # noqa: F401
+        have_embree = True
+    except Exception:
+        have_embree = False
+    if have_embree:
+        try:
+            import trimesh
+            m = trimesh.Trimesh(vertices=v, faces=f, process=False)
+            oo = np.ascontiguousarray(o, np.float32).reshape(-1, 3)
+            dd = np.ascontiguousarray(d, np.float32).reshape(-1, 3)
+            t0 = time.perf_counter()
+            m.ray.intersects_location(oo, dd, multiple_hits=False)   # test/performance_test.py:75
+            el = time.perf_counter() - t0
+            return {"value": round(len(oo) / el / 1e6, 3), "unit": "Mrays/s", "cores": 1, "kind": "reference",
+                    "sample": f"trimesh+embree mesh.ray.intersects_location(multiple_hits=False), {len(oo)} rays, 1 pass"}
+        except Exception:
+            pass
     R = OracleIntersector(v, f, mode=1)
     o = np.ascontiguousarray(o, np.float32).reshape(-1, 3)
     d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)

@@ -139,6 +139,17 @@ int tr_intersects_location_fill(const tr_bvh *bvh, const tr_rays *rays, int32_t 
                                 const int64_t *d_offsets, float *d_loc, int32_t *d_ray_idx,
                                 int32_t *d_tri_idx, int64_t ray_base, void *stream);
 
+/*    Fused variant (one traversal instead of two): tr_intersects_count_topk writes the uncapped
+ *    count AND, for each ray, the arena slots of its `cap` nearest hits (d_slots: [n, cap]
+ *    int32, -1 = none); after tr_hits_scan, tr_location_fill_slots produces exactly what
+ *    tr_intersects_location_fill produces, without traversing again.                      */
+int tr_intersects_count_topk(const tr_bvh *bvh, const tr_rays *rays, int32_t cap,
+                             int32_t *d_count, int32_t *d_slots, void *stream);
+int tr_location_fill_slots(const tr_bvh *bvh, const tr_rays *rays, int32_t cap,
+                           const int32_t *d_count, const int64_t *d_offsets,
+                           const int32_t *d_slots, float *d_loc, int32_t *d_ray_idx,
+                           int32_t *d_tri_idx, int64_t ray_base, void *stream);
+
 /* -- stream compaction of closest-hit results (ray_optix.py:142-144, 219-223): keeps the
  *    rows with hit != 0, in ray order.  d_offsets (n int64) = exclusive scan of hit, from
  *    tr_mask_scan (same total/h_total convention as tr_hits_scan).  Any output may be NULL. */

@@ -424,3 +424,17 @@ def test_refit_and_serialization(device, tmp_path):
     from triro.ray.ray_optix import OptixAccelStructureWrapper
     with pytest.raises(ValueError):
         OptixAccelStructureWrapper().deserialize(blob, device)
+
+
+def test_location_fused_equals_two_pass(device):
+    import triro.backend.ops as hops
+    v, f = W.nested_shells(4, radii=(1.0, 0.8, 0.6, 0.4, 0.3))
+    r = make(v, f, device)
+    o, d = W.pinhole_grid(300, 200)
+    ot, dt = T(o, device), T(d, device)
+    a = hops.intersects_location(r.as_wrapper, ot, dt, fused=True)
+    b = hops.intersects_location(r.as_wrapper, ot, dt, fused=False)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    a = hops.intersects_location(r.as_wrapper, ot, dt, ray_base=1000, fused=True)
+    assert int(a[1].min()) >= 1000

@@ -228,6 +228,7 @@ int tr_bvh_destroy(tr_bvh* bvh) {
         DeviceGuard g;
         if (g.enter(bvh->device) == TR_OK && bvh->arena) {
             if (hipFree(bvh->arena) != hipSuccess) status = tr_fail(TR_ERR_HIP, "hipFree(arena)");
+            if (bvh->refit_temp && hipFree(bvh->refit_temp) != hipSuccess) status = tr_fail(TR_ERR_HIP, "hipFree(refit_temp)");
             for (int k = 0; k < TR_SCHED_SLOTS; k++)
                 if (bvh->sched[k].buf && hipFree(bvh->sched[k].buf) != hipSuccess) status = tr_fail(TR_ERR_HIP, "hipFree(sched)");
         }

@@ -550,9 +550,13 @@ int tr_refit_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_
     const int64_t ni = bvh->num_nodes;
     Carver tc{nullptr};
     tc.take<float>(6 * (size_t)nf); tc.take<float>(6 * (size_t)(ni > 0 ? ni : 1)); tc.take<int32_t>((size_t)(ni > 0 ? ni : 1));
-    void* temp = nullptr;
-    TR_HIP_TRY(hipMalloc(&temp, align_up(tc.off, 256)));
-    Carver c2{(char*)temp};
+    const size_t need = align_up(tc.off, 256);
+    if (bvh->refit_temp_bytes < need) {
+        if (bvh->refit_temp) { TR_HIP_TRY(hipFree(bvh->refit_temp)); bvh->refit_temp = nullptr; bvh->refit_temp_bytes = 0; }
+        TR_HIP_TRY(hipMalloc(&bvh->refit_temp, need));
+        bvh->refit_temp_bytes = need;
+    }
+    Carver c2{(char*)bvh->refit_temp};
     float* sbox = c2.take<float>(6 * (size_t)nf);
     float* ibox = c2.take<float>(6 * (size_t)(ni > 0 ? ni : 1));
     int32_t* ready = c2.take<int32_t>((size_t)(ni > 0 ? ni : 1));
@@ -583,7 +587,5 @@ int tr_refit_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_
         if (status == TR_OK)
             for (int k = 0; k < 3; k++) { bvh->aabb_min[k] = box[k]; bvh->aabb_max[k] = box[3 + k]; }
     }
-    hipError_t fe = hipFree(temp);
-    if (fe != hipSuccess && status == TR_OK) status = tr_fail(TR_ERR_HIP, "hipFree(temp)");
     return status;
 }

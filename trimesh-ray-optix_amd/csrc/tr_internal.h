@@ -54,6 +54,8 @@ struct tr_bvh {
     tr_tri* tris = nullptr;
     float aabb_min[3] = {0, 0, 0};
     float aabb_max[3] = {0, 0, 0};
+    void* refit_temp = nullptr;   // boxes + flags of tr_bvh_refit, kept between calls (animation loops)
+    size_t refit_temp_bytes = 0;
     // adaptive launch order (speed only, see traverse.hip).  One slot per stream that has
     // queried this handle, so launches on different streams never share hint buffers.
     tr_sched_slot sched[TR_SCHED_SLOTS];

@@ -393,6 +393,88 @@ __global__ __launch_bounds__(256) void k_location(tr_bvh_view b, RayFetch rf, in
     }
 }
 
+// ---- fused multi-hit: ONE traversal yields the (uncapped) count and the slots of the `cap`
+// nearest hits; the fill pass then needs no traversal at all (the reference -- and the
+// tr_intersects_count + tr_intersects_location_fill pair -- traverse twice).
+template <int K>
+__global__ __launch_bounds__(256) void k_count_topk(tr_bvh_view b, RayFetch rf, int32_t cap,
+                                                    int32_t* __restrict__ count,
+                                                    int32_t* __restrict__ slots, int xcd_map,
+                                                    const uint32_t* __restrict__ order,
+                                                    uint32_t* __restrict__ cost) {
+    __shared__ int32_t ring_lds[TR_RING * 256];
+    const tr_ring ring = {ring_lds + threadIdx.x, 256};
+    const unsigned long long t_start = cost ? wall_clock64() : 0ull;
+    int64_t blk = blockIdx.x;
+    if (order) {
+        blk = order[blockIdx.x];
+    } else if (xcd_map > 0) {
+        const int64_t T = xcd_map, span = 8 * T;
+        const int64_t nfull = (int64_t)gridDim.x / span * span;
+        if (blk < nfull) {
+            const int64_t x = blk & 7, k = blk >> 3;
+            blk = ((k / T) * 8 + x) * T + (k % T);
+        }
+    }
+    const int64_t i = blk * 256 + threadIdx.x;
+    const bool in_range = i < rf.n;
+    float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
+    if (in_range) fetch_ray(rf, i, o, d);
+    tr_ray r;
+    const bool valid = tr_ray_setup(r, o[0], o[1], o[2], d[0], d[1], d[2]) && in_range;
+    tr_result res;
+    tr_topk<K> top;
+    tr_counters* nc = nullptr;
+    if (b.num_tris >= 2) {
+        wave_traverse<TR_Q_LOCATION, K, false>(b, r, valid, res, top, nc, ring);
+    } else {
+        top.init();
+        brute_one<TR_Q_LOCATION>(b, r, valid, res);
+        if (res.count) top.insert(res.best_t, res.best_face, 0);
+    }
+    if (in_range) {
+        count[i] = res.count;
+        int32_t* s = slots + i * cap;
+#pragma unroll
+        for (int k = 0; k < K; k++)
+            if (k < cap) s[k] = k < res.count ? top.slot[k] : -1;
+    }
+    if (cost && (threadIdx.x & 63) == 0) {
+        const unsigned long long dt = wall_clock64() - t_start;
+        atomicMax(&cost[blk], (uint32_t)(dt > 0x7ffffull ? 0x7ffffull : dt));
+    }
+}
+
+// one thread per (ray, k): re-evaluate the kept triangle (same arithmetic, same values)
+__global__ __launch_bounds__(256) void k_fill_slots(tr_bvh_view b, RayFetch rf, int32_t cap,
+                                                    const int32_t* __restrict__ count,
+                                                    const int64_t* __restrict__ offsets,
+                                                    const int32_t* __restrict__ slots,
+                                                    float* __restrict__ loc,
+                                                    int32_t* __restrict__ ray_idx,
+                                                    int32_t* __restrict__ tri_idx, int64_t ray_base) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = g / cap;
+    const int32_t k = (int32_t)(g - i * cap);
+    if (i >= rf.n) return;
+    const int32_t c = count[i];
+    if (k >= (c < cap ? c : cap)) return;
+    float o[3], d[3];
+    fetch_ray(rf, i, o, d);
+    tr_ray r;
+    tr_ray_setup(r, o[0], o[1], o[2], d[0], d[1], d[2]);
+    tr_counters* nc = nullptr;
+    const tr_tri t = tr_load_tri<false>(b, slots[g], nc);
+    tr_hit h;
+    tr_tri_hit(r, t.ax, t.ay, t.az, t.bx, t.by, t.bz, t.cx, t.cy, t.cz, h);
+    float l3[3], uv[2];
+    tr_hit_outputs(h, t.ax, t.ay, t.az, t.bx, t.by, t.bz, t.cx, t.cy, t.cz, l3, uv);
+    const int64_t w = offsets[i] + k;
+    loc[3 * w] = l3[0]; loc[3 * w + 1] = l3[1]; loc[3 * w + 2] = l3[2];
+    ray_idx[w] = (int32_t)(i + ray_base);
+    tri_idx[w] = t.face;
+}
+
 // ---- scans (replace the torch glue of ray.cpp:333-342 and ray_optix.py:142-144) ---------------
 constexpr int SCAN_ITEMS = 4;
 constexpr int SCAN_BLOCK = 1024;
@@ -540,6 +622,36 @@ tr_bvh_view make_view(const tr_bvh* bvh) {
     return v;
 }
 
+// Adaptive launch order: the blocks of the previous launch on the same (handle, stream) with the
+// same block count are started most-expensive-first, so the longest rays of a batch -- its
+// critical path -- do not start last.  Hints never affect results; each stream has its own
+// buffers, so overlapping launches cannot see a half-written order.  Returns cost != NULL when
+// this launch should record block costs (and be followed by k_sched_sort), order != NULL when a
+// measured order exists for this block count.
+void sched_acquire(const tr_bvh* bvh, hipStream_t stream, int64_t nblocks, const uint32_t** order,
+                   uint32_t** cost) {
+    *order = nullptr;
+    *cost = nullptr;
+    tr_bvh* mb = const_cast<tr_bvh*>(bvh);
+    if (!tr_opts().adaptive || !mb->sched_mutex || nblocks < 64 || nblocks > TR_SCHED_MAX) return;
+    tr_sched_slot* slot = nullptr;
+    std::lock_guard<std::mutex> lock(*mb->sched_mutex);
+    for (int k = 0; k < TR_SCHED_SLOTS && !slot; k++)
+        if (mb->sched[k].used && mb->sched[k].stream == stream) slot = &mb->sched[k];
+    for (int k = 0; k < TR_SCHED_SLOTS && !slot; k++)
+        if (!mb->sched[k].used) {
+            uint32_t* buf = nullptr;
+            if (hipMalloc((void**)&buf, sizeof(uint32_t) * 2 * TR_SCHED_MAX) != hipSuccess) { (void)hipGetLastError(); break; }
+            if (hipMemsetAsync(buf, 0, sizeof(uint32_t) * 2 * TR_SCHED_MAX, stream) != hipSuccess) { (void)hipFree(buf); break; }
+            mb->sched[k].used = true; mb->sched[k].stream = stream; mb->sched[k].buf = buf; mb->sched[k].nblocks = 0;
+            slot = &mb->sched[k];
+        }
+    if (!slot) return;
+    *cost = slot->buf;
+    if (slot->nblocks == nblocks) *order = slot->buf + TR_SCHED_MAX;
+    slot->nblocks = nblocks;   // the sort enqueued after the launch makes it valid for the next one
+}
+
 template <int Q, bool STATS>
 int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
                  unsigned long long* d_stats, hipStream_t stream) {
@@ -581,32 +693,9 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
         const bool compact = opt.compact && bvh->depth <= 32 &&
                              bvh->num_nodes * (int64_t)sizeof(tr_node) < ((int64_t)1 << 32) &&
                              bvh->num_tris * (int64_t)sizeof(tr_tri) < ((int64_t)1 << 32);
-        // Adaptive launch order: the blocks of the previous launch on the same (handle, stream)
-        // with the same block count are started most-expensive-first, so the longest rays of a
-        // batch -- its critical path -- do not start last.  Hints never affect results; each
-        // stream has its own buffers, so overlapping launches cannot see a half-written order.
         const uint32_t* order = nullptr;
         uint32_t* cost = nullptr;
-        tr_sched_slot* slot = nullptr;
-        tr_bvh* mb = const_cast<tr_bvh*>(bvh);
-        if (opt.adaptive && !STATS && mb->sched_mutex && nblocks_direct >= 64 && nblocks_direct <= TR_SCHED_MAX) {
-            std::lock_guard<std::mutex> lock(*mb->sched_mutex);
-            for (int k = 0; k < TR_SCHED_SLOTS && !slot; k++)
-                if (mb->sched[k].used && mb->sched[k].stream == stream) slot = &mb->sched[k];
-            for (int k = 0; k < TR_SCHED_SLOTS && !slot; k++)
-                if (!mb->sched[k].used) {
-                    uint32_t* buf = nullptr;
-                    if (hipMalloc((void**)&buf, sizeof(uint32_t) * 2 * TR_SCHED_MAX) != hipSuccess) { (void)hipGetLastError(); break; }
-                    if (hipMemsetAsync(buf, 0, sizeof(uint32_t) * 2 * TR_SCHED_MAX, stream) != hipSuccess) { (void)hipFree(buf); break; }
-                    mb->sched[k].used = true; mb->sched[k].stream = stream; mb->sched[k].buf = buf; mb->sched[k].nblocks = 0;
-                    slot = &mb->sched[k];
-                }
-            if (slot) {
-                cost = slot->buf;
-                if (slot->nblocks == nblocks_direct) order = slot->buf + TR_SCHED_MAX;
-                slot->nblocks = nblocks_direct;   // the sort enqueued below makes it valid for the next launch
-            }
-        }
+        if (!STATS) sched_acquire(bvh, stream, nblocks_direct, &order, &cost);
         if (compact)
             hipLaunchKernelGGL((k_query_direct<Q, STATS, true>), dim3((unsigned)nblocks_direct), dim3(256), 0, stream,
                                view, rf, out, opt.xcd_chunk, order, cost, d_stats);
@@ -709,6 +798,46 @@ int tr_intersects_location_fill(const tr_bvh* bvh, const tr_rays* rays, int32_t 
         hipLaunchKernelGGL(k_location<16>, grid, block, 0, s, view, rf, cap, d_offsets, d_loc, d_ray_idx, d_tri_idx, ray_base);
     else
         hipLaunchKernelGGL(k_location<32>, grid, block, 0, s, view, rf, cap, d_offsets, d_loc, d_ray_idx, d_tri_idx, ray_base);
+    TR_HIP_TRY(hipGetLastError());
+    return TR_OK;
+}
+
+int tr_intersects_count_topk(const tr_bvh* bvh, const tr_rays* rays, int32_t cap, int32_t* d_count,
+                             int32_t* d_slots, void* stream) {
+    if (!bvh) return tr_fail(TR_ERR_INVALID_ARG, "bvh == NULL");
+    if (cap < 1 || cap > TR_MAX_HITS_CAP) return tr_fail(TR_ERR_INVALID_ARG, "cap out of range");
+    RayFetch rf;
+    TR_TRY(make_fetch(rays, &rf));
+    if (rf.n == 0) return TR_OK;
+    if (!d_count || !d_slots) return tr_fail(TR_ERR_INVALID_ARG, "null output pointer");
+    tr_bvh_view view = make_view(bvh);
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)((rf.n + 255) / 256)), block(256);
+    const int xm = tr_opts().xcd_chunk;
+    const uint32_t* order = nullptr;
+    uint32_t* cost = nullptr;
+    sched_acquire(bvh, s, (int64_t)grid.x, &order, &cost);
+    if (cap <= 8) hipLaunchKernelGGL(k_count_topk<8>, grid, block, 0, s, view, rf, cap, d_count, d_slots, xm, order, cost);
+    else if (cap <= 16) hipLaunchKernelGGL(k_count_topk<16>, grid, block, 0, s, view, rf, cap, d_count, d_slots, xm, order, cost);
+    else hipLaunchKernelGGL(k_count_topk<32>, grid, block, 0, s, view, rf, cap, d_count, d_slots, xm, order, cost);
+    if (cost) hipLaunchKernelGGL(k_sched_sort, dim3(1), dim3(1024), 0, s, cost, cost + TR_SCHED_MAX, (int)grid.x);
+    TR_HIP_TRY(hipGetLastError());
+    return TR_OK;
+}
+
+int tr_location_fill_slots(const tr_bvh* bvh, const tr_rays* rays, int32_t cap, const int32_t* d_count,
+                           const int64_t* d_offsets, const int32_t* d_slots, float* d_loc,
+                           int32_t* d_ray_idx, int32_t* d_tri_idx, int64_t ray_base, void* stream) {
+    if (!bvh) return tr_fail(TR_ERR_INVALID_ARG, "bvh == NULL");
+    if (cap < 1 || cap > TR_MAX_HITS_CAP) return tr_fail(TR_ERR_INVALID_ARG, "cap out of range");
+    RayFetch rf;
+    TR_TRY(make_fetch(rays, &rf));
+    if (rf.n == 0) return TR_OK;
+    if (!d_count || !d_offsets || !d_slots) return tr_fail(TR_ERR_INVALID_ARG, "null input pointer");
+    tr_bvh_view view = make_view(bvh);
+    const int64_t threads = rf.n * cap;
+    hipLaunchKernelGGL(k_fill_slots, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       view, rf, cap, d_count, d_offsets, d_slots, d_loc, d_ray_idx, d_tri_idx, ray_base);
     TR_HIP_TRY(hipGetLastError());
     return TR_OK;
 }

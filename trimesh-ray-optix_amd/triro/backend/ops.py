@@ -81,6 +81,8 @@ ABI = {
     "tr_intersects_count": (_int, [_vp, C.POINTER(TrRays), _vp, _vp]),
     "tr_hits_scan": (_int, [_vp, _i64, _i32, _vp, _vp, C.POINTER(_i64), _vp]),
     "tr_intersects_location_fill": (_int, [_vp, C.POINTER(TrRays), _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "tr_intersects_count_topk": (_int, [_vp, C.POINTER(TrRays), _i32, _vp, _vp, _vp]),
+    "tr_location_fill_slots": (_int, [_vp, C.POINTER(TrRays), _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "tr_mask_scan": (_int, [_vp, _i64, _vp, _vp, C.POINTER(_i64), _vp]),
     "tr_compact_closest": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tr_trace_stats_closest": (_int, [_vp, C.POINTER(TrRays), C.POINTER(TrTraceStats), _vp]),
@@ -241,14 +243,39 @@ def intersects_count(accel_structure, origins, dirs) -> torch.Tensor:
     return out
 
 
-def intersects_location(accel_structure, origins, dirs, ray_base: int = 0) -> Tuple[torch.Tensor, ...]:
+def intersects_location(accel_structure, origins, dirs, ray_base: int = 0, fused: bool = True) -> Tuple[torch.Tensor, ...]:
     """ops.py:171-192 / ray.cpp:324-378.  (loc[h,3], ray_idx[h], tri_idx[h]); at most
     MAX_ANYHIT_SIZE hits per ray, grouped by ray; within a ray ordered by distance (the
-    reference leaves that order unspecified)."""
+    reference leaves that order unspecified).
+
+    fused=True (default): one traversal (count + slots of the 8 nearest hits), scan, fill from
+    the slots.  fused=False: the reference's protocol, count pass -> scan -> second traversal
+    (ray.cpp:330, 333-342, 372-374); both give identical results."""
     check_rays(origins, dirs)
     dev = origins.device
     lib = get_module()
     n = origins.numel() // 3
+    if fused:
+        with torch.cuda.device(dev):
+            stream = _stream_ptr(dev)
+            rays = make_rays(origins, dirs)
+            count = torch.empty(n, dtype=torch.int32, device=dev)
+            slots = torch.empty((n, MAX_ANYHIT_SIZE), dtype=torch.int32, device=dev)
+            _check(lib.tr_intersects_count_topk(_handle(accel_structure), C.byref(rays), MAX_ANYHIT_SIZE,
+                                                count.data_ptr(), slots.data_ptr(), stream))
+            offsets = torch.empty(n, dtype=torch.int64, device=dev)
+            total_d = torch.empty(1, dtype=torch.int64, device=dev)
+            total = C.c_int64(0)
+            _check(lib.tr_hits_scan(count.data_ptr(), n, MAX_ANYHIT_SIZE, offsets.data_ptr(), total_d.data_ptr(),
+                                    C.byref(total), stream))
+            nhits = int(total.value)
+            loc = torch.empty((nhits, 3), dtype=torch.float32, device=dev)
+            tri = torch.empty(nhits, dtype=torch.int32, device=dev)
+            ray = torch.empty(nhits, dtype=torch.int32, device=dev)
+            _check(lib.tr_location_fill_slots(_handle(accel_structure), C.byref(rays), MAX_ANYHIT_SIZE,
+                                              count.data_ptr(), offsets.data_ptr(), slots.data_ptr(),
+                                              loc.data_ptr(), ray.data_ptr(), tri.data_ptr(), ray_base, stream))
+        return loc, ray, tri
     with torch.cuda.device(dev):
         stream = _stream_ptr(dev)
         rays = make_rays(origins, dirs)
