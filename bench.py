@@ -42,8 +42,6 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--persistent", type=int, default=None)
     ap.add_argument("--blocks-per-cu", type=int, default=None)
-    ap.add_argument("--tile", type=int, default=0, help="experiment: pre-permute pinhole rays into TxT pixel tiles")
-    ap.add_argument("--perm", default="", help="experiment: .npy of per-ray costs; rays are pre-sorted by cost (descending)")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (tr_set_option)")
     ap.add_argument("--stats", action="store_true", help="also print traversal counters (diagnostic kernel)")
     return ap.parse_args()
@@ -122,15 +120,6 @@ def main():
         # every rank traces its own shard: same camera, rolled by `rank` rows so shards differ
         o_np = np.ascontiguousarray(o_np)
         d_np = np.roll(d_np, rank * 7, axis=0)
-        if args.tile:
-            T_ = args.tile
-            d_np = d_np.reshape(args.res // T_, T_, args.res // T_, T_, 3).transpose(0, 2, 1, 3, 4).reshape(-1, 3)
-            o_np = o_np.reshape(-1, 3)
-        if args.perm:
-            cost = np.load(args.perm).reshape(-1)
-            order = np.argsort(-cost, kind="stable")
-            d_np = d_np.reshape(-1, 3)[order]
-            o_np = o_np.reshape(-1, 3)[order]
         origins = torch.from_numpy(np.ascontiguousarray(o_np)).to(dev)
         dirs = torch.from_numpy(np.ascontiguousarray(d_np)).to(dev)
     else:
