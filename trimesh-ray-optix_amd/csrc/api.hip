@@ -277,6 +277,11 @@ int tr_set_option(const char* name, int64_t value) {
     }
     if (!strcmp(name, "refill")) { g_options.refill = value != 0; return TR_OK; }
     if (!strcmp(name, "adaptive")) { g_options.adaptive = value != 0; return TR_OK; }
+    if (!strcmp(name, "block_size")) {
+        if (value != 64 && value != 128 && value != 256) return tr_fail(TR_ERR_INVALID_ARG, "block_size must be 64, 128 or 256");
+        g_options.block_size = (int)value;
+        return TR_OK;
+    }
     if (!strcmp(name, "compact")) { g_options.compact = value != 0; return TR_OK; }
     if (!strcmp(name, "xcd_chunk")) {
         if (value < 0 || value > 65536) return tr_fail(TR_ERR_INVALID_ARG, "xcd_chunk out of range");

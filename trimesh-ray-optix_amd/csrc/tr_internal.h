@@ -90,6 +90,7 @@ struct tr_options {
     int persistent = 0;
     int blocks_per_cu = 8;
     int refill = 1;
+    int block_size = 128; // workgroup size of the direct kernel (64, 128 or 256)
     int adaptive = 1;     // start the blocks that were most expensive in the previous launch first
     int compact = 1;      // allow the 32-bit trail / 32-bit offset kernels when the BVH permits
     int refill_min = 16;

@@ -153,15 +153,15 @@ __device__ __forceinline__ void flush_stats(const tr_counters& c, unsigned long 
     }
 }
 
-template <int Q, bool STATS, bool COMPACT>
-__global__ __launch_bounds__(256) void k_query_direct(tr_bvh_view b, RayFetch rf, QueryOut out,
+template <int Q, bool STATS, bool COMPACT, int BS>
+__global__ __launch_bounds__(BS) void k_query_direct(tr_bvh_view b, RayFetch rf, QueryOut out,
                                                       int xcd_map,
                                                       const uint32_t* __restrict__ order,
                                                       uint32_t* __restrict__ cost,
                                                       unsigned long long* stats) {
     const unsigned long long t_start = cost ? wall_clock64() : 0ull;
-    __shared__ int32_t ring_lds[TR_RING * 256];
-    const tr_ring ring = {ring_lds + threadIdx.x, 256};
+    __shared__ int32_t ring_lds[TR_RING * BS];
+    const tr_ring ring = {ring_lds + threadIdx.x, BS};
     // XCD-aware block -> ray-tile map: workgroups are dealt round-robin over the 8 XCDs
     // (blocks b and b+8 share one).  The ray range is cut into chunks of `xcd_map` blocks and
     // chunk c goes to XCD c % 8, so each XCD's private L2 works on compact pieces of the image
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void k_query_direct(tr_bvh_view b, RayFetch rf
             blk = ((k / T) * 8 + x) * T + (k % T);
         }
     }
-    int64_t i = blk * 256 + threadIdx.x;
+    int64_t i = blk * BS + threadIdx.x;
     tr_counters cnt = {0, 0, 0};
     process_ray<Q, STATS, COMPACT>(b, rf, out, i, i < rf.n, &cnt, ring);
     if (cost && (threadIdx.x & 63) == 0) {
@@ -663,7 +663,8 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
     TR_TRY(tr_get_device_state(bvh->device, &st));
     tr_bvh_view view = make_view(bvh);
     const tr_options& opt = tr_opts();
-    const int64_t nblocks_direct = (rf.n + 255) / 256;
+    const int bs = opt.block_size;
+    const int64_t nblocks_direct = (rf.n + bs - 1) / bs;
     int64_t pgrid = (int64_t)st->num_cus * opt.blocks_per_cu;
     if (opt.persistent) {
         // size the persistent grid by what is actually resident (4 waves per block = 1 per SIMD)
@@ -696,12 +697,14 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
         const uint32_t* order = nullptr;
         uint32_t* cost = nullptr;
         if (!STATS) sched_acquire(bvh, stream, nblocks_direct, &order, &cost);
-        if (compact)
-            hipLaunchKernelGGL((k_query_direct<Q, STATS, true>), dim3((unsigned)nblocks_direct), dim3(256), 0, stream,
-                               view, rf, out, opt.xcd_chunk, order, cost, d_stats);
-        else
-            hipLaunchKernelGGL((k_query_direct<Q, STATS, false>), dim3((unsigned)nblocks_direct), dim3(256), 0, stream,
-                               view, rf, out, opt.xcd_chunk, order, cost, d_stats);
+        const int xc = opt.xcd_chunk * (256 / bs);   // chunk size is kept in rays
+#define TR_LAUNCH_DIRECT(C, B)                                                                          \
+    hipLaunchKernelGGL((k_query_direct<Q, STATS, C, B>), dim3((unsigned)nblocks_direct), dim3(B), 0, stream, \
+                       view, rf, out, xc, order, cost, d_stats)
+        if (bs == 64) { if (compact) TR_LAUNCH_DIRECT(true, 64); else TR_LAUNCH_DIRECT(false, 64); }
+        else if (bs == 128) { if (compact) TR_LAUNCH_DIRECT(true, 128); else TR_LAUNCH_DIRECT(false, 128); }
+        else { if (compact) TR_LAUNCH_DIRECT(true, 256); else TR_LAUNCH_DIRECT(false, 256); }
+#undef TR_LAUNCH_DIRECT
         if (cost)
             hipLaunchKernelGGL(k_sched_sort, dim3(1), dim3(1024), 0, stream, cost, cost + TR_SCHED_MAX,
                                (int)nblocks_direct);
