@@ -135,9 +135,11 @@ class RayMeshIntersector:
         else:
             ray_directions = torch.tile(check_direction.to(device=dev, dtype=torch.float32), [*contains.shape, 1])
         points = points.contiguous()
-        hit_count = torch.stack(
-            [hops.intersects_count(self.as_wrapper, points, ray_directions),
-             hops.intersects_count(self.as_wrapper, points, -ray_directions)], dim=0)
+        # the reference launches intersects_count twice (:257-263); both directions go through
+        # ONE launch here (rays are independent, so the counts are the same)
+        both = hops.intersects_count(self.as_wrapper, torch.cat([points, points], dim=0),
+                                     torch.cat([ray_directions, -ray_directions], dim=0))
+        hit_count = both.reshape(2, *contains.shape)
         hit_count_mod_2 = torch.remainder(hit_count, 2)
         agree = torch.all(hit_count_mod_2, dim=0)
         contain = (inside_aabb & agree & hit_count_mod_2[0]) == 1   # operator precedence of :267
