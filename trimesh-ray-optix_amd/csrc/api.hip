@@ -75,6 +75,35 @@ int tr_scratch_reserve(tr_device_state* st, size_t bytes, void** out) {
     return TR_OK;
 }
 
+int tr_build_temp_acquire(tr_device_state* st, size_t bytes, void** out) {
+    st->build_mutex.lock();
+    if (st->build_temp_bytes < bytes) {
+        hipError_t e = hipSuccess;
+        if (st->build_temp) { e = hipFree(st->build_temp); st->build_temp = nullptr; st->build_temp_bytes = 0; }
+        if (e == hipSuccess) e = hipMalloc(&st->build_temp, bytes);
+        if (e != hipSuccess) {
+            st->build_temp = nullptr;
+            st->build_mutex.unlock();
+            return tr_fail(e == hipErrorOutOfMemory ? TR_ERR_OUT_OF_MEMORY : TR_ERR_HIP,
+                           std::string("builder temporaries: ") + hipGetErrorName(e));
+        }
+        st->build_temp_bytes = bytes;
+    }
+    *out = st->build_temp;
+    return TR_OK;
+}
+
+int tr_build_temp_release(tr_device_state* st) {
+    int status = TR_OK;
+    if (!g_options.build_cache && st->build_temp) {
+        if (hipFree(st->build_temp) != hipSuccess) status = tr_fail(TR_ERR_HIP, "hipFree(builder temporaries)");
+        st->build_temp = nullptr;
+        st->build_temp_bytes = 0;
+    }
+    st->build_mutex.unlock();
+    return status;
+}
+
 extern "C" {
 
 int tr_abi_version(void) { return TR_ABI_VERSION; }
@@ -277,6 +306,7 @@ int tr_set_option(const char* name, int64_t value) {
     }
     if (!strcmp(name, "refill")) { g_options.refill = value != 0; return TR_OK; }
     if (!strcmp(name, "adaptive")) { g_options.adaptive = value != 0; return TR_OK; }
+    if (!strcmp(name, "build_cache")) { g_options.build_cache = value != 0; return TR_OK; }
     if (!strcmp(name, "block_size")) {
         if (value != 64 && value != 128 && value != 256) return tr_fail(TR_ERR_INVALID_ARG, "block_size must be 64, 128 or 256");
         g_options.block_size = (int)value;

@@ -71,11 +71,20 @@ struct tr_device_state {
     unsigned next_counter = 0;
     void* scratch = nullptr;        // scan partials etc.
     size_t scratch_bytes = 0;
+    // builder temporaries (sort buffers, boxes, hierarchy), kept between builds so that a
+    // rebuild (`update_raw`) costs no hipMalloc/hipFree.  One build per device at a time.
+    void* build_temp = nullptr;
+    size_t build_temp_bytes = 0;
+    std::mutex build_mutex;
 };
 constexpr int TR_NUM_COUNTERS = 4096;
 
 int tr_get_device_state(int device, tr_device_state** out);
 int tr_scratch_reserve(tr_device_state* st, size_t bytes, void** out);
+// returns with st->build_mutex HELD on success; tr_build_temp_release unlocks (and frees the
+// buffer when option build_cache == 0).  The caller must have drained its stream by then.
+int tr_build_temp_acquire(tr_device_state* st, size_t bytes, void** out);
+int tr_build_temp_release(tr_device_state* st);
 
 // builder (bvh_build.hip) -----------------------------------------------------------------
 int tr_build_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_t* d_faces,
@@ -96,6 +105,7 @@ struct tr_options {
     int refill_min = 16;
     int xcd_segments = 1;   // refill kernel: per-XCD work counters
     int xcd_chunk = 256;    // direct kernel: blocks per XCD-local chunk (0 = identity map)
+    int build_cache = 1;  // keep the builder's temporaries (about 130 B/triangle) per device between builds
     int leaf_min = 0;     // refill kernel only: lanes with a queued leaf that fire its leaf phase (0 = any)
 };
 tr_options& tr_opts();
