@@ -281,6 +281,32 @@ def test_update_raw_rebuilds(device):
     assert torch.equal(r.intersects_first(T(o, device), T(d, device)), a)
 
 
+def test_rebuild_shares_cached_temporaries(device):
+    """The builder's temporaries are cached per device and the refit-round count of a rebuild is
+    guessed from the previous height: interleave handles of different sizes, rebuild a shallow
+    tree into a deep one (guess too small -> extra rounds), and switch the cache off."""
+    from triro.backend import ops as hops
+    o, d = W.hash_rays(20000, 5, [-1.5] * 3, [1.5] * 3)
+    ot, dt = T(o, device), T(d, device)
+    meshes = [W.icosphere(2), W.bunny_standin(), W.random_soup(5000, seed=2), W.deep_tree_mesh(3000)]
+    exp = [OracleIntersector(v, f, 1).closest_raw(o, d) for v, f in meshes]
+    rs = [make(v, f, device) for v, f in meshes]
+    for cache in (1, 0, 1):
+        hops.set_option("build_cache", cache)
+        try:
+            for k in range(len(meshes)):
+                # every handle takes over the NEXT mesh: sizes and heights change both ways
+                v, f = meshes[(k + 1) % len(meshes)]
+                rs[k].update_raw(T(v, device), T(f, device))
+                assert_closest_equal(rs[k].intersects_closest(ot, dt), exp[(k + 1) % len(meshes)])
+            for k in range(len(meshes)):
+                v, f = meshes[k]
+                rs[k].update_raw(T(v, device), T(f, device))
+                assert_closest_equal(rs[k].intersects_closest(ot, dt), exp[k])
+        finally:
+            hops.set_option("build_cache", 1)
+
+
 def test_contains_points(device):
     v, f = W.icosphere(3)
     r = make(v, f, device)
