@@ -58,10 +58,8 @@ static int build_hierarchy(SimBvh& b, const std::vector<uint64_t>& keys, const s
         const float* a = cl[i] < 0 ? &sbox[6 * (int64_t)(~cl[i])] : &ibox[6 * (int64_t)cl[i]];
         const float* c = cr[i] < 0 ? &sbox[6 * (int64_t)(~cr[i])] : &ibox[6 * (int64_t)cr[i]];
         tr_node nd;
-        for (int k = 0; k < 3; k++) {
-            nd.lo0[k] = a[k]; nd.hi0[k] = a[3 + k];
-            nd.lo1[k] = c[k]; nd.hi1[k] = c[3 + k];
-        }
+        tr_node_set_box(nd.box0, a, a + 3);
+        tr_node_set_box(nd.box1, c, c + 3);
         nd.c0 = cl[i]; nd.c1 = cr[i];
         int32_t p = par[i], sib = 0;
         if (p >= 0) sib = (cl[p] == (int32_t)i) ? cr[p] : cl[p];

@@ -170,13 +170,13 @@ int tr_bvh_refit(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_t
 // ---- (de)serialisation: header + the arena, byte for byte -------------------------------------
 namespace {
 struct tr_blob_header {
-    char magic[8];          // "TRBVH\0\0\1"
+    char magic[8];          // "TRBVH\0\0\2"
     int64_t num_tris, num_nodes, arena_bytes;
     int32_t depth, key_mode;
     float aabb_min[3], aabb_max[3];
     uint32_t sizeof_node, sizeof_tri, sizeof_link, pad;
 };
-const char TR_MAGIC[8] = {'T', 'R', 'B', 'V', 'H', 0, 0, 1};
+const char TR_MAGIC[8] = {'T', 'R', 'B', 'V', 'H', 0, 0, 2};   // 2: child boxes stored lo.xy|lo.z hi.z|hi.xy
 }  // namespace
 
 int64_t tr_bvh_serialized_size(const tr_bvh* bvh) {

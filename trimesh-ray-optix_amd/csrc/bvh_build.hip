@@ -307,11 +307,8 @@ __global__ __launch_bounds__(256) void k_emit(const int32_t* __restrict__ childL
     const float* a = cl < 0 ? sbox + 6 * (int64_t)(~cl) : ibox + 6 * (int64_t)cl;
     const float* b = cr < 0 ? sbox + 6 * (int64_t)(~cr) : ibox + 6 * (int64_t)cr;
     tr_node nd;
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        nd.lo0[k] = a[k]; nd.hi0[k] = a[3 + k];
-        nd.lo1[k] = b[k]; nd.hi1[k] = b[3 + k];
-    }
+    tr_node_set_box(nd.box0, a, a + 3);
+    tr_node_set_box(nd.box1, b, b + 3);
     nd.c0 = cl; nd.c1 = cr;
     int32_t p = parent[i];
     int32_t sib = 0;
@@ -377,11 +374,8 @@ __global__ __launch_bounds__(256) void k_update_boxes(tr_node* __restrict__ node
     const int32_t cl = nodes[i].c0, cr = nodes[i].c1;
     const float* a = cl < 0 ? sbox + 6 * (int64_t)(~cl) : ibox + 6 * (int64_t)cl;
     const float* b = cr < 0 ? sbox + 6 * (int64_t)(~cr) : ibox + 6 * (int64_t)cr;
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        nodes[i].lo0[k] = a[k]; nodes[i].hi0[k] = a[3 + k];
-        nodes[i].lo1[k] = b[k]; nodes[i].hi1[k] = b[3 + k];
-    }
+    tr_node_set_box(nodes[i].box0, a, a + 3);
+    tr_node_set_box(nodes[i].box1, b, b + 3);
 }
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

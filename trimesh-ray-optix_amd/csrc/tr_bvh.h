@@ -29,14 +29,21 @@ struct alignas(16) tr_i4 {
     int32_t x, y, z, w;
 };
 
+// Child boxes are stored as {lo.x, lo.y | lo.z, hi.z | hi.x, hi.y}: every aligned pair of
+// floats meets the SAME pair of ray constants ((ox,oy) or (oz,oz)), so the slab planes of a
+// node are 6 packed subtracts + 6 packed multiplies on the register pairs the 16-byte loads
+// produce (tr_node_slabs).
 struct alignas(64) tr_node {
-    float lo0[3], hi0[3];  // child 0 box
-    float lo1[3], hi1[3];  // child 1 box
+    float box0[6];  // child 0: lo.x lo.y lo.z hi.z hi.x hi.y
+    float box1[6];  // child 1
     int32_t c0, c1;
     int32_t parent;   // -1 at the root
     int32_t sibling;  // other child of parent (same encoding as c0/c1); root: 0
 };
 static_assert(sizeof(tr_node) == 64, "node must be 64 B");
+TR_HD void tr_node_set_box(float* box, const float* lo, const float* hi) {
+    box[0] = lo[0]; box[1] = lo[1]; box[2] = lo[2]; box[3] = hi[2]; box[4] = hi[0]; box[5] = hi[1];
+}
 
 struct alignas(8) tr_link {
     int32_t parent, sibling;
@@ -197,6 +204,35 @@ TR_HD bool tr_pending(const tr_state_t<W>& st) { return st.p0 >= 0 || st.p1 >= 0
 template <typename W>
 TR_HD bool tr_done(const tr_state_t<W>& st) { return st.node < 0 && st.p0 < 0 && st.p1 < 0; }
 
+#ifndef TR_PK_SLAB
+#define TR_PK_SLAB 1
+#endif
+// Slab intervals of both children of a node held in three 16-byte registers:
+// n0 = lo0.x lo0.y lo0.z hi0.z | n1 = hi0.x hi0.y lo1.x lo1.y | n2 = lo1.z hi1.z hi1.x hi1.y.
+// On the device the 12 planes are packed FP32 (v_pk_add_f32 / v_pk_mul_f32: the same IEEE
+// subtract and multiply per plane as tr_slab, two planes per instruction).
+TR_HD void tr_node_slabs(const tr_ray& r, const tr_f4& n0, const tr_f4& n1, const tr_f4& n2,
+                         float& tn0, float& tf0, float& tn1, float& tf1) {
+#if defined(__HIP_DEVICE_COMPILE__) && TR_PK_SLAB
+    typedef float tr_v2 __attribute__((ext_vector_type(2)));
+    const tr_v2 oxy = {r.ox, r.oy}, ozz = {r.oz, r.oz};
+    const tr_v2 ixy = {r.ix, r.iy}, izz = {r.iz, r.iz};
+    const tr_v2 a = (tr_v2{n0.x, n0.y} - oxy) * ixy;   // child 0: x1 y1
+    const tr_v2 b = (tr_v2{n0.z, n0.w} - ozz) * izz;   //          z1 z2
+    const tr_v2 c = (tr_v2{n1.x, n1.y} - oxy) * ixy;   //          x2 y2
+    const tr_v2 d = (tr_v2{n1.z, n1.w} - oxy) * ixy;   // child 1: x1 y1
+    const tr_v2 e = (tr_v2{n2.x, n2.y} - ozz) * izz;   //          z1 z2
+    const tr_v2 f = (tr_v2{n2.z, n2.w} - oxy) * ixy;   //          x2 y2
+    tn0 = fmaxf(fmaxf(fminf(a.x, c.x), fminf(a.y, c.y)), fminf(b.x, b.y));
+    tf0 = fminf(fminf(fmaxf(a.x, c.x), fmaxf(a.y, c.y)), fmaxf(b.x, b.y)) * TR_SLAB_PAD;
+    tn1 = fmaxf(fmaxf(fminf(d.x, f.x), fminf(d.y, f.y)), fminf(e.x, e.y));
+    tf1 = fminf(fminf(fmaxf(d.x, f.x), fmaxf(d.y, f.y)), fmaxf(e.x, e.y)) * TR_SLAB_PAD;
+#else
+    tr_slab(r, n0.x, n0.y, n0.z, n1.x, n1.y, n0.w, tn0, tf0);
+    tr_slab(r, n1.z, n1.w, n2.x, n2.z, n2.w, n2.y, tn1, tf1);
+#endif
+}
+
 // NODE PHASE: visit st.node (lane must have a node and no queued leaf): fetch the 64-B node,
 // test both child boxes, queue hit leaf children in (p0, p1), then move to the next node
 // (near child, or the deepest owed far child; -1 when the hierarchy is exhausted).
@@ -207,10 +243,9 @@ TR_HD void tr_node_step(const tr_bvh_view& b, const tr_ray& r, tr_state& st, con
     const tr_f4* np = reinterpret_cast<const tr_f4*>(b.nodes + st.node);
     const tr_f4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
     if (STATS) cnt->nodes++;
-    // n0 = lo0.xyz hi0.x | n1 = hi0.yz lo1.xy | n2 = lo1.z hi1.xyz | n3 = c0 c1 parent sibling
+    // n3 = c0 c1 parent sibling
     float tn0, tf0, tn1, tf1;
-    tr_slab(r, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tn0, tf0);
-    tr_slab(r, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, tn1, tf1);
+    tr_node_slabs(r, n0, n1, n2, tn0, tf0, tn1, tf1);
     union { float f; int32_t i; } u0, u1, u2, u3;
     u0.f = n3.x; u1.f = n3.y; u2.f = n3.z; u3.f = n3.w;
     const int32_t c0 = u0.i, c1 = u1.i;
@@ -312,10 +347,9 @@ TR_HD void tr_fused_step(const tr_bvh_view& b, const tr_ray& r, tr_state_t<W>& s
     }
     st.p0 = -1; st.p1 = -1;
     if (Q == TR_Q_ANY && fin) st.node = -1;
-    // n0 = lo0.xyz hi0.x | n1 = hi0.yz lo1.xy | n2 = lo1.z hi1.xyz | n3 = c0 c1 parent sibling
+    // n3 = c0 c1 parent sibling
     float tn0, tf0, tn1, tf1;
-    tr_slab(r, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tn0, tf0);
-    tr_slab(r, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, tn1, tf1);
+    tr_node_slabs(r, n0, n1, n2, tn0, tf0, tn1, tf1);
     union { float f; int32_t i; } u0, u1, u2, u3;
     u0.f = n3.x; u1.f = n3.y; u2.f = n3.z; u3.f = n3.w;
     const int32_t c0 = u0.i, c1 = u1.i;

@@ -154,7 +154,12 @@ __device__ __forceinline__ void flush_stats(const tr_counters& c, unsigned long 
 }
 
 template <int Q, bool STATS, bool COMPACT, int BS>
-__global__ __launch_bounds__(BS) void k_query_direct(tr_bvh_view b, RayFetch rf, QueryOut out,
+#ifdef TR_WPE
+#define TR_WPE_ATTR __attribute__((amdgpu_waves_per_eu(TR_WPE)))
+#else
+#define TR_WPE_ATTR
+#endif
+__global__ __launch_bounds__(BS) TR_WPE_ATTR void k_query_direct(tr_bvh_view b, RayFetch rf, QueryOut out,
                                                       int xcd_map,
                                                       const uint32_t* __restrict__ order,
                                                       uint32_t* __restrict__ cost,
