@@ -88,6 +88,25 @@ struct tr_hit {
     float det;   // > 0 : front face (CCW from the ray origin)
 };
 
+// det, U, V of Moller-Trumbore for (ray, triangle) -- a pure function of its inputs: the
+// closest-hit kernels keep only (t_key, face, slot) per ray while traversing and call this
+// again on the winning triangle to get the same bits for the outputs.
+TR_HD void tr_tri_duv(const tr_ray& r, float ax, float ay, float az, float bx, float by, float bz,
+                      float cx, float cy, float cz, float& det, float& U, float& V) {
+    float e1x = bx - ax, e1y = by - ay, e1z = bz - az;
+    float e2x = cx - ax, e2y = cy - ay, e2z = cz - az;
+    float px = fmaf(r.dy, e2z, -(r.dz * e2y));
+    float py = fmaf(r.dz, e2x, -(r.dx * e2z));
+    float pz = fmaf(r.dx, e2y, -(r.dy * e2x));
+    det = tr_dot(e1x, e1y, e1z, px, py, pz);
+    float sx = r.ox - ax, sy = r.oy - ay, sz = r.oz - az;
+    U = tr_dot(sx, sy, sz, px, py, pz);
+    float qx = fmaf(sy, e1z, -(sz * e1y));
+    float qy = fmaf(sz, e1x, -(sx * e1z));
+    float qz = fmaf(sx, e1y, -(sy * e1x));
+    V = tr_dot(r.dx, r.dy, r.dz, qx, qy, qz);
+}
+
 // Moller-Trumbore given the triangle's own slab interval [tn, tf].  Early exits are kept: in
 // a wave most candidate triangles fail on det / U / V, and the compiler skips the rest of the
 // test when no lane is left (s_cbranch_execz).

@@ -58,7 +58,7 @@ __device__ __forceinline__ void fetch_ray(const RayFetch& rf, int64_t idx, float
 
 template <int Q>
 __device__ __forceinline__ void write_result(const tr_bvh_view& b, const QueryOut& out, int64_t i,
-                                             const tr_result& res) {
+                                             const tr_ray& r, const tr_result& res) {
     if (Q == TR_Q_ANY) {
         out.hit[i] = res.best_face >= 0 ? 1 : 0;
     } else if (Q == TR_Q_FIRST) {
@@ -71,9 +71,12 @@ __device__ __forceinline__ void write_result(const tr_bvh_view& b, const QueryOu
         if (res.best_face >= 0) {
             tr_counters* nc = nullptr;
             tr_tri t = tr_load_tri<false>(b, res.best_slot, nc);
-            tr_hit h; h.t = res.best_t; h.U = res.U; h.V = res.V; h.det = res.det;
+            // (det, U, V) are recomputed from the winning triangle instead of being carried
+            // through the traversal loop (three registers and their moves on every hit update)
+            tr_hit h; h.t = res.best_t;
+            tr_tri_duv(r, t.ax, t.ay, t.az, t.bx, t.by, t.bz, t.cx, t.cy, t.cz, h.det, h.U, h.V);
             tr_hit_outputs(h, t.ax, t.ay, t.az, t.bx, t.by, t.bz, t.cx, t.cy, t.cz, loc, uv);
-            hit = 1; front = res.det > 0.f ? 1 : 0;
+            hit = 1; front = h.det > 0.f ? 1 : 0;
         }
         out.hit[i] = hit;
         out.front[i] = front;
@@ -137,7 +140,7 @@ __device__ __forceinline__ void process_ray(const tr_bvh_view& b, const RayFetch
     tr_topk<1> top;
     if (b.num_tris >= 2) wave_traverse<Q, 1, STATS, COMPACT>(b, r, valid, res, top, cnt, ring);
     else brute_one<Q>(b, r, valid, res);
-    if (in_range) write_result<Q>(b, out, i, res);
+    if (in_range) write_result<Q>(b, out, i, r, res);
 }
 
 template <bool STATS>
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(256) void k_query_refill(tr_bvh_view b, RayFetch rf
         if (refill_now || (exhausted && nidle == 64)) {
             // write-back of all finished lanes together (one divergent pass, not one per ray)
             if (unwritten) {
-                write_result<Q>(b, out, rid, res);
+                write_result<Q>(b, out, rid, r, res);
                 unwritten = false;
             }
         }
