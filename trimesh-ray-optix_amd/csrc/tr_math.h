@@ -45,6 +45,9 @@ struct tr_ray {
     float ix, iy, iz;   // clamped reciprocals
 };
 
+TR_HD uint32_t tr_f2u(float f) { union { float f; uint32_t u; } c; c.f = f; return c.u; }
+TR_HD float tr_u2f(uint32_t u) { union { float f; uint32_t u; } c; c.u = u; return c.f; }
+
 TR_HD float tr_inv(float d) {
     float inv = 1.0f / d;
     if (fabsf(inv) > TR_HUGE) inv = copysignf(TR_HUGE, d);   // inf (d = +-0 or denormal)
@@ -127,8 +130,13 @@ TR_HD bool tr_tri_mt(const tr_ray& r, float ax, float ay, float az, float bx, fl
     float qy = fmaf(sz, e1x, -(sx * e1z));
     float qz = fmaf(sx, e1y, -(sy * e1x));
     float V = tr_dot(r.dx, r.dy, r.dz, qx, qy, qz);
-    bool ok = (det > 0.0f) ? (U >= 0.0f && V >= 0.0f && (U + V) <= det)
-                           : (U <= 0.0f && V <= 0.0f && (U + V) >= det);
+    // inside test, both orientations at once: flipping the sign of U, V and det when det < 0
+    // is exact (and -(U+V) == (-U)+(-V)), so  det>0 ? (U>=0 && V>=0 && U+V<=det)
+    //                                              : (U<=0 && V<=0 && U+V>=det)
+    // becomes three compares on the flipped values -- no branch on the orientation.
+    const uint32_t flip = tr_f2u(det) & 0x80000000u;
+    const float Uf = tr_u2f(tr_f2u(U) ^ flip), Vf = tr_u2f(tr_f2u(V) ^ flip);
+    const bool ok = (Uf >= 0.0f) & (Vf >= 0.0f) & ((Uf + Vf) <= fabsf(det));
     if (!ok) return false;
     float T = tr_dot(e2x, e2y, e2z, qx, qy, qz);
     float t = T / det;
