@@ -77,8 +77,10 @@ TR_HD void tr_slab(const tr_ray& r, float lox, float loy, float loz, float hix, 
 }
 
 // box accepted for traversal with an upper limit on the entry distance
+// (tn <= tf && tf >= 0 && tn <= tlimit) with tlimit >= 0, folded into one compare:
+// max(tn, 0) <= tf  <=>  tn <= tf && 0 <= tf;  max(tn, 0) <= tlimit  <=>  tn <= tlimit.
 TR_HD bool tr_slab_hit(float tn, float tf, float tlimit) {
-    return (tn <= tf) && (tf >= 0.0f) && (tn <= tlimit);
+    return fmaxf(tn, 0.0f) <= fminf(tf, tlimit);
 }
 
 TR_HD float tr_dot(float ax, float ay, float az, float bx, float by, float bz) {
