@@ -357,10 +357,7 @@ TR_HD void tr_fused_step(const tr_bvh_view& b, const tr_ray& r, tr_state_t<W>& s
         if (STATS && live) cnt->tris++;
         fin = tr_fold_leaf<Q, K>(live, r, t0, q0, st.p0n, st.p0f, res, top);
     }
-    st.p0 = st.p1; st.p0n = st.p1n; st.p0f = st.p1f;
-    st.p1 = st.p2; st.p1n = st.p2n; st.p1f = st.p2f;
-    st.p2 = -1;
-    if (Q == TR_Q_ANY && fin) { st.node = -1; st.p0 = -1; st.p1 = -1; }
+    if (Q == TR_Q_ANY && fin) { st.node = -1; st.p1 = -1; st.p2 = -1; }
 #else
     const bool has_node = st.node >= 0;
     const tr_f4* np = tr_node_ptr<COMPACT>(b, has_node ? st.node : 0);
@@ -397,26 +394,33 @@ TR_HD void tr_fused_step(const tr_bvh_view& b, const tr_ray& r, tr_state_t<W>& s
     bool h0 = tr_slab_hit(tn0, tf0, lim) && go;
     bool h1 = tr_slab_hit(tn1, tf1, lim) && go;
 #if TR_LEAF_QUEUE
-    // at most one leaf is queued here (has_node requires p2 < 0 and the head was just tested)
-    if (h0 && c0 < 0) {
-        if (st.p0 < 0) { st.p0 = ~c0; st.p0n = tn0; st.p0f = tf0; }
-        else { st.p1 = ~c0; st.p1n = tn0; st.p1f = tf0; }
-        h0 = false;
-    }
-    if (h1 && c1 < 0) {
-        if (st.p0 < 0) { st.p0 = ~c1; st.p0n = tn1; st.p0f = tf1; }
-        else if (st.p1 < 0) { st.p1 = ~c1; st.p1n = tn1; st.p1f = tf1; }
-        else { st.p2 = ~c1; st.p2n = tn1; st.p2f = tf1; }
-        h1 = false;
+    // New FIFO = (carried entries, new leaf of child 0, new leaf of child 1), written as selects
+    // (no shift-then-push: every move is a v_cndmask).  The head (p0) was consumed above; b =
+    // old p1 and c = old p2 are carried.  When c is valid the node waited (go is false, no new
+    // leaves) and c takes the place of "leaf of child 1" in the formulas below.
+    {
+        const bool l0 = h0 && c0 < 0;
+        const bool wait = st.p2 >= 0;
+        const bool l1 = (h1 && c1 < 0) || wait;
+        h0 = h0 && c0 >= 0;
+        h1 = h1 && c1 >= 0;
+        const int32_t i1 = wait ? st.p2 : ~c1;
+        const float e1 = wait ? st.p2n : tn1, x1 = wait ? st.p2f : tf1;
+        const bool hb = st.p1 >= 0, two = l0 && l1;
+        const int32_t xi = l0 ? ~c0 : (l1 ? i1 : -1);      // first new entry
+        const float xe = l0 ? tn0 : e1, xx = l0 ? tf0 : x1;
+        st.p0 = hb ? st.p1 : xi;   st.p0n = hb ? st.p1n : xe;   st.p0f = hb ? st.p1f : xx;
+        st.p1 = hb ? xi : (two ? i1 : -1);   st.p1n = hb ? xe : e1;   st.p1f = hb ? xx : x1;
+        st.p2 = (hb && two) ? i1 : -1;   st.p2n = e1;   st.p2f = x1;
     }
 #else
     if (h0 && c0 < 0) { st.p0 = ~c0; st.p0n = tn0; st.p0f = tf0; h0 = false; }
     if (h1 && c1 < 0) { st.p1 = ~c1; st.p1n = tn1; st.p1f = tf1; h1 = false; }
 #endif
     if (go) {
-        if (h0 | h1) {
-            const bool both = h0 & h1;
-            const bool swap = both ? (tn1 < tn0) : h1;
+        if (h0 || h1) {
+            const bool both = h0 && h1;
+            const bool swap = (both && tn1 < tn0) || !h0;   // descend into c1?
             if (both) {
                 st.trail |= (W(1) << st.depth);
                 if (ring.base) {
