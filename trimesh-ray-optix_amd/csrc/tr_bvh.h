@@ -344,7 +344,10 @@ TR_HD void tr_fused_step(const tr_bvh_view& b, const tr_ray& r, tr_state_t<W>& s
     // one leaf test per trip: the head of the lane's FIFO (p0, p1, p2).  The node is visited
     // unless the FIFO is full (it then waits one trip: no fetch, no new leaves).
     const bool has_node = st.node >= 0 && st.p2 < 0;
-    const tr_f4* np = tr_node_ptr<COMPACT>(b, has_node ? st.node : 0);
+    // node index or 0, from the sign bits (a select here loses the SGPR-base + 32-bit-offset
+    // addressing of the four node loads)
+    const int32_t nidx = st.node & ~(st.node >> 31) & (st.p2 >> 31);
+    const tr_f4* np = tr_node_ptr<COMPACT>(b, nidx);
     const tr_f4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
     if (STATS && has_node) cnt->nodes++;
     bool fin = false;
