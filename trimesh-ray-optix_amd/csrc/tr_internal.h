@@ -36,6 +36,7 @@ struct tr_sched_slot {
     hipStream_t stream = nullptr;
     uint32_t* buf = nullptr;
     int64_t nblocks = 0;    // block count the current order was measured for (0 = none)
+    int64_t launches = 0;   // launches with this block count so far
     bool used = false;
 };
 

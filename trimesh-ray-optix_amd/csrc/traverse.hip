@@ -203,26 +203,42 @@ __global__ __launch_bounds__(BS) TR_WPE_ATTR void k_query_direct(tr_bvh_view b, 
 __global__ __launch_bounds__(1024) void k_sched_sort(uint32_t* __restrict__ cost,
                                                       uint32_t* __restrict__ order, int nblocks) {
     __shared__ uint32_t bins[256];
+    __shared__ uint32_t wsum[4];
     __shared__ uint32_t smax;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < 256) bins[tid] = 0;
     if (tid == 0) smax = 1;
     __syncthreads();
     uint32_t m = 0;
     for (int i = tid; i < nblocks; i += 1024) { const uint32_t c = cost[i]; m = c > m ? c : m; }
-    atomicMax(&smax, m);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { const uint32_t o = __shfl_xor(m, off); m = o > m ? o : m; }
+    if (lane == 0) atomicMax(&smax, m);
     __syncthreads();
-    const uint32_t mx = smax;
-    for (int i = tid; i < nblocks; i += 1024)
-        atomicAdd(&bins[255u - (uint32_t)(((unsigned long long)cost[i] * 255ull) / mx)], 1u);   // 0 = most expensive
+    // any monotone quantisation will do: level 0 = most expensive (costs are < 2^19 ticks)
+    const float scale = 255.0f / (float)smax;
+    for (int i = tid; i < nblocks; i += 1024) {
+        const uint32_t q = 255u - min(255u, (uint32_t)((float)cost[i] * scale));
+        atomicAdd(&bins[q], 1u);
+    }
     __syncthreads();
-    if (tid == 0) {   // exclusive scan of 256 bins
-        uint32_t run = 0;
-        for (int k = 0; k < 256; k++) { const uint32_t v = bins[k]; bins[k] = run; run += v; }
+    if (tid < 256) {   // exclusive scan of the 256 bins: wave scans + 4 wave totals
+        const uint32_t v = bins[tid];
+        uint32_t inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(inc, off); if (lane >= off) inc += o; }
+        if (lane == 63) wsum[wave] = inc;
+        bins[tid] = inc - v;
+    }
+    __syncthreads();
+    if (tid < 256) {
+        uint32_t pre = 0;
+        for (int w = 0; w < wave; w++) pre += wsum[w];
+        bins[tid] += pre;
     }
     __syncthreads();
     for (int i = tid; i < nblocks; i += 1024) {
-        const uint32_t q = 255u - (uint32_t)(((unsigned long long)cost[i] * 255ull) / mx);
+        const uint32_t q = 255u - min(255u, (uint32_t)((float)cost[i] * scale));
         order[atomicAdd(&bins[q], 1u)] = (uint32_t)i;
         cost[i] = 0u;
     }
@@ -655,9 +671,16 @@ void sched_acquire(const tr_bvh* bvh, hipStream_t stream, int64_t nblocks, const
             slot = &mb->sched[k];
         }
     if (!slot) return;
-    *cost = slot->buf;
-    if (slot->nblocks == nblocks) *order = slot->buf + TR_SCHED_MAX;
+    if (slot->nblocks == nblocks) {
+        *order = slot->buf + TR_SCHED_MAX;
+        slot->launches++;
+    } else {
+        slot->launches = 0;
+    }
     slot->nblocks = nblocks;   // the sort enqueued after the launch makes it valid for the next one
+    // measure + re-sort after each of the first launches of a batch size, then every 4th: the
+    // costs of a scene change slowly and the sort (8 us) is serial work behind every launch
+    if (slot->launches < 3 || (slot->launches & 3) == 3) *cost = slot->buf;
 }
 
 template <int Q, bool STATS>
