@@ -40,6 +40,18 @@ if stats:
         out["kernel_stats"].append({"name": short_name(r["Name"]), "calls": int(r["Calls"]),
                                     "avg_ns": float(r["AverageNs"]), "min_ns": int(r["MinNs"]),
                                     "max_ns": int(r["MaxNs"]), "pct": float(r["Percentage"])})
+# the timed region of bench.py = the LAST `steps` dispatches of the dominant kernel (the first
+# call runs without a learned launch order, then `warmup` untimed calls)
+trace = glob.glob(os.path.join(root, "trace", "*", "*_kernel_trace.csv"))
+if trace:
+    durs = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(trace[0]))
+            if kernel_key in r["Kernel_Name"]]
+    steps = int(os.environ.get("PROFILE_STEPS", "20"))
+    if len(durs) >= steps:
+        tail = durs[-steps:]
+        out["timed_region"] = {"kernel": kernel_key, "steps": steps, "avg_us": sum(tail) / len(tail) / 1e3,
+                               "min_us": min(tail) / 1e3, "max_us": max(tail) / 1e3,
+                               "first_call_us": durs[0] / 1e3}
 pmc = defaultdict(list)
 meta = {}
 for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
@@ -78,6 +90,11 @@ with open(os.path.join("profiles", f"{tag}_summary.md"), "w") as f:
     f.write("## kernel-trace --stats\n\n| kernel | calls | avg us | min us | max us | % |\n|---|---|---|---|---|---|\n")
     for k in out.get("kernel_stats", []):
         f.write(f"| `{k['name']}` | {k['calls']} | {k['avg_ns']/1e3:.1f} | {k['min_ns']/1e3:.1f} | {k['max_ns']/1e3:.1f} | {k['pct']:.2f} |\n")
+    if "timed_region" in out:
+        t = out["timed_region"]
+        f.write(f"\nTimed region (last {t['steps']} dispatches of `{t['kernel']}`, i.e. without the first call "
+                f"({t['first_call_us']:.1f} us, no learned launch order yet) and the warm-up): "
+                f"avg {t['avg_us']:.1f} us, min {t['min_us']:.1f}, max {t['max_us']:.1f}.\n")
     f.write(f"\n## PMC (separate passes), kernel filter `{kernel_key}`, averages per launch\n\nlaunch: {meta}\n\n| counter | value |\n|---|---|\n")
     for k, v in sorted(p.items()):
         f.write(f"| {k} | {v:.6g} |\n")

@@ -105,7 +105,7 @@ struct tr_options {
     int compact = 1;      // allow the 32-bit trail / 32-bit offset kernels when the BVH permits
     int refill_min = 16;
     int xcd_segments = 1;   // refill kernel: per-XCD work counters
-    int xcd_chunk = 256;    // direct kernel: blocks per XCD-local chunk (0 = identity map)
+    int xcd_chunk = 128;    // direct kernel: blocks per XCD-local chunk (0 = identity map)
     int build_cache = 1;  // keep the builder's temporaries (about 130 B/triangle) per device between builds
     int leaf_min = 0;     // refill kernel only: lanes with a queued leaf that fire its leaf phase (0 = any)
 };

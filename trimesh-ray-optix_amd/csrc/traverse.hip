@@ -201,14 +201,21 @@ __global__ __launch_bounds__(BS) TR_WPE_ATTR void k_query_direct(tr_bvh_view b, 
 // the order inside a level is arbitrary -- any permutation is a correct launch order).
 // Resets the cost array for the next measurement.
 __global__ __launch_bounds__(1024) void k_sched_sort(uint32_t* __restrict__ cost,
-                                                      uint32_t* __restrict__ order, int nblocks) {
-    __shared__ uint32_t bins[256];
-    __shared__ uint32_t wsum[4];
+                                                      uint32_t* __restrict__ order, int nblocks,
+                                                      int xcd_map) {
+    // list x: blocks whose home in the XCD-chunked map is XCD x (see k_query_direct; the blocks
+    // past the last whole span are dealt round-robin there, so their home is i % 8).  Launch
+    // slot j*8+x runs on XCD x, so list x fills the slots of XCD x in cost order: expensive
+    // blocks first AND every block stays on the XCD (L2) that its neighbours in the image use.
+    // |list x| = number of slots of XCD x because the whole spans are multiples of 8 blocks.
+    __shared__ uint32_t bins[8][256];
     __shared__ uint32_t smax;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < 256) bins[tid] = 0;
+    for (int k = tid; k < 8 * 256; k += 1024) (&bins[0][0])[k] = 0;
     if (tid == 0) smax = 1;
     __syncthreads();
+    const int T = xcd_map;
+    const int nfull = T > 0 ? nblocks / (8 * T) * (8 * T) : 0;
     uint32_t m = 0;
     for (int i = tid; i < nblocks; i += 1024) { const uint32_t c = cost[i]; m = c > m ? c : m; }
 #pragma unroll
@@ -219,27 +226,27 @@ __global__ __launch_bounds__(1024) void k_sched_sort(uint32_t* __restrict__ cost
     const float scale = 255.0f / (float)smax;
     for (int i = tid; i < nblocks; i += 1024) {
         const uint32_t q = 255u - min(255u, (uint32_t)((float)cost[i] * scale));
-        atomicAdd(&bins[q], 1u);
+        const int x = i < nfull ? (i / T) & 7 : i & 7;
+        atomicAdd(&bins[x][q], 1u);
     }
     __syncthreads();
-    if (tid < 256) {   // exclusive scan of the 256 bins: wave scans + 4 wave totals
-        const uint32_t v = bins[tid];
-        uint32_t inc = v;
+    if (wave < 8) {   // exclusive scan of list `wave`: 4 bins per lane
+        uint32_t v[4], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { v[k] = bins[wave][4 * lane + k]; sum += v[k]; }
+        uint32_t inc = sum;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(inc, off); if (lane >= off) inc += o; }
-        if (lane == 63) wsum[wave] = inc;
-        bins[tid] = inc - v;
-    }
-    __syncthreads();
-    if (tid < 256) {
-        uint32_t pre = 0;
-        for (int w = 0; w < wave; w++) pre += wsum[w];
-        bins[tid] += pre;
+        uint32_t run = inc - sum;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { bins[wave][4 * lane + k] = run; run += v[k]; }
     }
     __syncthreads();
     for (int i = tid; i < nblocks; i += 1024) {
         const uint32_t q = 255u - min(255u, (uint32_t)((float)cost[i] * scale));
-        order[atomicAdd(&bins[q], 1u)] = (uint32_t)i;
+        const int x = i < nfull ? (i / T) & 7 : i & 7;
+        const uint32_t j = atomicAdd(&bins[x][q], 1u);
+        order[j * 8u + (uint32_t)x] = (uint32_t)i;
         cost[i] = 0u;
     }
 }
@@ -728,7 +735,10 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
         const uint32_t* order = nullptr;
         uint32_t* cost = nullptr;
         if (!STATS) sched_acquire(bvh, stream, nblocks_direct, &order, &cost);
-        const int xc = opt.xcd_chunk * (256 / bs);   // chunk size is kept in rays
+        // chunk size of the XCD map: the option is in units of 256 rays; at least 4 chunks per
+        // XCD so that the XCDs' shares of an uneven image stay comparable
+        int xc = opt.xcd_chunk * (256 / bs);
+        while (xc > 0 && (int64_t)xc * 32 > nblocks_direct) xc >>= 1;
 #define TR_LAUNCH_DIRECT(C, B)                                                                          \
     hipLaunchKernelGGL((k_query_direct<Q, STATS, C, B>), dim3((unsigned)nblocks_direct), dim3(B), 0, stream, \
                        view, rf, out, xc, order, cost, d_stats)
@@ -738,7 +748,7 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
 #undef TR_LAUNCH_DIRECT
         if (cost)
             hipLaunchKernelGGL(k_sched_sort, dim3(1), dim3(1024), 0, stream, cost, cost + TR_SCHED_MAX,
-                               (int)nblocks_direct);
+                               (int)nblocks_direct, xc);
     }
     TR_HIP_TRY(hipGetLastError());
     return TR_OK;
@@ -854,7 +864,7 @@ int tr_intersects_count_topk(const tr_bvh* bvh, const tr_rays* rays, int32_t cap
     if (cap <= 8) hipLaunchKernelGGL(k_count_topk<8>, grid, block, 0, s, view, rf, cap, d_count, d_slots, xm, order, cost);
     else if (cap <= 16) hipLaunchKernelGGL(k_count_topk<16>, grid, block, 0, s, view, rf, cap, d_count, d_slots, xm, order, cost);
     else hipLaunchKernelGGL(k_count_topk<32>, grid, block, 0, s, view, rf, cap, d_count, d_slots, xm, order, cost);
-    if (cost) hipLaunchKernelGGL(k_sched_sort, dim3(1), dim3(1024), 0, s, cost, cost + TR_SCHED_MAX, (int)grid.x);
+    if (cost) hipLaunchKernelGGL(k_sched_sort, dim3(1), dim3(1024), 0, s, cost, cost + TR_SCHED_MAX, (int)grid.x, xm);
     TR_HIP_TRY(hipGetLastError());
     return TR_OK;
 }
