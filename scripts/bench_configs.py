@@ -33,6 +33,20 @@ def timeit(fn, reps=20, warm=4):
     return (time.perf_counter() - t0) / reps
 
 
+def timeit_median(fn, reps=9, warm=2):
+    """host-synchronous operations (build, refit): median of individually timed calls"""
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    return sorted(ts)[len(ts) // 2]
+
+
 def report(name, n, sec, **kw):
     print(json.dumps(dict(config=name, rays=n, ms=round(sec * 1e3, 4), mrays_per_s=round(n / sec / 1e6, 1), **kw)), flush=True)
 
@@ -61,12 +75,15 @@ t0 = time.perf_counter()
 r = RayMeshIntersector(vertices=T(v), faces=T(f))
 torch.cuda.synchronize()
 build_s = time.perf_counter() - t0
-report("C5 BVH build (incl. upload), headline mesh", len(f), build_s, note="units are triangles, not rays")
+report("C5 BVH first build (incl. host->device upload), headline mesh", len(f), build_s, note="units are triangles, not rays")
+vd, fd = r.mesh_vertices, r.mesh_faces
+report("C5 BVH rebuild (update_raw, mesh resident), headline mesh", len(f), timeit_median(lambda: r.update_raw(vd, fd)),
+       note="units are triangles")
 n = 100_000_000 // 8
 o5, d5 = W.hash_rays_torch(n, 99, v.min(0) * 1.5, v.max(0) * 1.5, device=dev)
 report("C5(ii) closest, one 12.5M-ray shard of the 100M hash rays, 1310720 tris", n,
        timeit(lambda: r.intersects_closest(o5, d5), reps=8), tris=len(f))
 v2 = W.displaced(v, seed=1, amplitude=0.05)
 vt = T(v2)
-report("refit of the headline mesh (same faces, new vertices)", len(f), timeit(lambda: r.refit(vt), reps=5, warm=1),
+report("refit of the headline mesh (same faces, new vertices)", len(f), timeit_median(lambda: r.refit(vt)),
        note="units are triangles")
