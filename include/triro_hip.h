@@ -170,7 +170,8 @@ int tr_trace_stats_closest(const tr_bvh *bvh, const tr_rays *rays, tr_trace_stat
  *    name = "adaptive" (0/1: learn the launch order from the previous launch), "compact",
  *    "xcd_chunk", "persistent" (0/1), "refill" (0/1), "refill_min" (1..64 idle lanes that
  *    trigger a refill), "blocks_per_cu" (int), "block_size" (64/128/256 threads of the direct
- *    kernel), "build_cache" (0/1: keep the builder's temporaries, about 130 B/triangle per
+ *    kernel), "scramble" (0/1: launches without a measured order visit each
+ *    XCD's blocks in a scrambled order), "build_cache" (0/1: keep the builder's temporaries, about 130 B/triangle per
  *    device, between builds so a rebuild costs no allocation; default 1).
  *    Returns TR_ERR_INVALID_ARG for unknown names.                                         */
 int tr_set_option(const char *name, int64_t value);

@@ -353,10 +353,28 @@ def test_launch_shapes_agree(device):
         b = r.intersects_closest(ot, dt)
         cb = r.intersects_count(ot, dt)
     finally:
-        hops.set_option("persistent", 1)
+        hops.set_option("persistent", 0)
     for x, y in zip(a, b):
         assert torch.equal(x, y)
     assert torch.equal(ca, cb)
+    # every launch-shape knob of the direct kernel is a pure scheduling choice
+    defaults = {"adaptive": 1, "scramble": 1, "block_size": 128, "xcd_chunk": 128, "compact": 1}
+    try:
+        for name, values in (("adaptive", (0,)), ("scramble", (0,)), ("block_size", (64, 256)),
+                             ("xcd_chunk", (0, 48, 1024)), ("compact", (0,))):
+            for val in values:
+                hops.set_option(name, val)
+                if name == "scramble":
+                    hops.set_option("adaptive", 0)        # the scrambled order is the one without hints
+                for _ in range(2):                        # second call runs on the learned order
+                    c = r.intersects_closest(ot, dt)
+                    for x, y in zip(c, b):
+                        assert torch.equal(x, y), (name, val)
+                hops.set_option(name, defaults[name])
+                hops.set_option("adaptive", 1)
+    finally:
+        for name, val in defaults.items():
+            hops.set_option(name, val)
     # size-independent properties at full size (10M-ray class inputs are covered in bench.py)
     hit, front, tri, loc, uv = a
     assert torch.equal(hit, tri >= 0) and torch.equal(hit, ca > 0)

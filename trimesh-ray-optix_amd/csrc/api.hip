@@ -306,6 +306,7 @@ int tr_set_option(const char* name, int64_t value) {
     }
     if (!strcmp(name, "refill")) { g_options.refill = value != 0; return TR_OK; }
     if (!strcmp(name, "adaptive")) { g_options.adaptive = value != 0; return TR_OK; }
+    if (!strcmp(name, "scramble")) { g_options.scramble = value != 0; return TR_OK; }
     if (!strcmp(name, "build_cache")) { g_options.build_cache = value != 0; return TR_OK; }
     if (!strcmp(name, "block_size")) {
         if (value != 64 && value != 128 && value != 256) return tr_fail(TR_ERR_INVALID_ARG, "block_size must be 64, 128 or 256");

@@ -106,6 +106,7 @@ struct tr_options {
     int refill_min = 16;
     int xcd_segments = 1;   // refill kernel: per-XCD work counters
     int xcd_chunk = 128;    // direct kernel: blocks per XCD-local chunk (0 = identity map)
+    int scramble = 1;     // launches without a measured order visit each XCD's blocks in a scrambled order
     int build_cache = 1;  // keep the builder's temporaries (about 130 B/triangle) per device between builds
     int leaf_min = 0;     // refill kernel only: lanes with a queued leaf that fire its leaf phase (0 = any)
 };

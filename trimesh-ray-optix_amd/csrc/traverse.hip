@@ -163,7 +163,7 @@ template <int Q, bool STATS, bool COMPACT, int BS>
 #define TR_WPE_ATTR
 #endif
 __global__ __launch_bounds__(BS) TR_WPE_ATTR void k_query_direct(tr_bvh_view b, RayFetch rf, QueryOut out,
-                                                      int xcd_map,
+                                                      int xcd_map, int scramble,
                                                       const uint32_t* __restrict__ order,
                                                       uint32_t* __restrict__ cost,
                                                       unsigned long long* stats) {
@@ -182,7 +182,12 @@ __global__ __launch_bounds__(BS) TR_WPE_ATTR void k_query_direct(tr_bvh_view b, 
         const int64_t T = xcd_map, span = 8 * T;
         const int64_t nfull = (int64_t)gridDim.x / span * span;   // blocks covered by whole spans
         if (blk < nfull) {
-            const int64_t x = blk & 7, k = blk >> 3;              // XCD label, index within it
+            const int64_t x = blk & 7;                            // XCD label
+            int64_t k = blk >> 3;                                 // index within the XCD
+            // no measured order yet: visit the XCD's blocks in a scrambled order (k -> k*P mod
+            // count, P prime) so that an expensive image region is spread over the whole
+            // launch instead of being started last
+            if (scramble > 1) k = (k * scramble) % (nfull >> 3);
             blk = ((k / T) * 8 + x) * T + (k % T);
         }
     }
@@ -739,9 +744,15 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
         // XCD so that the XCDs' shares of an uneven image stay comparable
         int xc = opt.xcd_chunk * (256 / bs);
         while (xc > 0 && (int64_t)xc * 32 > nblocks_direct) xc >>= 1;
+        int scramble = 0;
+        if (xc > 0 && opt.scramble) {
+            const int64_t cnt = nblocks_direct / (8 * (int64_t)xc) * xc;   // blocks per XCD in whole spans
+            for (int p : {7919, 7907, 7901})
+                if (cnt > 1 && cnt % p != 0) { scramble = p; break; }
+        }
 #define TR_LAUNCH_DIRECT(C, B)                                                                          \
     hipLaunchKernelGGL((k_query_direct<Q, STATS, C, B>), dim3((unsigned)nblocks_direct), dim3(B), 0, stream, \
-                       view, rf, out, xc, order, cost, d_stats)
+                       view, rf, out, xc, scramble, order, cost, d_stats)
         if (bs == 64) { if (compact) TR_LAUNCH_DIRECT(true, 64); else TR_LAUNCH_DIRECT(false, 64); }
         else if (bs == 128) { if (compact) TR_LAUNCH_DIRECT(true, 128); else TR_LAUNCH_DIRECT(false, 128); }
         else { if (compact) TR_LAUNCH_DIRECT(true, 256); else TR_LAUNCH_DIRECT(false, 256); }
