@@ -1,12 +1,15 @@
 // traverse.hip -- query kernels and their C-ABI launchers (replace the five OptiX pipelines
 // of triro/backend/shaders.cu:67-246 and the launch wrappers of ray.cpp:161-378).
 //
-// One ray per lane, wave64.  Two launch shapes:
+// One ray per lane, wave64; the per-ray state machine is tr_fused_step (tr_bvh.h): stackless
+// trail + LDS far-child ring, one node visit and one queued leaf test per trip.  Launch shapes:
+//   direct     : grid = ceil(n/BS) workgroups of BS = 64/128/256 rays (default, k_query_direct).
+//                Which ray block a workgroup takes is a scheduling choice: the measured
+//                per-XCD cost order of the previous launch (k_sched_sort), else the
+//                XCD-chunked, scrambled static map.
 //   persistent : grid = CUs x blocks_per_cu; each wave pulls 64-ray batches from a global
-//                work counter (Aila & Laine style persistent threads) -- no tail of
-//                half-empty workgroups, and the counter ring lets launches overlap.
-//   direct     : grid = ceil(n/256), ray = global thread id.
-// The per-ray state machine is tr_node_step / tr_leaf_step (tr_bvh.h): stackless trail + ring.
+//                work counter (option, not faster at the measured sizes); `refill` adds
+//                per-lane refill ("active-ray repacking", experimental, slower).
 // Kernel parameters travel by value (no per-call malloc/memcpy/free as in ray.cpp:279-287).
 #include "tr_internal.h"
 
@@ -157,12 +160,7 @@ __device__ __forceinline__ void flush_stats(const tr_counters& c, unsigned long 
 }
 
 template <int Q, bool STATS, bool COMPACT, int BS>
-#ifdef TR_WPE
-#define TR_WPE_ATTR __attribute__((amdgpu_waves_per_eu(TR_WPE)))
-#else
-#define TR_WPE_ATTR
-#endif
-__global__ __launch_bounds__(BS) TR_WPE_ATTR void k_query_direct(tr_bvh_view b, RayFetch rf, QueryOut out,
+__global__ __launch_bounds__(BS) void k_query_direct(tr_bvh_view b, RayFetch rf, QueryOut out,
                                                       int xcd_map, int scramble,
                                                       const uint32_t* __restrict__ order,
                                                       uint32_t* __restrict__ cost,
