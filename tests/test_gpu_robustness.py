@@ -105,3 +105,56 @@ def test_axis_aligned_everything(device):
     n1 = len(o)
     inside = (o[:, 0] >= 0) & (o[:, 0] <= 6) & (o[:, 1] >= 0) & (o[:, 1] <= 6)
     assert np.array_equal(hit[:n1], inside)                      # boundary lines included on all four sides
+
+
+def test_concurrent_streams_and_threads_share_one_handle(device):
+    """Many host threads, each on its own stream, query ONE handle with different batch sizes while
+    the launch-order hints (per handle, per stream; 8 slots) are learned and re-sorted.  More
+    streams than slots on purpose: the extra ones run without hints.  Every result must equal the
+    single-stream answer; hints are scheduling only."""
+    import threading
+    from triro.ray.ray_optix import RayMeshIntersector
+    v, f = W.bunny_standin()
+    r = RayMeshIntersector(vertices=T(v, device), faces=T(f, device))
+    o, d = W.hash_rays(400_000, 31, v.min(0) * 1.4, v.max(0) * 1.4)
+    ot, dt = T(o, device), T(d, device)
+    ref = [x.clone() for x in r.intersects_closest(ot, dt)]
+    cnt_ref = r.intersects_count(ot, dt).clone()
+    loc_ref = {}
+    torch.cuda.synchronize()
+    sizes = [400_000, 131_072, 65_537, 300_001, 8_193, 200_000, 99_999, 262_144, 50_000, 399_999, 77_777, 16_384]
+    errors = []
+    for n in set(sizes):    # multi-hit answers (scan + fill) per size, computed alone
+        loc_ref[n] = [x.clone() for x in r.intersects_location(ot[:n], dt[:n])]
+    torch.cuda.synchronize()
+
+    def worker(k):
+        try:
+            s = torch.cuda.Stream(device=device)
+            n = sizes[k]
+            with torch.cuda.stream(s):
+                for it in range(12):
+                    out = r.intersects_closest(ot[:n], dt[:n])
+                    if it % 4 == 3:
+                        c = r.intersects_count(ot[:n], dt[:n])
+                        s.synchronize()
+                        if not torch.equal(c, cnt_ref[:n]):
+                            errors.append((k, it, "count"))
+                        got = r.intersects_location(ot[:n], dt[:n])     # scans on this stream
+                        s.synchronize()
+                        if not all(torch.equal(x, y) for x, y in zip(got, loc_ref[n])):
+                            errors.append((k, it, "location"))
+                    s.synchronize()
+                    for x, y in zip(out, ref):
+                        if not torch.equal(x, y[:n]):
+                            errors.append((k, it, "closest"))
+                            return
+        except Exception as e:   # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(len(sizes))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]

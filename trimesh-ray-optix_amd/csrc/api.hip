@@ -1,7 +1,7 @@
 // api.hip -- runtime bring-up, error reporting and acceleration-structure entry points of the
 // C ABI (include/triro_hip.h).  Replaces triro/backend/base.cpp (global OptiX context, module,
 // pipelines, SBTs: base.cpp:15-157) -- none of those concepts survive; what remains is a
-// per-device table {CU count, work-counter ring, scan scratch} created on first use.
+// per-device table {CU count, work-counter ring, builder temporaries} created on first use.
 #include <mutex>
 #include <string.h>
 
@@ -58,20 +58,6 @@ int tr_get_device_state(int device, tr_device_state** out) {
         st.ready = true;
     }
     *out = &st;
-    return TR_OK;
-}
-
-int tr_scratch_reserve(tr_device_state* st, size_t bytes, void** out) {
-    std::lock_guard<std::mutex> lock(g_mutex);
-    if (st->scratch_bytes < bytes) {
-        DeviceGuard g;
-        if (g.enter(st->device) != TR_OK) return tr_fail(TR_ERR_NO_DEVICE, "hipSetDevice failed");
-        if (st->scratch) { TR_HIP_TRY(hipFree(st->scratch)); st->scratch = nullptr; st->scratch_bytes = 0; }
-        size_t want = bytes < (1u << 20) ? (1u << 20) : bytes * 2;
-        TR_HIP_TRY(hipMalloc(&st->scratch, want));
-        st->scratch_bytes = want;
-    }
-    *out = st->scratch;
     return TR_OK;
 }
 

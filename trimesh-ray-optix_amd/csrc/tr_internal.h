@@ -70,8 +70,6 @@ struct tr_device_state {
     int num_cus = 0;
     int* counters = nullptr;        // ring of work counters for persistent launches
     unsigned next_counter = 0;
-    void* scratch = nullptr;        // scan partials etc.
-    size_t scratch_bytes = 0;
     // builder temporaries (sort buffers, boxes, hierarchy), kept between builds so that a
     // rebuild (`update_raw`) costs no hipMalloc/hipFree.  One build per device at a time.
     void* build_temp = nullptr;
@@ -81,7 +79,6 @@ struct tr_device_state {
 constexpr int TR_NUM_COUNTERS = 4096;
 
 int tr_get_device_state(int device, tr_device_state** out);
-int tr_scratch_reserve(tr_device_state* st, size_t bytes, void** out);
 // returns with st->build_mutex HELD on success; tr_build_temp_release unlocks (and frees the
 // buffer when option build_cache == 0).  The caller must have drained its stream by then.
 int tr_build_temp_acquire(tr_device_state* st, size_t bytes, void** out);

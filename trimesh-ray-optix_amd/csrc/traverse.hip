@@ -777,13 +777,27 @@ int scan_impl(const T* d_in, int64_t n, int32_t cap, int64_t* d_offsets, int64_t
         TR_HIP_TRY(hipMemsetAsync(d_total, 0, sizeof(int64_t), stream));
     } else {
         int64_t nblocks = (n + SCAN_TILE - 1) / SCAN_TILE;
-        void* scratch;
-        TR_TRY(tr_scratch_reserve(st, sizeof(int64_t) * (size_t)nblocks, &scratch));
-        int64_t* partial = (int64_t*)scratch;
+        // block partials: a stream-ordered allocation, so scans enqueued on different streams
+        // (or from different host threads) never share scratch and nothing synchronises
+        int64_t* partial = nullptr;
+        const size_t bytes = sizeof(int64_t) * (size_t)nblocks;
+        bool pooled = hipMallocAsync((void**)&partial, bytes, stream) == hipSuccess;
+        if (!pooled) {
+            (void)hipGetLastError();
+            TR_HIP_TRY(hipMalloc((void**)&partial, bytes));
+        }
         hipLaunchKernelGGL((k_scan_partial<T>), dim3((unsigned)nblocks), dim3(SCAN_BLOCK), 0, stream, d_in, n, cap, partial);
         hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(SCAN_BLOCK), 0, stream, partial, nblocks, d_total);
         hipLaunchKernelGGL((k_scan_final<T>), dim3((unsigned)nblocks), dim3(SCAN_BLOCK), 0, stream, d_in, n, cap, partial, d_offsets);
-        TR_HIP_TRY(hipGetLastError());
+        hipError_t le = hipGetLastError();
+        if (pooled) {
+            hipError_t fe = hipFreeAsync(partial, stream);
+            if (le == hipSuccess) le = fe;
+        } else {
+            (void)hipStreamSynchronize(stream);   // no stream-ordered allocator: free after the work
+            (void)hipFree(partial);
+        }
+        TR_HIP_TRY(le);
     }
     if (h_total) {
         TR_HIP_TRY(hipMemcpyAsync(h_total, d_total, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
