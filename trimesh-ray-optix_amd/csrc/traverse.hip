@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256) void k_location(tr_bvh_view b, RayFetch rf, in
 // ---- fused multi-hit: ONE traversal yields the (uncapped) count and the slots of the `cap`
 // nearest hits; the fill pass then needs no traversal at all (the reference -- and the
 // tr_intersects_count + tr_intersects_location_fill pair -- traverse twice).
-template <int K>
+template <int K, bool COMPACT>
 __global__ __launch_bounds__(256) void k_count_topk(tr_bvh_view b, RayFetch rf, int32_t cap,
                                                     int32_t* __restrict__ count,
                                                     int32_t* __restrict__ slots, int xcd_map,
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256) void k_count_topk(tr_bvh_view b, RayFetch rf, 
     tr_topk<K> top;
     tr_counters* nc = nullptr;
     if (b.num_tris >= 2) {
-        wave_traverse<TR_Q_LOCATION, K, false>(b, r, valid, res, top, nc, ring);
+        wave_traverse<TR_Q_LOCATION, K, false, COMPACT>(b, r, valid, res, top, nc, ring);
     } else {
         top.init();
         brute_one<TR_Q_LOCATION>(b, r, valid, res);
@@ -884,9 +884,13 @@ int tr_intersects_count_topk(const tr_bvh* bvh, const tr_rays* rays, int32_t cap
     const uint32_t* order = nullptr;
     uint32_t* cost = nullptr;
     sched_acquire(bvh, s, (int64_t)grid.x, &order, &cost);
-    if (cap <= 8) hipLaunchKernelGGL(k_count_topk<8>, grid, block, 0, s, view, rf, cap, d_count, d_slots, xm, order, cost);
-    else if (cap <= 16) hipLaunchKernelGGL(k_count_topk<16>, grid, block, 0, s, view, rf, cap, d_count, d_slots, xm, order, cost);
-    else hipLaunchKernelGGL(k_count_topk<32>, grid, block, 0, s, view, rf, cap, d_count, d_slots, xm, order, cost);
+    const bool compact = tr_opts().compact && bvh->depth <= 32 &&
+                         bvh->num_nodes * (int64_t)sizeof(tr_node) < ((int64_t)1 << 32) &&
+                         bvh->num_tris * (int64_t)sizeof(tr_tri) < ((int64_t)1 << 32);
+    if (cap <= 8 && compact) hipLaunchKernelGGL((k_count_topk<8, true>), grid, block, 0, s, view, rf, cap, d_count, d_slots, xm, order, cost);
+    else if (cap <= 8) hipLaunchKernelGGL((k_count_topk<8, false>), grid, block, 0, s, view, rf, cap, d_count, d_slots, xm, order, cost);
+    else if (cap <= 16) hipLaunchKernelGGL((k_count_topk<16, false>), grid, block, 0, s, view, rf, cap, d_count, d_slots, xm, order, cost);
+    else hipLaunchKernelGGL((k_count_topk<32, false>), grid, block, 0, s, view, rf, cap, d_count, d_slots, xm, order, cost);
     if (cost) hipLaunchKernelGGL(k_sched_sort, dim3(1), dim3(1024), 0, s, cost, cost + TR_SCHED_MAX, (int)grid.x, xm);
     TR_HIP_TRY(hipGetLastError());
     return TR_OK;
