@@ -33,8 +33,8 @@ BYTES_PER_RAY_CLOSEST = 50      # 24 B in + 26 B out
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--subdiv", type=int, default=8, help="icosphere subdivisions (8 = 1 310 720 tris)")
     ap.add_argument("--res", type=int, default=1024, help="ray grid is res x res")
     ap.add_argument("--rays", choices=["pinhole", "hash"], default="pinhole")
@@ -173,6 +173,9 @@ def main():
         out = step()
     barrier()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    import gc
+    gc.collect()
+    gc.disable()            # a step is ~0.3 ms: keep collector pauses out of the timed region
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record()
@@ -180,6 +183,7 @@ def main():
         ev[k][1].record()
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
     if os.environ.get("TRIRO_BENCH_TRACE") and rank == 0:   # per-step durations, launch order
         print("per-step ms:", " ".join(f"{x:.3f}" for x in kernel_ms), file=sys.stderr)
