@@ -390,6 +390,40 @@ def test_launch_shapes_agree(device):
     assert stats["rays"] == 100000 and stats["node_visits"] > 0
 
 
+def test_tile_mapping_is_a_pure_permutation(device):
+    """Image-shaped batches may be traced in 8x8 pixel tiles per wave (option tile; automatic from
+    4 M rays on).  Outputs are written at the true flat index: forced on (2) == off (0) for
+    [H,W,3], [B,H,W,3], a broadcast origin, strided directions, and sizes where it must not engage."""
+    import triro.backend.ops as hops
+    v, f = W.bunny_standin()
+    r = make(v, f, device)
+    o, d = W.pinhole_grid(200, 136)                      # [H=136, W=200, 3]: W % 8 == 0, H % 8 == 0
+    ot, dt = T(o, device), T(d, device)
+    H, Wd = ot.shape[:2]
+    assert Wd % 8 == 0 and H % 8 == 0
+    cases = {
+        "HW": (ot, dt),
+        "BHW": (torch.stack([ot, ot * 1.01]), torch.stack([dt, dt])),
+        "broadcast origin": (ot[:1, :1].expand(H, Wd, 3), dt),
+        "strided dirs": (ot, torch.stack([dt, dt], dim=2)[:, :, 1]),
+        "W not multiple of 8": (ot[:, :Wd - 3], dt[:, :Wd - 3]),
+        "odd row count": (ot[:H - 3], dt[:H - 3]),
+    }
+    try:
+        for name, (oo, dd) in cases.items():
+            hops.set_option("tile", 0)
+            ref = r.intersects_closest(oo, dd)
+            cref = r.intersects_count(oo, dd)
+            hops.set_option("tile", 2)
+            for _ in range(2):
+                got = r.intersects_closest(oo, dd)
+                for x, y in zip(got, ref):
+                    assert torch.equal(x, y), name
+            assert torch.equal(r.intersects_count(oo, dd), cref), name
+    finally:
+        hops.set_option("tile", 1)
+
+
 def test_adaptive_launch_order_never_changes_results(device):
     """the launch order learned from the previous launch (per handle and stream) is a pure
     scheduling hint: repeated calls, other batch sizes, other streams and a rebuild in between

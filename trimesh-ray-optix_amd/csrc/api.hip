@@ -292,6 +292,10 @@ int tr_set_option(const char* name, int64_t value) {
     }
     if (!strcmp(name, "refill")) { g_options.refill = value != 0; return TR_OK; }
     if (!strcmp(name, "adaptive")) { g_options.adaptive = value != 0; return TR_OK; }
+    if (!strcmp(name, "tile")) {
+        if (value < 0 || value > 2) return tr_fail(TR_ERR_INVALID_ARG, "tile must be 0, 1 or 2");
+        g_options.tile = (int)value; return TR_OK;
+    }
     if (!strcmp(name, "scramble")) { g_options.scramble = value != 0; return TR_OK; }
     if (!strcmp(name, "build_cache")) { g_options.build_cache = value != 0; return TR_OK; }
     if (!strcmp(name, "block_size")) {
