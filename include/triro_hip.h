@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define TR_ABI_VERSION 1
+#define TR_ABI_VERSION 2
 #define TR_MAX_ANYHIT_SIZE 8 /* LaunchParams.h:8  (per-ray cap of intersects_location) */
 #define TR_MAX_SIZE_LENGTH 4 /* LaunchParams.h:9  (ray tensors have <= 4 dims)         */
 #define TR_MAX_HITS_CAP 32   /* largest `cap` tr_intersects_location_fill accepts      */
@@ -140,14 +140,20 @@ int tr_intersects_location_fill(const tr_bvh *bvh, const tr_rays *rays, int32_t 
                                 int32_t *d_tri_idx, int64_t ray_base, void *stream);
 
 /*    Fused variant (one traversal instead of two): tr_intersects_count_topk writes the uncapped
- *    count AND, for each ray, the arena slots of its `cap` nearest hits (d_slots: [n, cap]
- *    int32, -1 = none); after tr_hits_scan, tr_location_fill_slots produces exactly what
- *    tr_intersects_location_fill produces, without traversing again.                      */
+ *    count AND, for each ray, its `cap` nearest hits as UNSORTED entries {t_key, arena slot}
+ *    (d_hits: [n, cap] tr_hit_entry = 8 bytes each; the first min(count, cap) of a ray are
+ *    valid); after tr_hits_scan, tr_location_fill_slots ranks them by (distance, triangle
+ *    index) and produces exactly what tr_intersects_location_fill produces, without
+ *    traversing again.                                                                      */
+typedef struct tr_hit_entry {
+    float t_key;
+    int32_t slot;
+} tr_hit_entry;
 int tr_intersects_count_topk(const tr_bvh *bvh, const tr_rays *rays, int32_t cap,
-                             int32_t *d_count, int32_t *d_slots, void *stream);
+                             int32_t *d_count, tr_hit_entry *d_hits, void *stream);
 int tr_location_fill_slots(const tr_bvh *bvh, const tr_rays *rays, int32_t cap,
                            const int32_t *d_count, const int64_t *d_offsets,
-                           const int32_t *d_slots, float *d_loc, int32_t *d_ray_idx,
+                           const tr_hit_entry *d_hits, float *d_loc, int32_t *d_ray_idx,
                            int32_t *d_tri_idx, int64_t ray_base, void *stream);
 
 /* -- stream compaction of closest-hit results (ray_optix.py:142-144, 219-223): keeps the

@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
     for s in header_symbols():
         assert hasattr(lib, s), f"{s} declared in include/triro_hip.h but not exported"
     assert set(hops.ABI) == set(header_symbols())
-    assert hops.get_module().tr_abi_version() == 1
+    assert hops.get_module().tr_abi_version() == 2
 
 
 def test_struct_layout_matches_header():

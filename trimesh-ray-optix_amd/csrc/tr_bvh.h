@@ -21,6 +21,7 @@
 // Szirmay-Kalos 2014 style backtracking).  The builder guarantees depth <= 64.
 #pragma once
 #include "tr_math.h"
+#include "../../include/triro_hip.h"   // tr_hit_entry
 
 // Leaf schedule of the fused trip.  1: ONE leaf test per trip out of a 3-slot per-lane FIFO (a
 // node visit can add two leaves while one is consumed; the node waits only when the FIFO is
@@ -95,6 +96,39 @@ struct tr_topk {
             t[i] = lt ? nt : tt; face[i] = lt ? nface : tf_; slot[i] = lt ? nslot : ts;
             nt = lt ? tt : nt; nface = lt ? tf_ : nface; nslot = lt ? ts : nslot;
         }
+    }
+};
+
+// K = 0: the multi-hit list lives in memory, unsorted (tr_intersects_count_topk).  A lane carries
+// a pointer and a fill count instead of 3*K registers of sorted (t, face, slot): the K = 8
+// kernel needed 92 VGPRs (5 waves/SIMD) and ran a 32-select insertion for the whole wave on
+// almost every leaf trip.  Appending is one 8-byte store; a ray with more than `cap` hits
+// replaces its farthest stored hit when the new one is closer (rare path: loads).  The fill
+// pass ranks the <= cap entries of a ray by (t_key, face) -- same final order as the sorted list.
+static_assert(sizeof(tr_hit_entry) == 8, "hit entries are 8 bytes (include/triro_hip.h)");
+template <>
+struct tr_topk<0> {
+    tr_hit_entry* ent;    // this ray's `cap` entries (set by the kernel, not by init())
+    const tr_tri* tris;   // faces for tie-breaks
+    int32_t cap, n;
+    TR_HDM void init() { n = 0; }
+    TR_HDM void insert(float nt, int32_t nface, int32_t nslot) {
+        if (n < cap) {
+            ent[n].t_key = nt; ent[n].slot = nslot;
+            n++;
+            return;
+        }
+        // more than `cap` hits: keep the `cap` nearest by (t_key, face)
+        int32_t mi = 0;
+        float mt = ent[0].t_key;
+        int32_t mf = tris[ent[0].slot].face;
+        for (int32_t j = 1; j < cap; j++) {
+            const float tj = ent[j].t_key;
+            if (tj < mt) continue;
+            const int32_t fj = tris[ent[j].slot].face;
+            if (tj > mt || fj > mf) { mi = j; mt = tj; mf = fj; }
+        }
+        if (tr_closer(nt, nface, mt, mf)) { ent[mi].t_key = nt; ent[mi].slot = nslot; }
     }
 };
 

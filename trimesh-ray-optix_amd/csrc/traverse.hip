@@ -31,6 +31,8 @@ struct QueryOut {
     float* loc;
     float* uv;
     int32_t* count;
+    tr_hit_entry* hits;   // TR_Q_LOCATION: [n, cap] unsorted nearest hits (tr_topk<0>)
+    int32_t cap;
 };
 
 // strided fetch of ray `idx`: the reference's getRay/getIndices (shaders.cu:27-63) with
@@ -66,7 +68,7 @@ __device__ __forceinline__ void write_result(const tr_bvh_view& b, const QueryOu
         out.hit[i] = res.best_face >= 0 ? 1 : 0;
     } else if (Q == TR_Q_FIRST) {
         out.tri[i] = res.best_face;
-    } else if (Q == TR_Q_COUNT) {
+    } else if (Q == TR_Q_COUNT || Q == TR_Q_LOCATION) {
         out.count[i] = res.count;
     } else if (Q == TR_Q_CLOSEST) {
         float loc[3] = {0.f, 0.f, 0.f}, uv[2] = {0.f, 0.f};
@@ -140,9 +142,24 @@ __device__ __forceinline__ void process_ray(const tr_bvh_view& b, const RayFetch
     tr_ray r;
     const bool valid = tr_ray_setup(r, o[0], o[1], o[2], d[0], d[1], d[2]) && in_range;
     tr_result res;
-    tr_topk<1> top;
-    if (b.num_tris >= 2) wave_traverse<Q, 1, STATS, COMPACT>(b, r, valid, res, top, cnt, ring);
-    else brute_one<Q>(b, r, valid, res);
+    if (Q == TR_Q_LOCATION) {
+        // fused multi-hit: uncapped count + the ray's `cap` nearest hits as unsorted entries
+        tr_topk<0> top;
+        top.ent = out.hits + (in_range ? i : 0) * out.cap;
+        top.tris = b.tris;
+        top.cap = out.cap;
+        if (b.num_tris >= 2) {
+            wave_traverse<Q, 0, STATS, COMPACT>(b, r, valid, res, top, cnt, ring);
+        } else {
+            top.init();
+            brute_one<Q>(b, r, valid, res);
+            if (res.count) top.insert(res.best_t, res.best_face, 0);
+        }
+    } else {
+        tr_topk<1> top;
+        if (b.num_tris >= 2) wave_traverse<Q, 1, STATS, COMPACT>(b, r, valid, res, top, cnt, ring);
+        else brute_one<Q>(b, r, valid, res);
+    }
     if (in_range) write_result<Q>(b, out, i, r, res);
 }
 
@@ -434,83 +451,43 @@ __global__ __launch_bounds__(256) void k_location(tr_bvh_view b, RayFetch rf, in
     }
 }
 
-// ---- fused multi-hit: ONE traversal yields the (uncapped) count and the slots of the `cap`
-// nearest hits; the fill pass then needs no traversal at all (the reference -- and the
-// tr_intersects_count + tr_intersects_location_fill pair -- traverse twice).
-template <int K, bool COMPACT>
-__global__ __launch_bounds__(256) void k_count_topk(tr_bvh_view b, RayFetch rf, int32_t cap,
-                                                    int32_t* __restrict__ count,
-                                                    int32_t* __restrict__ slots, int xcd_map,
-                                                    const uint32_t* __restrict__ order,
-                                                    uint32_t* __restrict__ cost) {
-    __shared__ int32_t ring_lds[TR_RING * 256];
-    const tr_ring ring = {ring_lds + threadIdx.x, 256};
-    const unsigned long long t_start = cost ? wall_clock64() : 0ull;
-    int64_t blk = blockIdx.x;
-    if (order) {
-        blk = order[blockIdx.x];
-    } else if (xcd_map > 0) {
-        const int64_t T = xcd_map, span = 8 * T;
-        const int64_t nfull = (int64_t)gridDim.x / span * span;
-        if (blk < nfull) {
-            const int64_t x = blk & 7, k = blk >> 3;
-            blk = ((k / T) * 8 + x) * T + (k % T);
-        }
-    }
-    const int64_t i = blk * 256 + threadIdx.x;
-    const bool in_range = i < rf.n;
-    float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
-    if (in_range) fetch_ray(rf, i, o, d);
-    tr_ray r;
-    const bool valid = tr_ray_setup(r, o[0], o[1], o[2], d[0], d[1], d[2]) && in_range;
-    tr_result res;
-    tr_topk<K> top;
-    tr_counters* nc = nullptr;
-    if (b.num_tris >= 2) {
-        wave_traverse<TR_Q_LOCATION, K, false, COMPACT>(b, r, valid, res, top, nc, ring);
-    } else {
-        top.init();
-        brute_one<TR_Q_LOCATION>(b, r, valid, res);
-        if (res.count) top.insert(res.best_t, res.best_face, 0);
-    }
-    if (in_range) {
-        count[i] = res.count;
-        int32_t* s = slots + i * cap;
-#pragma unroll
-        for (int k = 0; k < K; k++)
-            if (k < cap) s[k] = k < res.count ? top.slot[k] : -1;
-    }
-    if (cost && (threadIdx.x & 63) == 0) {
-        const unsigned long long dt = wall_clock64() - t_start;
-        atomicMax(&cost[blk], (uint32_t)(dt > 0x7ffffull ? 0x7ffffull : dt));
-    }
-}
-
-// one thread per (ray, k): re-evaluate the kept triangle (same arithmetic, same values)
-__global__ __launch_bounds__(256) void k_fill_slots(tr_bvh_view b, RayFetch rf, int32_t cap,
-                                                    const int32_t* __restrict__ count,
-                                                    const int64_t* __restrict__ offsets,
-                                                    const int32_t* __restrict__ slots,
-                                                    float* __restrict__ loc,
-                                                    int32_t* __restrict__ ray_idx,
-                                                    int32_t* __restrict__ tri_idx, int64_t ray_base) {
+// ---- fused multi-hit (memory-resident hit list, tr_topk<0>): the traversal is
+// k_query_direct<TR_Q_LOCATION>; k_fill_list ranks each ray's entries and writes the rows.
+// one thread per (ray, k): rank entry k among the ray's stored entries by (t_key, face), then
+// re-evaluate its triangle (same arithmetic, same values) and write row offsets[i] + rank
+__global__ __launch_bounds__(256) void k_fill_list(tr_bvh_view b, RayFetch rf, int32_t cap,
+                                                   const int32_t* __restrict__ count,
+                                                   const int64_t* __restrict__ offsets,
+                                                   const tr_hit_entry* __restrict__ entries,
+                                                   float* __restrict__ loc,
+                                                   int32_t* __restrict__ ray_idx,
+                                                   int32_t* __restrict__ tri_idx, int64_t ray_base) {
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t i = g / cap;
     const int32_t k = (int32_t)(g - i * cap);
     if (i >= rf.n) return;
     const int32_t c = count[i];
-    if (k >= (c < cap ? c : cap)) return;
+    const int32_t ns = c < cap ? c : cap;
+    if (k >= ns) return;
+    const tr_hit_entry* e = entries + i * cap;
+    const tr_hit_entry me = e[k];
+    tr_counters* nc = nullptr;
+    const tr_tri t = tr_load_tri<false>(b, me.slot, nc);
+    int32_t rank = 0;
+    for (int32_t j = 0; j < ns; j++) {
+        if (j == k) continue;
+        const tr_hit_entry ej = e[j];
+        if (ej.t_key < me.t_key || (ej.t_key == me.t_key && b.tris[ej.slot].face < t.face)) rank++;
+    }
     float o[3], d[3];
     fetch_ray(rf, i, o, d);
     tr_ray r;
     tr_ray_setup(r, o[0], o[1], o[2], d[0], d[1], d[2]);
-    tr_counters* nc = nullptr;
-    const tr_tri t = tr_load_tri<false>(b, slots[g], nc);
     tr_hit h;
     tr_tri_hit(r, t.ax, t.ay, t.az, t.bx, t.by, t.bz, t.cx, t.cy, t.cz, h);
     float l3[3], uv[2];
     tr_hit_outputs(h, t.ax, t.ay, t.az, t.bx, t.by, t.bz, t.cx, t.cy, t.cz, l3, uv);
-    const int64_t w = offsets[i] + k;
+    const int64_t w = offsets[i] + rank;
     loc[3 * w] = l3[0]; loc[3 * w + 1] = l3[1]; loc[3 * w + 2] = l3[2];
     ray_idx[w] = (int32_t)(i + ray_base);
     tri_idx[w] = t.face;
@@ -714,7 +691,7 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
     const int bs = opt.block_size;
     const int64_t nblocks_direct = (rf.n + bs - 1) / bs;
     int64_t pgrid = (int64_t)st->num_cus * opt.blocks_per_cu;
-    if (opt.persistent) {
+    if (opt.persistent && Q != TR_Q_LOCATION) {   // the multi-hit list query has only the direct shape
         // size the persistent grid by what is actually resident (4 waves per block = 1 per SIMD)
         static int occ_refill = 0, occ_plain = 0;   // per instantiation <Q, STATS>
         int& occ = opt.refill ? occ_refill : occ_plain;
@@ -887,45 +864,30 @@ int tr_intersects_location_fill(const tr_bvh* bvh, const tr_rays* rays, int32_t 
 }
 
 int tr_intersects_count_topk(const tr_bvh* bvh, const tr_rays* rays, int32_t cap, int32_t* d_count,
-                             int32_t* d_slots, void* stream) {
+                             tr_hit_entry* d_hits, void* stream) {
     if (!bvh) return tr_fail(TR_ERR_INVALID_ARG, "bvh == NULL");
     if (cap < 1 || cap > TR_MAX_HITS_CAP) return tr_fail(TR_ERR_INVALID_ARG, "cap out of range");
     RayFetch rf;
     TR_TRY(make_fetch(rays, &rf));
     if (rf.n == 0) return TR_OK;
-    if (!d_count || !d_slots) return tr_fail(TR_ERR_INVALID_ARG, "null output pointer");
-    tr_bvh_view view = make_view(bvh);
-    hipStream_t s = (hipStream_t)stream;
-    dim3 grid((unsigned)((rf.n + 255) / 256)), block(256);
-    const int xm = tr_opts().xcd_chunk;
-    const uint32_t* order = nullptr;
-    uint32_t* cost = nullptr;
-    sched_acquire(bvh, s, (int64_t)grid.x, &order, &cost);
-    const bool compact = tr_opts().compact && bvh->depth <= 32 &&
-                         bvh->num_nodes * (int64_t)sizeof(tr_node) < ((int64_t)1 << 32) &&
-                         bvh->num_tris * (int64_t)sizeof(tr_tri) < ((int64_t)1 << 32);
-    if (cap <= 8 && compact) hipLaunchKernelGGL((k_count_topk<8, true>), grid, block, 0, s, view, rf, cap, d_count, d_slots, xm, order, cost);
-    else if (cap <= 8) hipLaunchKernelGGL((k_count_topk<8, false>), grid, block, 0, s, view, rf, cap, d_count, d_slots, xm, order, cost);
-    else if (cap <= 16) hipLaunchKernelGGL((k_count_topk<16, false>), grid, block, 0, s, view, rf, cap, d_count, d_slots, xm, order, cost);
-    else hipLaunchKernelGGL((k_count_topk<32, false>), grid, block, 0, s, view, rf, cap, d_count, d_slots, xm, order, cost);
-    if (cost) hipLaunchKernelGGL(k_sched_sort, dim3(1), dim3(1024), 0, s, cost, cost + TR_SCHED_MAX, (int)grid.x, xm);
-    TR_HIP_TRY(hipGetLastError());
-    return TR_OK;
+    if (!d_count || !d_hits) return tr_fail(TR_ERR_INVALID_ARG, "null output pointer");
+    QueryOut out = {nullptr, nullptr, nullptr, nullptr, nullptr, d_count, d_hits, cap};
+    return launch_query<TR_Q_LOCATION, false>(bvh, rays, out, nullptr, (hipStream_t)stream);
 }
 
 int tr_location_fill_slots(const tr_bvh* bvh, const tr_rays* rays, int32_t cap, const int32_t* d_count,
-                           const int64_t* d_offsets, const int32_t* d_slots, float* d_loc,
+                           const int64_t* d_offsets, const tr_hit_entry* d_hits, float* d_loc,
                            int32_t* d_ray_idx, int32_t* d_tri_idx, int64_t ray_base, void* stream) {
     if (!bvh) return tr_fail(TR_ERR_INVALID_ARG, "bvh == NULL");
     if (cap < 1 || cap > TR_MAX_HITS_CAP) return tr_fail(TR_ERR_INVALID_ARG, "cap out of range");
     RayFetch rf;
     TR_TRY(make_fetch(rays, &rf));
     if (rf.n == 0) return TR_OK;
-    if (!d_count || !d_offsets || !d_slots) return tr_fail(TR_ERR_INVALID_ARG, "null input pointer");
+    if (!d_count || !d_offsets || !d_hits) return tr_fail(TR_ERR_INVALID_ARG, "null input pointer");
     tr_bvh_view view = make_view(bvh);
     const int64_t threads = rf.n * cap;
-    hipLaunchKernelGGL(k_fill_slots, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       view, rf, cap, d_count, d_offsets, d_slots, d_loc, d_ray_idx, d_tri_idx, ray_base);
+    hipLaunchKernelGGL(k_fill_list, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       view, rf, cap, d_count, d_offsets, d_hits, d_loc, d_ray_idx, d_tri_idx, ray_base);
     TR_HIP_TRY(hipGetLastError());
     return TR_OK;
 }

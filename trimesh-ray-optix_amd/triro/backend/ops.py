@@ -106,7 +106,7 @@ def get_module():
         fn = getattr(lib, name)   # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.tr_abi_version() != 1:
+    if lib.tr_abi_version() != 2:
         raise RuntimeError("libtriro_hip.so ABI version mismatch")
     _lib = lib
     return _lib
@@ -260,7 +260,7 @@ def intersects_location(accel_structure, origins, dirs, ray_base: int = 0, fused
             stream = _stream_ptr(dev)
             rays = make_rays(origins, dirs)
             count = torch.empty(n, dtype=torch.int32, device=dev)
-            slots = torch.empty((n, MAX_ANYHIT_SIZE), dtype=torch.int32, device=dev)
+            slots = torch.empty((n, MAX_ANYHIT_SIZE, 2), dtype=torch.int32, device=dev)   # tr_hit_entry {t_key, slot}
             _check(lib.tr_intersects_count_topk(_handle(accel_structure), C.byref(rays), MAX_ANYHIT_SIZE,
                                                 count.data_ptr(), slots.data_ptr(), stream))
             offsets = torch.empty(n, dtype=torch.int64, device=dev)
