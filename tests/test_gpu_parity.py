@@ -358,10 +358,10 @@ def test_launch_shapes_agree(device):
         assert torch.equal(x, y)
     assert torch.equal(ca, cb)
     # every launch-shape knob of the direct kernel is a pure scheduling choice
-    defaults = {"adaptive": 1, "scramble": 1, "block_size": 128, "xcd_chunk": 128, "compact": 1}
+    defaults = {"adaptive": 1, "scramble": 1, "block_size": 128, "xcd_chunk": 128, "compact": 1, "steal": 1}
     try:
         for name, values in (("adaptive", (0,)), ("scramble", (0,)), ("block_size", (64, 256)),
-                             ("xcd_chunk", (0, 48, 1024)), ("compact", (0,))):
+                             ("xcd_chunk", (0, 48, 1024)), ("compact", (0,)), ("steal", (0, 2, 8, 64))):
             for val in values:
                 hops.set_option(name, val)
                 if name == "scramble":
@@ -370,6 +370,9 @@ def test_launch_shapes_agree(device):
                     c = r.intersects_closest(ot, dt)
                     for x, y in zip(c, b):
                         assert torch.equal(x, y), (name, val)
+                if name == "steal":                       # the other queries that can steal
+                    assert torch.equal(r.intersects_count(ot, dt), cb), (name, val)
+                    assert torch.equal(r.intersects_first(ot, dt), b[2]), (name, val)
                 hops.set_option(name, defaults[name])
                 hops.set_option("adaptive", 1)
     finally:

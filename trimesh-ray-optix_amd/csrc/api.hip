@@ -292,6 +292,10 @@ int tr_set_option(const char* name, int64_t value) {
     }
     if (!strcmp(name, "refill")) { g_options.refill = value != 0; return TR_OK; }
     if (!strcmp(name, "adaptive")) { g_options.adaptive = value != 0; return TR_OK; }
+    if (!strcmp(name, "steal")) {   // 0 off, 1 on (threshold 64 trips), > 1: on with this trip threshold
+        if (value < 0 || value > 4096) return tr_fail(TR_ERR_INVALID_ARG, "steal out of range");
+        g_options.steal = (int)value; return TR_OK;
+    }
     if (!strcmp(name, "tile")) {
         if (value < 0 || value > 2) return tr_fail(TR_ERR_INVALID_ARG, "tile must be 0, 1 or 2");
         g_options.tile = (int)value; return TR_OK;

@@ -132,6 +132,147 @@ __device__ __forceinline__ void wave_traverse(const tr_bvh_view& b, const tr_ray
     }
 }
 
+// ---- intra-wave work stealing ------------------------------------------------------------------
+// A wave runs until its slowest ray is done; on the headline batch that is 334 trips for one
+// grazing ray while the other 63 lanes finished after 30-60.  Here an idle lane takes the
+// SHALLOWEST owed far child (the biggest untouched subtree) of a busy lane together with that
+// lane's ray and traverses it as an independent sub-traversal (empty trail: it ends when the
+// subtree is exhausted); the per-ray results are merged at the end of the wave by the same
+// (t_key, face) minimum (closest / first) or by summation (count).  Any partition of the tree
+// among lanes examines the same set of candidate triangles except for culling, so results are
+// bit-identical.  Donors are rays that cannot lose culling by being split: count rays (no
+// culling at all) and closest/first rays that have found no hit yet after `steal_min` trips --
+// the grazing rays that make the long waves.  wl = 6*64 ints of LDS scratch per wave.
+#ifndef TR_STEAL_EVERY
+#define TR_STEAL_EVERY 3u     // hand-overs are attempted on every (TR_STEAL_EVERY+1)-th trip ...
+#endif
+#ifndef TR_STEAL_IDLE
+#define TR_STEAL_IDLE 1       // ... when at least this many lanes are idle
+#endif
+__device__ __forceinline__ int lane_rank(unsigned long long mask) {   // set bits of mask below this lane
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+template <int Q, bool STATS, bool COMPACT>
+__device__ __forceinline__ bool wave_traverse_steal(const tr_bvh_view& b, tr_ray& r, bool go,
+                                                    tr_result& res, tr_counters* cnt,
+                                                    const tr_ring ring, int32_t* wl, int lane,
+                                                    uint32_t steal_min) {
+    typedef typename tr_word<COMPACT>::T W;
+    tr_result_init(res);
+    tr_topk<1> top;
+    tr_state_t<W> fs;
+    tr_state_init(fs);
+    if (!go) fs.node = -1;
+    int owner = lane;          // lane whose ray this lane is working on
+    bool split = false;        // wave-uniform: some ray is (or was) traversed by more than one lane
+    uint32_t trip = 0;
+    // explicit LDS pointers: volatile accesses through generic pointers would compile to flat
+    // loads/stores with 64-bit addresses held in VGPRs for the whole loop
+    typedef __attribute__((address_space(3))) volatile int32_t lds_i32;
+    typedef __attribute__((address_space(3))) volatile unsigned long long lds_u64;
+    lds_i32* const lw = (lds_i32*)wl;
+    lds_i32* const list = lw;                    // [64] donor lane of pair k
+    lds_i32* const xnode = lw + 64;              // [64] node handed over by donor lane
+    lds_i32* const xdepth = lw + 128;            // [64] its depth
+    // per-ray accumulators at the owner's index: partial results are deposited whenever a lane
+    // finishes a piece of work (before it takes the next one) and once more at the end
+    int32_t* sum = wl + 192;                                                        // count
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(wl + 192);   // closest / first
+    lds_i32* const vsum = lw + 192;
+    lds_u64* const vkeys = (lds_u64*)(lw + 192);
+    lds_i32* const vslots = lw + 320;
+    auto deposit = [&]() {
+        if (Q == TR_Q_COUNT) {
+            if (res.count) atomicAdd(&sum[owner], res.count);
+        } else {
+            const bool have = res.best_slot >= 0;
+            const unsigned long long key = ((unsigned long long)__float_as_uint(res.best_t) << 32) |
+                                           (unsigned)res.best_face;   // t_key >= 0: bits order like values
+            if (have) atomicMin(&keys[owner], key);
+            __builtin_amdgcn_wave_barrier();
+            if (have && vkeys[owner] == key) vslots[owner] = res.best_slot;   // faces are distinct: one winner
+        }
+    };
+    for (;;) {
+        // TR_STEAL_EVERY+1 plain trips (idle lanes sit them out under the exec mask: a trip takes
+        // longer the more lanes take part in its loads), then one look at the wave
+#pragma unroll 1
+        for (uint32_t k = 0; k <= TR_STEAL_EVERY; k++) {
+            if (!tr_done(fs)) tr_fused_step<Q, 1, STATS, COMPACT, W>(b, r, fs, res, top, cnt, ring);
+            TR_CONVERGE();
+        }
+        trip += TR_STEAL_EVERY + 1u;
+        const bool done = tr_done(fs);
+        const unsigned long long idle = __ballot(done);
+        if (idle == ~0ull) break;
+        if (__popcll(idle) >= TR_STEAL_IDLE) {
+            const W cand = fs.trail & fs.owned;      // owed far children that are still in the ring
+            const bool can_give = !done && cand != 0 && trip >= steal_min &&
+                                  (Q == TR_Q_COUNT || res.best_slot < 0);
+            const unsigned long long donors = __ballot(can_give);
+            const int ni = __popcll(idle), nd = __popcll(donors);
+            const int np = ni < nd ? ni : nd;
+            if (np > 0) {
+                if (!split) {   // first hand-over in this wave: set the accumulators up
+                    if (Q == TR_Q_COUNT) vsum[lane] = 0;
+                    else vkeys[lane] = ~0ull;
+                    split = true;
+                    __builtin_amdgcn_wave_barrier();
+                }
+                const int drank = lane_rank(donors), irank = lane_rank(idle);
+                if (can_give && drank < np) {
+                    const uint32_t j = (uint32_t)__builtin_ctzll((unsigned long long)cand);
+                    list[drank] = lane;
+                    xnode[lane] = ring.base[(j & (TR_RING - 1)) * ring.stride];
+                    xdepth[lane] = (int32_t)(j + 1);
+                    fs.trail &= ~(W(1) << j);
+                    fs.owned &= ~(W(1) << j);
+                }
+                __builtin_amdgcn_wave_barrier();
+                const bool take = done && irank < np;
+                const int src = take ? list[irank] : lane;
+                // a lane that takes new work first hands in what it has found so far
+                if (take) {
+                    deposit();
+                    tr_result_init(res);
+                }
+                // the ray (and its owner / current bound) moves with the subtree
+                r.ox = __shfl(r.ox, src); r.oy = __shfl(r.oy, src); r.oz = __shfl(r.oz, src);
+                r.dx = __shfl(r.dx, src); r.dy = __shfl(r.dy, src); r.dz = __shfl(r.dz, src);
+                r.ix = __shfl(r.ix, src); r.iy = __shfl(r.iy, src); r.iz = __shfl(r.iz, src);
+                const int own2 = __shfl(owner, src);
+                const float bt = __shfl(res.best_t, src);
+                if (take) {
+                    owner = own2;
+                    tr_state_init(fs);
+                    fs.node = xnode[src];
+                    fs.depth = (uint32_t)xdepth[src];
+                    res.best_t = bt;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    if (split) {
+        // everybody hands in what it still holds; every owner lane reads its ray's total
+        deposit();
+        __builtin_amdgcn_wave_barrier();
+        if (Q == TR_Q_COUNT) {
+            res.count = vsum[lane];
+        } else {
+            const unsigned long long k = vkeys[lane];
+            tr_result_init(res);
+            if (k != ~0ull) {
+                res.best_t = __uint_as_float((unsigned)(k >> 32));
+                res.best_face = (int32_t)(unsigned)k;
+                res.best_slot = vslots[lane];
+            }
+        }
+    }
+    return split;
+}
+
 // All 64 lanes of a wave call this together (`in_range` = the lane owns ray i).
 template <int Q, bool STATS, bool COMPACT = false>
 __device__ __forceinline__ void process_ray(const tr_bvh_view& b, const RayFetch& rf,
@@ -163,6 +304,26 @@ __device__ __forceinline__ void process_ray(const tr_bvh_view& b, const RayFetch
     if (in_range) write_result<Q>(b, out, i, r, res);
 }
 
+template <int Q, bool STATS, bool COMPACT>
+__device__ __forceinline__ void process_ray_steal(const tr_bvh_view& b, const RayFetch& rf,
+                                                  const QueryOut& out, int64_t i, bool in_range,
+                                                  tr_counters* cnt, const tr_ring ring, int32_t* wl,
+                                                  uint32_t steal_min) {
+    float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
+    if (in_range) fetch_ray(rf, i, o, d);
+    tr_ray r;
+    const bool valid = tr_ray_setup(r, o[0], o[1], o[2], d[0], d[1], d[2]) && in_range;
+    tr_result res;
+    bool split = false;
+    if (b.num_tris >= 2) split = wave_traverse_steal<Q, STATS, COMPACT>(b, r, valid, res, cnt, ring, wl, (int)(threadIdx.x & 63), steal_min);
+    else brute_one<Q>(b, r, valid, res);   // no hierarchy below two triangles
+    if (split && in_range) {   // this lane may hold another lane's ray now: take its own again
+        fetch_ray(rf, i, o, d);
+        tr_ray_setup(r, o[0], o[1], o[2], d[0], d[1], d[2]);
+    }
+    if (in_range) write_result<Q>(b, out, i, r, res);
+}
+
 template <bool STATS>
 __device__ __forceinline__ void flush_stats(const tr_counters& c, unsigned long long* stats) {
     if (!STATS) return;
@@ -176,9 +337,9 @@ __device__ __forceinline__ void flush_stats(const tr_counters& c, unsigned long 
     }
 }
 
-template <int Q, bool STATS, bool COMPACT, int BS>
+template <int Q, bool STATS, bool COMPACT, int BS, bool STEAL = false>
 __global__ __launch_bounds__(BS) void k_query_direct(tr_bvh_view b, RayFetch rf, QueryOut out,
-                                                      int xcd_map, int scramble, int tile_w,
+                                                      int xcd_map, int scramble, int tile_w, int steal_min,
                                                       const uint32_t* __restrict__ order,
                                                       uint32_t* __restrict__ cost,
                                                       unsigned long long* stats) {
@@ -215,7 +376,15 @@ __global__ __launch_bounds__(BS) void k_query_direct(tr_bvh_view b, RayFetch rf,
         i = (ty * 8 + (lane >> 3)) * tile_w + tx * 8 + (lane & 7);
     }
     tr_counters cnt = {0, 0, 0};
-    process_ray<Q, STATS, COMPACT>(b, rf, out, i, i < rf.n, &cnt, ring);
+    if (STEAL) {
+        __shared__ alignas(8) int32_t steal_lds[(BS / 64) * 384];
+        // the scramble argument is not needed by launches that steal: it carries the trip
+        // threshold from which a closest/first ray without a hit may give subtrees away
+        process_ray_steal<Q, STATS, COMPACT>(b, rf, out, i, i < rf.n, &cnt, ring,
+                                             steal_lds + (threadIdx.x >> 6) * 384, (uint32_t)steal_min);
+    } else {
+        process_ray<Q, STATS, COMPACT>(b, rf, out, i, i < rf.n, &cnt, ring);
+    }
     if (cost && (threadIdx.x & 63) == 0) {
         const unsigned long long dt = wall_clock64() - t_start;     // 100 MHz ticks
         atomicMax(&cost[blk], (uint32_t)(dt > 0x7ffffull ? 0x7ffffull : dt));
@@ -744,7 +913,25 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
         }
 #define TR_LAUNCH_DIRECT(C, B)                                                                          \
     hipLaunchKernelGGL((k_query_direct<Q, STATS, C, B>), dim3((unsigned)nblocks_direct), dim3(B), 0, stream, \
-                       view, rf, out, xc, scramble, tile_w, order, cost, d_stats)
+                       view, rf, out, xc, scramble, tile_w, steal_min, order, cost, d_stats)
+        // intra-wave work stealing (wave_traverse_steal).  steal = 1 (default): closest / first
+        // launches below 4 M rays, donors from their 64th trip on -- +6 % on the headline, +43 % at
+        // 262 k rays, +25 % on the 4-shell scene, -3 % on 1 M incoherent rays; larger launches are
+        // throughput-bound (-7 % at 10 M incoherent rays) and count loses 4 % (no culling to
+        // protect, but its waves are balanced enough).  steal >= 2 forces it on, with that trip
+        // threshold, for closest / first / count at any size (tests).
+        const int steal_min = opt.steal > 1 ? opt.steal : 64;
+        const bool steal = !STATS && bs == 128 &&
+                           ((opt.steal == 1 && rf.n < ((int64_t)1 << 22) && (Q == TR_Q_CLOSEST || Q == TR_Q_FIRST)) ||
+                            (opt.steal > 1 && (Q == TR_Q_CLOSEST || Q == TR_Q_FIRST || Q == TR_Q_COUNT)));
+        if (steal) {
+            if (compact)
+                hipLaunchKernelGGL((k_query_direct<Q, false, true, 128, true>), dim3((unsigned)nblocks_direct), dim3(128), 0, stream,
+                                   view, rf, out, xc, scramble, tile_w, steal_min, order, cost, d_stats);
+            else
+                hipLaunchKernelGGL((k_query_direct<Q, false, false, 128, true>), dim3((unsigned)nblocks_direct), dim3(128), 0, stream,
+                                   view, rf, out, xc, scramble, tile_w, steal_min, order, cost, d_stats);
+        } else
         if (bs == 64) { if (compact) TR_LAUNCH_DIRECT(true, 64); else TR_LAUNCH_DIRECT(false, 64); }
         else if (bs == 128) { if (compact) TR_LAUNCH_DIRECT(true, 128); else TR_LAUNCH_DIRECT(false, 128); }
         else { if (compact) TR_LAUNCH_DIRECT(true, 256); else TR_LAUNCH_DIRECT(false, 256); }
