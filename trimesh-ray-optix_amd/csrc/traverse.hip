@@ -140,9 +140,10 @@ __device__ __forceinline__ void wave_traverse(const tr_bvh_view& b, const tr_ray
 // subtree is exhausted); the per-ray results are merged at the end of the wave by the same
 // (t_key, face) minimum (closest / first) or by summation (count).  Any partition of the tree
 // among lanes examines the same set of candidate triangles except for culling, so results are
-// bit-identical.  Donors are rays that cannot lose culling by being split: count rays (no
-// culling at all) and closest/first rays that have found no hit yet after `steal_min` trips --
-// the grazing rays that make the long waves.  wl = 6*64 ints of LDS scratch per wave.
+// bit-identical.  Donors are rays that are still busy at their `steal_min`-th trip (64): by then a
+// primary ray has normally found its hit (the thief inherits that bound), and what is left are
+// the grazing rays that make the long waves.  Splitting earlier costs culling (-6 % at 48, -15 %
+// at 32 on the headline).  wl = 6*64 ints of LDS scratch per wave.
 #ifndef TR_STEAL_EVERY
 #define TR_STEAL_EVERY 3u     // hand-overs are attempted on every (TR_STEAL_EVERY+1)-th trip ...
 #endif
@@ -208,8 +209,7 @@ __device__ __forceinline__ bool wave_traverse_steal(const tr_bvh_view& b, tr_ray
         if (idle == ~0ull) break;
         if (__popcll(idle) >= TR_STEAL_IDLE) {
             const W cand = fs.trail & fs.owned;      // owed far children that are still in the ring
-            const bool can_give = !done && cand != 0 && trip >= steal_min &&
-                                  (Q == TR_Q_COUNT || res.best_slot < 0);
+            const bool can_give = !done && cand != 0 && trip >= steal_min;
             const unsigned long long donors = __ballot(can_give);
             const int ni = __popcll(idle), nd = __popcll(donors);
             const int np = ni < nd ? ni : nd;
@@ -915,7 +915,7 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
     hipLaunchKernelGGL((k_query_direct<Q, STATS, C, B>), dim3((unsigned)nblocks_direct), dim3(B), 0, stream, \
                        view, rf, out, xc, scramble, tile_w, steal_min, order, cost, d_stats)
         // intra-wave work stealing (wave_traverse_steal).  steal = 1 (default): closest / first
-        // launches below 4 M rays, donors from their 64th trip on -- +6 % on the headline, +43 % at
+        // launches below 4 M rays, donors from their 64th trip on -- +11 % on the headline, +45 % at
         // 262 k rays, +25 % on the 4-shell scene, -3 % on 1 M incoherent rays; larger launches are
         // throughput-bound (-7 % at 10 M incoherent rays) and count loses 4 % (no culling to
         // protect, but its waves are balanced enough).  steal >= 2 forces it on, with that trip
