@@ -915,14 +915,14 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
     hipLaunchKernelGGL((k_query_direct<Q, STATS, C, B>), dim3((unsigned)nblocks_direct), dim3(B), 0, stream, \
                        view, rf, out, xc, scramble, tile_w, steal_min, order, cost, d_stats)
         // intra-wave work stealing (wave_traverse_steal).  steal = 1 (default): closest / first
-        // launches below 4 M rays, donors from their 64th trip on -- +11 % on the headline, +45 % at
+        // launches of up to 4 M rays, donors from their 64th trip on -- +11 % on the headline, +45 % at
         // 262 k rays, +25 % on the 4-shell scene, -3 % on 1 M incoherent rays; larger launches are
         // throughput-bound (-7 % at 10 M incoherent rays) and count loses 4 % (no culling to
         // protect, but its waves are balanced enough).  steal >= 2 forces it on, with that trip
         // threshold, for closest / first / count at any size (tests).
         const int steal_min = opt.steal > 1 ? opt.steal : 64;
         const bool steal = !STATS && bs == 128 &&
-                           ((opt.steal == 1 && rf.n < ((int64_t)1 << 22) && (Q == TR_Q_CLOSEST || Q == TR_Q_FIRST)) ||
+                           ((opt.steal == 1 && rf.n <= ((int64_t)1 << 22) && (Q == TR_Q_CLOSEST || Q == TR_Q_FIRST)) ||
                             (opt.steal > 1 && (Q == TR_Q_CLOSEST || Q == TR_Q_FIRST || Q == TR_Q_COUNT)));
         if (steal) {
             if (compact)
