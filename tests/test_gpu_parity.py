@@ -393,6 +393,32 @@ def test_launch_shapes_agree(device):
     assert stats["rays"] == 100000 and stats["node_visits"] > 0
 
 
+@pytest.mark.parametrize("threshold", [2, 8])
+def test_work_stealing_is_exact(device, threshold):
+    """Intra-wave work stealing forced on with a tiny trip threshold (idle lanes take subtrees of
+    busy lanes from trip 2 / 8 on): closest, first and count against the oracle on coherent and
+    incoherent rays, a multi-layer scene, a soup, and the deep tree that needs the 64-bit trail."""
+    import triro.backend.ops as hops
+    cases = [
+        (W.nested_shells(4), tuple(x.reshape(-1, 3) for x in W.pinhole_grid(160, 120))),
+        (W.random_soup(4000, seed=9), W.hash_rays(30000, 21, [-1.3] * 3, [1.3] * 3)),
+        (W.deep_tree_mesh(3000), W.hash_rays(20000, 22, [-0.2] * 3, [1.2] * 3)),
+        (W.bunny_standin(), tuple(x.reshape(-1, 3) for x in W.pinhole_grid(256, 192))),
+    ]
+    try:
+        hops.set_option("steal", threshold)
+        for (v, f), (o, d) in cases:
+            r = make(v, f, device)
+            R = OracleIntersector(v, f, 1)
+            ot, dt = T(o, device), T(d, device)
+            for _ in range(2):
+                assert_closest_equal(r.intersects_closest(ot, dt), R.closest_raw(o, d))
+            assert np.array_equal(r.intersects_count(ot, dt).cpu().numpy(), R.intersects_count(o, d))
+            assert np.array_equal(r.intersects_first(ot, dt).cpu().numpy(), R.intersects_first(o, d))
+    finally:
+        hops.set_option("steal", 1)
+
+
 def test_tile_mapping_is_a_pure_permutation(device):
     """Image-shaped batches may be traced in 8x8 pixel tiles per wave (option tile; automatic from
     4 M rays on).  Outputs are written at the true flat index: forced on (2) == off (0) for
