@@ -176,7 +176,7 @@ int tr_trace_stats_closest(const tr_bvh *bvh, const tr_rays *rays, tr_trace_stat
  *    name = "adaptive" (0/1: learn the launch order from the previous launch), "compact",
  *    "xcd_chunk", "persistent" (0/1), "refill" (0/1), "refill_min" (1..64 idle lanes that
  *    trigger a refill), "blocks_per_cu" (int), "block_size" (64/128/256 threads of the direct
- *    kernel), "steal" (intra-wave work stealing: 0 off / 1 closest and first up to
+ *    kernel), "steal" (intra-wave work stealing: 0 off / 1 closest, first and any up to
  *    4 M rays / >= 2 forced, the value is the trip count from which a ray gives subtrees away),
  *    "tile" (0 never / 1 from 4 M rays on / 2 always:
  *    image-shaped batches [..., H, W, 3] with W % 8 == 0 are traced in 8x8 pixel tiles per wave),

@@ -373,6 +373,7 @@ def test_launch_shapes_agree(device):
                 if name == "steal":                       # the other queries that can steal
                     assert torch.equal(r.intersects_count(ot, dt), cb), (name, val)
                     assert torch.equal(r.intersects_first(ot, dt), b[2]), (name, val)
+                    assert torch.equal(r.intersects_any(ot, dt), b[0]), (name, val)
                 hops.set_option(name, defaults[name])
                 hops.set_option("adaptive", 1)
     finally:
@@ -415,6 +416,7 @@ def test_work_stealing_is_exact(device, threshold):
                 assert_closest_equal(r.intersects_closest(ot, dt), R.closest_raw(o, d))
             assert np.array_equal(r.intersects_count(ot, dt).cpu().numpy(), R.intersects_count(o, d))
             assert np.array_equal(r.intersects_first(ot, dt).cpu().numpy(), R.intersects_first(o, d))
+            assert np.array_equal(r.intersects_any(ot, dt).cpu().numpy(), R.intersects_count(o, d) > 0)
     finally:
         hops.set_option("steal", 1)
 

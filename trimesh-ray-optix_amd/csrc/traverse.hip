@@ -186,6 +186,8 @@ __device__ __forceinline__ bool wave_traverse_steal(const tr_bvh_view& b, tr_ray
     auto deposit = [&]() {
         if (Q == TR_Q_COUNT) {
             if (res.count) atomicAdd(&sum[owner], res.count);
+        } else if (Q == TR_Q_ANY) {
+            if (res.best_face >= 0) vsum[owner] = 1;      // any hit of any worker
         } else {
             const bool have = res.best_slot >= 0;
             const unsigned long long key = ((unsigned long long)__float_as_uint(res.best_t) << 32) |
@@ -215,7 +217,7 @@ __device__ __forceinline__ bool wave_traverse_steal(const tr_bvh_view& b, tr_ray
             const int np = ni < nd ? ni : nd;
             if (np > 0) {
                 if (!split) {   // first hand-over in this wave: set the accumulators up
-                    if (Q == TR_Q_COUNT) vsum[lane] = 0;
+                    if (Q == TR_Q_COUNT || Q == TR_Q_ANY) vsum[lane] = 0;
                     else vkeys[lane] = ~0ull;
                     split = true;
                     __builtin_amdgcn_wave_barrier();
@@ -260,6 +262,8 @@ __device__ __forceinline__ bool wave_traverse_steal(const tr_bvh_view& b, tr_ray
         __builtin_amdgcn_wave_barrier();
         if (Q == TR_Q_COUNT) {
             res.count = vsum[lane];
+        } else if (Q == TR_Q_ANY) {
+            res.best_face = vsum[lane] ? 0 : -1;
         } else {
             const unsigned long long k = vkeys[lane];
             tr_result_init(res);
@@ -914,16 +918,16 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
 #define TR_LAUNCH_DIRECT(C, B)                                                                          \
     hipLaunchKernelGGL((k_query_direct<Q, STATS, C, B>), dim3((unsigned)nblocks_direct), dim3(B), 0, stream, \
                        view, rf, out, xc, scramble, tile_w, steal_min, order, cost, d_stats)
-        // intra-wave work stealing (wave_traverse_steal).  steal = 1 (default): closest / first
+        // intra-wave work stealing (wave_traverse_steal).  steal = 1 (default): closest / first / any
         // launches of up to 4 M rays, donors from their 64th trip on -- +11 % on the headline, +45 % at
         // 262 k rays, +25 % on the 4-shell scene, -3 % on 1 M incoherent rays; larger launches are
         // throughput-bound (-7 % at 10 M incoherent rays) and count loses 4 % (no culling to
         // protect, but its waves are balanced enough).  steal >= 2 forces it on, with that trip
-        // threshold, for closest / first / count at any size (tests).
+        // threshold, for closest / first / any / count at any size (tests).
         const int steal_min = opt.steal > 1 ? opt.steal : 64;
         const bool steal = !STATS && bs == 128 &&
-                           ((opt.steal == 1 && rf.n <= ((int64_t)1 << 22) && (Q == TR_Q_CLOSEST || Q == TR_Q_FIRST)) ||
-                            (opt.steal > 1 && (Q == TR_Q_CLOSEST || Q == TR_Q_FIRST || Q == TR_Q_COUNT)));
+                           ((opt.steal == 1 && rf.n <= ((int64_t)1 << 22) && (Q == TR_Q_CLOSEST || Q == TR_Q_FIRST || Q == TR_Q_ANY)) ||
+                            (opt.steal > 1 && (Q == TR_Q_CLOSEST || Q == TR_Q_FIRST || Q == TR_Q_COUNT || Q == TR_Q_ANY)));
         if (steal) {
             if (compact)
                 hipLaunchKernelGGL((k_query_direct<Q, false, true, 128, true>), dim3((unsigned)nblocks_direct), dim3(128), 0, stream,
