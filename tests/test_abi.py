@@ -35,7 +35,19 @@ def test_library_exports_every_declared_symbol():
     for s in header_symbols():
         assert hasattr(lib, s), f"{s} declared in include/triro_hip.h but not exported"
     assert set(hops.ABI) == set(header_symbols())
-    assert hops.get_module().tr_abi_version() == 2
+    assert hops.get_module().tr_abi_version() == hops.ABI_VERSION
+
+
+def test_abi_version_constant_matches_header_and_build_entry():
+    """The binding's ABI_VERSION is the header's TR_ABI_VERSION, and __graft_entry__.build() (the
+    driver's build check) passes with it."""
+    import re
+    import triro.backend.ops as hops
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "triro_hip.h")).read()
+    assert int(re.search(r"#define\s+TR_ABI_VERSION\s+(\d+)", hdr).group(1)) == hops.ABI_VERSION
+    import __graft_entry__ as g
+    g.build()
 
 
 def test_struct_layout_matches_header():

@@ -30,6 +30,7 @@ MAX_ANYHIT_SIZE = 8   # LaunchParams.h:8
 MAX_SIZE_LENGTH = 4   # LaunchParams.h:9
 
 _LIB_NAME = "libtriro_hip.so"
+ABI_VERSION = 2     # TR_ABI_VERSION of include/triro_hip.h this binding was written against
 _lib = None
 _lib_error = None
 
@@ -106,8 +107,8 @@ def get_module():
         fn = getattr(lib, name)   # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.tr_abi_version() != 2:
-        raise RuntimeError("libtriro_hip.so ABI version mismatch")
+    if lib.tr_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libtriro_hip.so ABI version {lib.tr_abi_version()} != {ABI_VERSION} expected by this binding")
     _lib = lib
     return _lib
 
