@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Randomised GPU-vs-oracle parity sweep (run on the GPU box): random meshes, ray sets, ray tensor
+shapes and launch-shape options (work stealing thresholds, tiles, block sizes, adaptive order).
+Every query must match the oracle bit for bit.  usage: python scripts/fuzz_parity.py [--iters 60] [--seed 1]"""
+import argparse, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "trimesh-ray-optix_amd")]
+import numpy as np, torch
+import workloads as W
+from oracle.oracle import OracleIntersector
+from triro.ray.ray_optix import RayMeshIntersector
+from triro.backend import ops as hops
+
+ap = argparse.ArgumentParser(); ap.add_argument("--iters", type=int, default=60); ap.add_argument("--seed", type=int, default=1)
+a = ap.parse_args()
+rng = np.random.default_rng(a.seed)
+dev = torch.device("cuda:0")
+T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+DEFAULTS = {"steal": 1, "tile": 1, "block_size": 128, "adaptive": 1, "xcd_chunk": 128, "compact": 1, "scramble": 1}
+bad = 0
+for it in range(a.iters):
+    kind = rng.integers(0, 5)
+    if kind == 0: v, f = W.icosphere(int(rng.integers(1, 6)))
+    elif kind == 1: v, f = W.random_soup(int(rng.integers(2, 6000)), seed=int(rng.integers(1 << 30)), size=float(rng.uniform(0.02, 0.6)))
+    elif kind == 2: v, f = W.nested_shells(int(rng.integers(2, 5)))
+    elif kind == 3:
+        v, f = W.icosphere(int(rng.integers(3, 6))); v = W.displaced(v, seed=int(rng.integers(1000)), amplitude=float(rng.uniform(0.01, 0.3)))
+    else: v, f = W.deep_tree_mesh(int(rng.integers(100, 3000)))
+    v = (v * np.float32(rng.uniform(0.1, 20.0)) + rng.uniform(-3, 3, 3).astype(np.float32)).astype(np.float32)
+    lo, hi = v.min(0), v.max(0); ext = np.maximum(hi - lo, 1e-3)
+    rk = rng.integers(0, 3)
+    if rk == 0:
+        h, w = int(rng.integers(1, 40)) * 8, int(rng.integers(1, 40)) * 8
+        o, d = W.pinhole_grid(w, h, distance=float(2.5 * np.linalg.norm(ext)))
+        o = o + ((lo + hi) / 2).astype(np.float32)
+    elif rk == 1:
+        n = int(rng.integers(1, 60000)); o, d = W.hash_rays(n, int(rng.integers(1 << 20)), lo - 0.5 * ext, hi + 0.5 * ext)
+    else:
+        n = int(rng.integers(64, 30000)); o, d = W.hash_rays(n, int(rng.integers(1 << 20)), lo - 0.1 * ext, hi + 0.1 * ext)
+        d = ((lo + hi) / 2 - o + rng.normal(0, 0.05, o.shape) * ext).astype(np.float32)   # aimed at the mesh
+    opts = {"steal": int(rng.choice([0, 1, 2, 5, 17, 64])), "tile": int(rng.choice([0, 1, 2])),
+            "block_size": int(rng.choice([64, 128, 128, 128, 128, 256])), "adaptive": int(rng.choice([0, 1, 1])),
+            "xcd_chunk": int(rng.choice([0, 16, 128, 300])), "compact": int(rng.choice([0, 1, 1])), "scramble": int(rng.choice([0, 1]))}
+    for k, val in opts.items(): hops.set_option(k, val)
+    try:
+        r = RayMeshIntersector(vertices=T(v), faces=T(f)); R = OracleIntersector(v, f, 1)
+        ot, dt = T(o), T(d); of, df = o.reshape(-1, 3), d.reshape(-1, 3)
+        for rep in range(3):
+            hit, front, tri, loc, uv = [x.cpu().numpy() for x in r.intersects_closest(ot, dt)]
+            eh, ef, et, el, eu = R.closest_raw(of, df)[:5]
+            ok = (np.array_equal(hit.reshape(-1), eh) and np.array_equal(front.reshape(-1), ef) and np.array_equal(tri.reshape(-1), et)
+                  and np.array_equal(loc.reshape(-1, 3), el) and np.array_equal(uv.reshape(-1, 2), eu))
+            cnt = R.intersects_count(of, df)
+            ok &= np.array_equal(r.intersects_count(ot, dt).cpu().numpy().reshape(-1), cnt)
+            ok &= np.array_equal(r.intersects_any(ot, dt).cpu().numpy().reshape(-1), cnt > 0)
+            ok &= np.array_equal(r.intersects_first(ot, dt).cpu().numpy().reshape(-1), et)
+            lo3, ra, tr_ = [x.cpu().numpy() for x in r.intersects_location(ot, dt)]
+            el2, er2, et2 = R.intersects_location(of, df)
+            ok &= np.array_equal(ra, er2) and np.array_equal(tr_, et2) and np.array_equal(lo3, el2)
+            if not ok: break
+    finally:
+        for k, val in DEFAULTS.items(): hops.set_option(k, val)
+    if not ok:
+        bad += 1
+        print("MISMATCH iter", it, "mesh kind", kind, "tris", len(f), "rays", o.shape, "opts", opts, flush=True)
+    elif it % 10 == 0:
+        print("iter", it, "ok  tris", len(f), "rays", tuple(o.shape), opts, flush=True)
+print("done:", a.iters, "iterations,", bad, "mismatches")
+sys.exit(1 if bad else 0)

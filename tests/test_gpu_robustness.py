@@ -158,3 +158,15 @@ def test_concurrent_streams_and_threads_share_one_handle(device):
     for t in threads:
         t.join()
     assert not errors, errors[:5]
+
+
+def test_randomised_parity_sweep(device):
+    """scripts/fuzz_parity.py with a fixed seed: random meshes, rays, tensor shapes and launch-shape
+    options (stealing thresholds, tiles, block sizes, ...), every query bit-exact against the oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_parity.py"), "--iters", "16", "--seed", "3"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
