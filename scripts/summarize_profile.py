@@ -86,7 +86,8 @@ out["derived"] = d
 os.makedirs("profiles", exist_ok=True)
 json.dump(out, open(os.path.join("profiles", f"{tag}_summary.json"), "w"), indent=1)
 with open(os.path.join("profiles", f"{tag}_summary.md"), "w") as f:
-    f.write(f"# rocprofv3 summary `{tag}` (bench.py --steps 20 --warmup 3, MI355X)\n\n")
+    cmd = os.environ.get("PROFILE_CMD", "bench.py --steps 20 --warmup 3 --no-cpu-baseline")
+    f.write(f"# rocprofv3 summary `{tag}` ({cmd}, MI355X)\n\n")
     f.write("## kernel-trace --stats\n\n| kernel | calls | avg us | min us | max us | % |\n|---|---|---|---|---|---|\n")
     for k in out.get("kernel_stats", []):
         f.write(f"| `{k['name']}` | {k['calls']} | {k['avg_ns']/1e3:.1f} | {k['min_ns']/1e3:.1f} | {k['max_ns']/1e3:.1f} | {k['pct']:.2f} |\n")
