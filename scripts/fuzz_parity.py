@@ -16,7 +16,8 @@ a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
 dev = torch.device("cuda:0")
 T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
-DEFAULTS = {"steal": 1, "tile": 1, "block_size": 128, "adaptive": 1, "xcd_chunk": 128, "compact": 1, "scramble": 1}
+DEFAULTS = {"steal": 1, "tile": 1, "block_size": 128, "adaptive": 1, "xcd_chunk": 128, "compact": 1, "scramble": 1,
+            "persistent": 0, "refill": 1, "refill_min": 16, "xcd_segments": 1, "leaf_min": 0, "blocks_per_cu": 8}
 bad = 0
 for it in range(a.iters):
     kind = rng.integers(0, 5)
@@ -28,8 +29,18 @@ for it in range(a.iters):
     else: v, f = W.deep_tree_mesh(int(rng.integers(100, 3000)))
     v = (v * np.float32(rng.uniform(0.1, 20.0)) + rng.uniform(-3, 3, 3).astype(np.float32)).astype(np.float32)
     lo, hi = v.min(0), v.max(0); ext = np.maximum(hi - lo, 1e-3)
-    rk = rng.integers(0, 3)
-    if rk == 0:
+    rk = rng.integers(0, 4)
+    if rk == 3:
+        # rays that START ON the mesh (vertices, edge midpoints, points inside a face): t_key = +-0.0
+        # ties, the family that exposed the -0.0 key of the stealing merge
+        n = int(rng.integers(64, 20000)); fi = rng.integers(0, len(f), n); tv = v[f[fi]]
+        w = rng.random((n, 3)).astype(np.float32); w[rng.random(n) < 0.4] = [1, 0, 0]; w[rng.random(n) < 0.2] = [0.5, 0.5, 0]
+        w /= w.sum(1, keepdims=True)
+        o = np.where((w == [1, 0, 0]).all(1)[:, None], tv[:, 0], (w[:, :1] * tv[:, 0] + w[:, 1:2] * tv[:, 1] + w[:, 2:] * tv[:, 2])).astype(np.float32)
+        nrm = np.cross(tv[:, 1] - tv[:, 0], tv[:, 2] - tv[:, 0]).astype(np.float32)
+        pick = rng.integers(0, 4, n)[:, None]
+        d = np.where(pick == 0, nrm, np.where(pick == 1, -nrm, np.where(pick == 2, (lo + hi) / 2 - o, rng.normal(size=(n, 3))))).astype(np.float32)
+    elif rk == 0:
         h, w = int(rng.integers(1, 40)) * 8, int(rng.integers(1, 40)) * 8
         o, d = W.pinhole_grid(w, h, distance=float(2.5 * np.linalg.norm(ext)))
         o = o + ((lo + hi) / 2).astype(np.float32)
@@ -40,7 +51,10 @@ for it in range(a.iters):
         d = ((lo + hi) / 2 - o + rng.normal(0, 0.05, o.shape) * ext).astype(np.float32)   # aimed at the mesh
     opts = {"steal": int(rng.choice([0, 1, 2, 5, 17, 64])), "tile": int(rng.choice([0, 1, 2])),
             "block_size": int(rng.choice([64, 128, 128, 128, 128, 256])), "adaptive": int(rng.choice([0, 1, 1])),
-            "xcd_chunk": int(rng.choice([0, 16, 128, 300])), "compact": int(rng.choice([0, 1, 1])), "scramble": int(rng.choice([0, 1]))}
+            "xcd_chunk": int(rng.choice([0, 16, 128, 300])), "compact": int(rng.choice([0, 1, 1])), "scramble": int(rng.choice([0, 1])),
+            # optional launch shapes (persistent batches / per-lane refill engage on batches larger than the resident grid)
+            "persistent": int(rng.choice([0, 0, 1])), "refill": int(rng.choice([0, 1])), "refill_min": int(rng.choice([1, 16, 48])),
+            "xcd_segments": int(rng.choice([0, 1])), "leaf_min": int(rng.choice([0, 16, 64])), "blocks_per_cu": int(rng.choice([1, 8]))}
     for k, val in opts.items(): hops.set_option(k, val)
     try:
         r = RayMeshIntersector(vertices=T(v), faces=T(f)); R = OracleIntersector(v, f, 1)

@@ -2,6 +2,7 @@
 // C ABI (include/triro_hip.h).  Replaces triro/backend/base.cpp (global OptiX context, module,
 // pipelines, SBTs: base.cpp:15-157) -- none of those concepts survive; what remains is a
 // per-device table {CU count, work-counter ring, builder temporaries} created on first use.
+#include <atomic>
 #include <mutex>
 #include <string.h>
 
@@ -12,23 +13,40 @@ thread_local std::string g_last_error;
 std::mutex g_mutex;
 constexpr int TR_MAX_DEVICES = 64;
 tr_device_state g_devices[TR_MAX_DEVICES];
-tr_options g_options;
 
-struct DeviceGuard {
-    int prev = -1;
-    bool changed = false;
-    int enter(int device) {
-        if (hipGetDevice(&prev) != hipSuccess) return TR_ERR_NO_DEVICE;
-        if (prev != device) {
-            if (hipSetDevice(device) != hipSuccess) return TR_ERR_NO_DEVICE;
-            changed = true;
-        }
-        return TR_OK;
-    }
-    ~DeviceGuard() {
-        if (changed) (void)hipSetDevice(prev);
+// option table: name, field, accepted range (0/1 options are normalised with != 0)
+struct opt_desc {
+    const char* name;
+    int tr_options::*field;
+    int64_t lo, hi;
+    bool boolean;
+};
+const opt_desc OPTS[] = {
+    {"persistent", &tr_options::persistent, 0, 1, true},
+    {"blocks_per_cu", &tr_options::blocks_per_cu, 1, 32, false},
+    {"refill", &tr_options::refill, 0, 1, true},
+    {"block_size", &tr_options::block_size, 64, 256, false},
+    {"adaptive", &tr_options::adaptive, 0, 1, true},
+    {"compact", &tr_options::compact, 0, 1, true},
+    {"refill_min", &tr_options::refill_min, 1, 64, false},
+    {"xcd_segments", &tr_options::xcd_segments, 0, 1, true},
+    {"xcd_chunk", &tr_options::xcd_chunk, 0, 65536, false},
+    {"steal", &tr_options::steal, 0, 4096, false},
+    {"tile", &tr_options::tile, 0, 2, false},
+    {"scramble", &tr_options::scramble, 0, 1, true},
+    {"build_cache", &tr_options::build_cache, 0, 1, true},
+    {"leaf_min", &tr_options::leaf_min, 0, 64, false},
+};
+constexpr int NUM_OPTS = (int)(sizeof(OPTS) / sizeof(OPTS[0]));
+struct opt_store {
+    std::atomic<int> v[NUM_OPTS];
+    opt_store() {
+        const tr_options d;
+        for (int k = 0; k < NUM_OPTS; k++) v[k].store(d.*(OPTS[k].field), std::memory_order_relaxed);
     }
 };
+opt_store g_opts;
+
 }  // namespace
 
 void tr_set_error(const std::string& msg) { g_last_error = msg; }
@@ -36,7 +54,11 @@ int tr_fail(int code, const std::string& msg) {
     g_last_error = msg;
     return code;
 }
-tr_options& tr_opts() { return g_options; }
+tr_options tr_opts() {
+    tr_options o;
+    for (int k = 0; k < NUM_OPTS; k++) o.*(OPTS[k].field) = g_opts.v[k].load(std::memory_order_relaxed);
+    return o;
+}
 
 int tr_get_device_state(int device, tr_device_state** out) {
     if (device < 0 || device >= TR_MAX_DEVICES) return tr_fail(TR_ERR_INVALID_ARG, "device ordinal out of range");
@@ -47,7 +69,7 @@ int tr_get_device_state(int device, tr_device_state** out) {
         if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
             return tr_fail(TR_ERR_NO_DEVICE, "no HIP device available (libtriro_hip has no CPU fallback)");
         if (device >= count) return tr_fail(TR_ERR_NO_DEVICE, "device ordinal >= device count");
-        DeviceGuard g;
+        tr_device_guard g;
         if (g.enter(device) != TR_OK) return tr_fail(TR_ERR_NO_DEVICE, "hipSetDevice failed");
         hipDeviceProp_t prop;
         TR_HIP_TRY(hipGetDeviceProperties(&prop, device));
@@ -81,7 +103,7 @@ int tr_build_temp_acquire(tr_device_state* st, size_t bytes, void** out) {
 
 int tr_build_temp_release(tr_device_state* st) {
     int status = TR_OK;
-    if (!g_options.build_cache && st->build_temp) {
+    if (!tr_opts().build_cache && st->build_temp) {
         if (hipFree(st->build_temp) != hipSuccess) status = tr_fail(TR_ERR_HIP, "hipFree(builder temporaries)");
         st->build_temp = nullptr;
         st->build_temp_bytes = 0;
@@ -120,7 +142,7 @@ int tr_bvh_build(const float* d_vertices, int64_t nv, const int32_t* d_faces, in
     }
     tr_device_state* st;
     TR_TRY(tr_get_device_state(device, &st));
-    DeviceGuard g;
+    tr_device_guard g;
     if (g.enter(device) != TR_OK) return tr_fail(TR_ERR_NO_DEVICE, "hipSetDevice failed");
     tr_bvh* bvh = new (std::nothrow) tr_bvh();
     if (!bvh) return tr_fail(TR_ERR_OUT_OF_MEMORY, "host allocation failed");
@@ -140,7 +162,7 @@ int tr_bvh_build(const float* d_vertices, int64_t nv, const int32_t* d_faces, in
 int tr_bvh_update(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_t* d_faces,
                   int64_t nf, void* stream) {
     if (!bvh) return tr_fail(TR_ERR_INVALID_ARG, "bvh == NULL");
-    DeviceGuard g;
+    tr_device_guard g;
     if (g.enter(bvh->device) != TR_OK) return tr_fail(TR_ERR_NO_DEVICE, "hipSetDevice failed");
     return tr_build_impl(bvh, d_vertices, nv, d_faces, nf, (hipStream_t)stream);
 }
@@ -148,7 +170,7 @@ int tr_bvh_update(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_
 int tr_bvh_refit(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_t* d_faces,
                  int64_t nf, void* stream) {
     if (!bvh) return tr_fail(TR_ERR_INVALID_ARG, "bvh == NULL");
-    DeviceGuard g;
+    tr_device_guard g;
     if (g.enter(bvh->device) != TR_OK) return tr_fail(TR_ERR_NO_DEVICE, "hipSetDevice failed");
     return tr_refit_impl(bvh, d_vertices, nv, d_faces, nf, (hipStream_t)stream);
 }
@@ -167,18 +189,20 @@ const char TR_MAGIC[8] = {'T', 'R', 'B', 'V', 'H', 0, 0, 2};   // 2: child boxes
 
 int64_t tr_bvh_serialized_size(const tr_bvh* bvh) {
     if (!bvh) return -1;
-    return (int64_t)sizeof(tr_blob_header) + (bvh->num_tris > 0 ? bvh->arena_bytes : 0);
+    // only the bytes the current mesh uses: after update_raw() to a smaller mesh the arena keeps
+    // its larger capacity, which is not part of the hierarchy
+    return (int64_t)sizeof(tr_blob_header) + (bvh->num_tris > 0 ? tr_arena_used_bytes(bvh->num_tris) : 0);
 }
 
 int tr_bvh_serialize(const tr_bvh* bvh, void* h_buffer, int64_t size, void* stream) {
     if (!bvh || !h_buffer) return tr_fail(TR_ERR_INVALID_ARG, "null argument");
     if (size < tr_bvh_serialized_size(bvh)) return tr_fail(TR_ERR_INVALID_ARG, "buffer too small");
-    DeviceGuard g;
+    tr_device_guard g;
     if (g.enter(bvh->device) != TR_OK) return tr_fail(TR_ERR_NO_DEVICE, "hipSetDevice failed");
     tr_blob_header h;
     memset(&h, 0, sizeof h);
     memcpy(h.magic, TR_MAGIC, 8);
-    h.num_tris = bvh->num_tris; h.num_nodes = bvh->num_nodes; h.arena_bytes = bvh->num_tris > 0 ? bvh->arena_bytes : 0;
+    h.num_tris = bvh->num_tris; h.num_nodes = bvh->num_nodes; h.arena_bytes = bvh->num_tris > 0 ? tr_arena_used_bytes(bvh->num_tris) : 0;
     h.depth = bvh->depth; h.key_mode = bvh->key_mode;
     for (int k = 0; k < 3; k++) { h.aabb_min[k] = bvh->aabb_min[k]; h.aabb_max[k] = bvh->aabb_max[k]; }
     h.sizeof_node = sizeof(tr_node); h.sizeof_tri = sizeof(tr_tri); h.sizeof_link = sizeof(tr_link);
@@ -215,7 +239,7 @@ int tr_bvh_deserialize(const void* h_buffer, int64_t size, void* stream, tr_bvh*
     int s = tr_build_impl(bvh, nullptr, 0, nullptr, 0, (hipStream_t)stream);
     if (s == TR_OK && h.num_tris > 0) {
         s = tr_arena_alloc(bvh, h.num_tris);
-        if (s == TR_OK && bvh->arena_bytes != h.arena_bytes) s = tr_fail(TR_ERR_INVALID_ARG, "arena size mismatch");
+        if (s == TR_OK && tr_arena_used_bytes(h.num_tris) != h.arena_bytes) s = tr_fail(TR_ERR_INVALID_ARG, "arena size mismatch");
         if (s == TR_OK) {
             if (hipMemcpyAsync(bvh->arena, (const char*)h_buffer + sizeof h, (size_t)h.arena_bytes, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess ||
                 hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
@@ -240,9 +264,9 @@ int tr_bvh_destroy(tr_bvh* bvh) {
     if (!bvh) return TR_OK;
     int status = TR_OK;
     {
-        DeviceGuard g;
-        if (g.enter(bvh->device) == TR_OK && bvh->arena) {
-            if (hipFree(bvh->arena) != hipSuccess) status = tr_fail(TR_ERR_HIP, "hipFree(arena)");
+        tr_device_guard g;
+        if (g.enter(bvh->device) == TR_OK) {
+            if (bvh->arena && hipFree(bvh->arena) != hipSuccess) status = tr_fail(TR_ERR_HIP, "hipFree(arena)");
             if (bvh->refit_temp && hipFree(bvh->refit_temp) != hipSuccess) status = tr_fail(TR_ERR_HIP, "hipFree(refit_temp)");
             for (int k = 0; k < TR_SCHED_SLOTS; k++)
                 if (bvh->sched[k].buf && hipFree(bvh->sched[k].buf) != hipSuccess) status = tr_fail(TR_ERR_HIP, "hipFree(sched)");
@@ -270,7 +294,7 @@ int tr_bvh_get_info(const tr_bvh* bvh, tr_bvh_info* info) {
 int tr_bvh_download(const tr_bvh* bvh, void* h_nodes, void* h_links, void* h_tris, void* stream) {
     if (!bvh) return tr_fail(TR_ERR_INVALID_ARG, "bvh == NULL");
     hipStream_t s = (hipStream_t)stream;
-    DeviceGuard g;
+    tr_device_guard g;
     if (g.enter(bvh->device) != TR_OK) return tr_fail(TR_ERR_NO_DEVICE, "hipSetDevice failed");
     if (h_nodes && bvh->num_nodes)
         TR_HIP_TRY(hipMemcpyAsync(h_nodes, bvh->nodes, sizeof(tr_node) * (size_t)bvh->num_nodes, hipMemcpyDeviceToHost, s));
@@ -284,44 +308,15 @@ int tr_bvh_download(const tr_bvh* bvh, void* h_nodes, void* h_links, void* h_tri
 
 int tr_set_option(const char* name, int64_t value) {
     if (!name) return tr_fail(TR_ERR_INVALID_ARG, "name == NULL");
-    if (!strcmp(name, "persistent")) { g_options.persistent = value != 0; return TR_OK; }
-    if (!strcmp(name, "blocks_per_cu")) {
-        if (value < 1 || value > 32) return tr_fail(TR_ERR_INVALID_ARG, "blocks_per_cu out of range");
-        g_options.blocks_per_cu = (int)value;
-        return TR_OK;
-    }
-    if (!strcmp(name, "refill")) { g_options.refill = value != 0; return TR_OK; }
-    if (!strcmp(name, "adaptive")) { g_options.adaptive = value != 0; return TR_OK; }
-    if (!strcmp(name, "steal")) {   // 0 off, 1 on (threshold 64 trips), > 1: on with this trip threshold
-        if (value < 0 || value > 4096) return tr_fail(TR_ERR_INVALID_ARG, "steal out of range");
-        g_options.steal = (int)value; return TR_OK;
-    }
-    if (!strcmp(name, "tile")) {
-        if (value < 0 || value > 2) return tr_fail(TR_ERR_INVALID_ARG, "tile must be 0, 1 or 2");
-        g_options.tile = (int)value; return TR_OK;
-    }
-    if (!strcmp(name, "scramble")) { g_options.scramble = value != 0; return TR_OK; }
-    if (!strcmp(name, "build_cache")) { g_options.build_cache = value != 0; return TR_OK; }
-    if (!strcmp(name, "block_size")) {
-        if (value != 64 && value != 128 && value != 256) return tr_fail(TR_ERR_INVALID_ARG, "block_size must be 64, 128 or 256");
-        g_options.block_size = (int)value;
-        return TR_OK;
-    }
-    if (!strcmp(name, "compact")) { g_options.compact = value != 0; return TR_OK; }
-    if (!strcmp(name, "xcd_chunk")) {
-        if (value < 0 || value > 65536) return tr_fail(TR_ERR_INVALID_ARG, "xcd_chunk out of range");
-        g_options.xcd_chunk = (int)value;
-        return TR_OK;
-    }
-    if (!strcmp(name, "xcd_segments")) { g_options.xcd_segments = value != 0; return TR_OK; }
-    if (!strcmp(name, "leaf_min")) {
-        if (value < 0 || value > 64) return tr_fail(TR_ERR_INVALID_ARG, "leaf_min out of range");
-        g_options.leaf_min = (int)value;
-        return TR_OK;
-    }
-    if (!strcmp(name, "refill_min")) {
-        if (value < 1 || value > 64) return tr_fail(TR_ERR_INVALID_ARG, "refill_min out of range");
-        g_options.refill_min = (int)value;
+    for (int k = 0; k < NUM_OPTS; k++) {
+        if (strcmp(name, OPTS[k].name)) continue;
+        if (OPTS[k].boolean) value = value != 0;
+        if (value < OPTS[k].lo || value > OPTS[k].hi)
+            return tr_fail(TR_ERR_INVALID_ARG, std::string(name) + " out of range [" + std::to_string(OPTS[k].lo) +
+                                                   ", " + std::to_string(OPTS[k].hi) + "]");
+        if (!strcmp(name, "block_size") && value != 64 && value != 128 && value != 256)
+            return tr_fail(TR_ERR_INVALID_ARG, "block_size must be 64, 128 or 256");
+        g_opts.v[k].store((int)value, std::memory_order_relaxed);
         return TR_OK;
     }
     return tr_fail(TR_ERR_INVALID_ARG, std::string("unknown option: ") + name);

@@ -45,12 +45,32 @@ __global__ void k_init_bounds(uint32_t* bounds) {
     int t = threadIdx.x;
     if (t < 3) bounds[t] = 0xffffffffu;        // min (encoded)
     else if (t < 6) bounds[t] = 0u;            // max (encoded)
+    else if (t == 6) bounds[6] = 0xffffffffu;  // smallest face id with a vertex index outside [0, nv)
+}
+
+// Vertex indices of face f, range-checked against nv (the reference hands unchecked index
+// buffers to optixAccelBuild, ray.cpp:44-58).  A face with an index outside [0, nv) is never
+// dereferenced: it becomes a degenerate triangle at the origin and its id is reported through
+// `bad` (atomicMin -> the build fails with TR_ERR_INVALID_ARG naming the first such face).
+__device__ __forceinline__ bool load_face(const float* __restrict__ verts, int64_t nv,
+                                          const int32_t* __restrict__ faces, int64_t f, float* a,
+                                          float* b, float* c) {
+    const int32_t ia = faces[3 * f], ib = faces[3 * f + 1], ic = faces[3 * f + 2];
+    const bool ok = (uint64_t)(int64_t)ia < (uint64_t)nv && (uint64_t)(int64_t)ib < (uint64_t)nv &&
+                    (uint64_t)(int64_t)ic < (uint64_t)nv;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        a[k] = ok ? verts[3 * (int64_t)ia + k] : 0.f;
+        b[k] = ok ? verts[3 * (int64_t)ib + k] : 0.f;
+        c[k] = ok ? verts[3 * (int64_t)ic + k] : 0.f;
+    }
+    return ok;
 }
 
 // ---- 1. triangle boxes + mesh bounds ------------------------------------------------
 // grid-stride over the triangles; wave shuffle + LDS block reduction, then 6 atomics per
 // workgroup (one atomic per WAVE on the same six words took 1.4 ms at 1.3 M triangles)
-__global__ __launch_bounds__(256) void k_tri_bounds(const float* __restrict__ verts,
+__global__ __launch_bounds__(256) void k_tri_bounds(const float* __restrict__ verts, int64_t nv,
                                                     const int32_t* __restrict__ faces, int64_t nf,
                                                     float* __restrict__ tribox,
                                                     uint32_t* __restrict__ bounds) {
@@ -58,10 +78,8 @@ __global__ __launch_bounds__(256) void k_tri_bounds(const float* __restrict__ ve
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nf;
          i += (int64_t)gridDim.x * blockDim.x) {
-        int32_t ia = faces[3 * i], ib = faces[3 * i + 1], ic = faces[3 * i + 2];
-        const float* a = verts + 3 * (int64_t)ia;
-        const float* b = verts + 3 * (int64_t)ib;
-        const float* c = verts + 3 * (int64_t)ic;
+        float a[3], b[3], c[3];
+        if (!load_face(verts, nv, faces, i, a, b, c)) atomicMin(&bounds[6], (uint32_t)i);
         float l[3], h[3];
         tr_tri_box(a[0], a[1], a[2], b[0], b[1], b[2], c[0], c[1], c[2], l, h);
         float* o = tribox + 6 * i;
@@ -228,7 +246,7 @@ __global__ __launch_bounds__(64 * RS_WAVES) void k_rs_scatter(
 }
 
 // ---- 4. gather Morton-ordered triangle records -------------------------------------------
-__global__ __launch_bounds__(256) void k_gather(const float* __restrict__ verts,
+__global__ __launch_bounds__(256) void k_gather(const float* __restrict__ verts, int64_t nv,
                                                 const int32_t* __restrict__ faces,
                                                 const uint32_t* __restrict__ order, int64_t nf,
                                                 tr_tri* __restrict__ tris,
@@ -236,9 +254,8 @@ __global__ __launch_bounds__(256) void k_gather(const float* __restrict__ verts,
     int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nf) return;
     int64_t f = order[k];
-    const float* a = verts + 3 * (int64_t)faces[3 * f];
-    const float* b = verts + 3 * (int64_t)faces[3 * f + 1];
-    const float* c = verts + 3 * (int64_t)faces[3 * f + 2];
+    float a[3], b[3], c[3];
+    load_face(verts, nv, faces, f, a, b, c);   // bad faces were reported by k_tri_bounds
     tr_tri t;
     t.ax = a[0]; t.ay = a[1]; t.az = a[2];
     t.bx = b[0]; t.by = b[1]; t.bz = b[2];
@@ -320,15 +337,15 @@ __global__ __launch_bounds__(256) void k_emit(const int32_t* __restrict__ childL
 }
 
 // ---- refit (same topology, new vertex positions) ------------------------------------------------
-__global__ __launch_bounds__(256) void k_regather(const float* __restrict__ verts,
+__global__ __launch_bounds__(256) void k_regather(const float* __restrict__ verts, int64_t nv,
                                                   const int32_t* __restrict__ faces, int64_t nf,
-                                                  tr_tri* __restrict__ tris, float* __restrict__ sbox) {
+                                                  tr_tri* __restrict__ tris, float* __restrict__ sbox,
+                                                  uint32_t* __restrict__ bad) {
     int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nf) return;
     const int64_t f = tris[k].face;
-    const float* a = verts + 3 * (int64_t)faces[3 * f];
-    const float* b = verts + 3 * (int64_t)faces[3 * f + 1];
-    const float* c = verts + 3 * (int64_t)faces[3 * f + 2];
+    float a[3], b[3], c[3];
+    if (!load_face(verts, nv, faces, f, a, b, c)) atomicMin(bad, (uint32_t)f);
     tr_tri t;
     t.ax = a[0]; t.ay = a[1]; t.az = a[2];
     t.bx = b[0]; t.by = b[1]; t.bz = b[2];
@@ -407,9 +424,13 @@ static size_t carve_arena(tr_bvh* bvh, char* base, int64_t nf) {
 // (re)allocate the arena for `nf` triangles and point nodes/links/tris into it
 int tr_arena_alloc(tr_bvh* bvh, int64_t nf) {
     if (!bvh->arena || bvh->capacity_tris < nf) {
-        if (bvh->arena) { TR_HIP_TRY(hipFree(bvh->arena)); bvh->arena = nullptr; }
+        // the new arena first: if it cannot be had, the handle keeps a consistent (old) state;
+        // the caller resets the hierarchy on any build failure
         size_t bytes = carve_arena(bvh, nullptr, nf);
-        TR_HIP_TRY(hipMalloc(&bvh->arena, bytes));
+        void* fresh = nullptr;
+        TR_HIP_TRY(hipMalloc(&fresh, bytes));
+        if (bvh->arena) (void)hipFree(bvh->arena);   // hipFree synchronises: no launch still reads it
+        bvh->arena = fresh;
         bvh->arena_bytes = (int64_t)bytes;
         bvh->capacity_tris = nf;
     }
@@ -417,13 +438,30 @@ int tr_arena_alloc(tr_bvh* bvh, int64_t nf) {
     return TR_OK;
 }
 
+int64_t tr_arena_used_bytes(int64_t nf) { return (int64_t)carve_arena(nullptr, nullptr, nf); }
+
+void tr_bvh_reset(tr_bvh* bvh) {
+    bvh->num_tris = 0; bvh->num_nodes = 0; bvh->depth = 0; bvh->key_mode = 0;
+    for (int k = 0; k < 3; k++) { bvh->aabb_min[k] = 0.f; bvh->aabb_max[k] = 0.f; }
+    for (int k = 0; k < TR_SCHED_SLOTS; k++) bvh->sched[k].nblocks = 0;
+}
+
 int tr_build_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_t* d_faces,
                   int64_t nf, hipStream_t stream) {
     if (nf < 0 || nv < 0) return tr_fail(TR_ERR_INVALID_ARG, "negative mesh size");
     if (nf >= (int64_t)1 << 31) return tr_fail(TR_ERR_INVALID_ARG, "more than 2^31-1 triangles");
-    if (nf > 0 && (!d_vertices || !d_faces)) return tr_fail(TR_ERR_INVALID_ARG, "null mesh pointer");
+    // an empty vertex array may be NULL: every face is then out of range and reported as such
+    if (nf > 0 && (!d_faces || (!d_vertices && nv > 0))) return tr_fail(TR_ERR_INVALID_ARG, "null mesh pointer");
 
-    TR_TRY(tr_arena_alloc(bvh, nf));
+    {
+        const int as = tr_arena_alloc(bvh, nf);
+        if (as != TR_OK) {
+            const std::string msg = tr_last_error();
+            tr_bvh_reset(bvh);
+            tr_set_error(msg);
+            return as;
+        }
+    }
     bvh->num_tris = nf;
     bvh->num_nodes = nf >= 2 ? nf - 1 : 0;
     bvh->depth = 0;
@@ -472,16 +510,17 @@ int tr_build_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_
     const unsigned gF = (unsigned)cdiv(nf, TB);
 
     hipLaunchKernelGGL(k_init_bounds, dim3(1), dim3(64), 0, stream, bounds);
-    hipLaunchKernelGGL(k_tri_bounds, dim3(gF < 1024u ? gF : 1024u), dim3(TB), 0, stream, d_vertices, d_faces, nf, tribox, bounds);
+    hipLaunchKernelGGL(k_tri_bounds, dim3(gF < 1024u ? gF : 1024u), dim3(TB), 0, stream, d_vertices, nv, d_faces, nf, tribox, bounds);
     check(hipGetLastError(), "k_tri_bounds");
     // mesh bounds back to the host; completes with the first synchronisation below
     uint32_t hb[8] = {0};
-    check(hipMemcpyAsync(hb, bounds, sizeof(uint32_t) * 6, hipMemcpyDeviceToHost, stream), "memcpy bounds");
+    hb[6] = 0xffffffffu;
+    check(hipMemcpyAsync(hb, bounds, sizeof(uint32_t) * 7, hipMemcpyDeviceToHost, stream), "memcpy bounds");
 
     if (nf == 1) {
         // single triangle: no hierarchy; queries use the brute-force kernel
         hipLaunchKernelGGL(k_morton, dim3(gF), dim3(TB), 0, stream, tribox, nf, bounds, k0, v0);
-        hipLaunchKernelGGL(k_gather, dim3(gF), dim3(TB), 0, stream, d_vertices, d_faces, v0, nf, bvh->tris, sbox);
+        hipLaunchKernelGGL(k_gather, dim3(gF), dim3(TB), 0, stream, d_vertices, nv, d_faces, v0, nf, bvh->tris, sbox);
         check(hipGetLastError(), "k_gather");
     } else {
         hipLaunchKernelGGL(k_morton, dim3(gF), dim3(TB), 0, stream, tribox, nf, bounds, k0, v0);
@@ -500,7 +539,7 @@ int tr_build_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_
         }
         check(hipGetLastError(), "radix sort");
         // after 8 passes the sorted data is back in (k0, v0) == (kin, vin)
-        hipLaunchKernelGGL(k_gather, dim3(gF), dim3(TB), 0, stream, d_vertices, d_faces, vin, nf, bvh->tris, sbox);
+        hipLaunchKernelGGL(k_gather, dim3(gF), dim3(TB), 0, stream, d_vertices, nv, d_faces, vin, nf, bvh->tris, sbox);
         check(hipGetLastError(), "k_gather");
 
         const int64_t ni = nf - 1;
@@ -534,8 +573,10 @@ int tr_build_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_
                 check(hipGetLastError(), "k_emit");
                 check(hipMemcpyAsync(&root_ready, ready, sizeof(int32_t), hipMemcpyDeviceToHost, stream), "memcpy root");
                 check(hipStreamSynchronize(stream), "sync refit");
+                if (status == TR_OK && hb[6] != 0xffffffffu) break;   // malformed mesh: reported below
                 batch = 8;
             }
+            if (hb[6] != 0xffffffffu) break;
             if (status != TR_OK) break;
             if (root_ready == 0) { status = tr_fail(TR_ERR_INTERNAL, "refit did not reach the root"); break; }
             bvh->depth = root_ready;
@@ -546,6 +587,9 @@ int tr_build_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_
     }
     // drain the stream before the temporaries are handed back
     check(hipStreamSynchronize(stream), "sync build");
+    if (status == TR_OK && hb[6] != 0xffffffffu)
+        status = tr_fail(TR_ERR_INVALID_ARG, "face " + std::to_string(hb[6]) + " has a vertex index outside [0, " +
+                                                 std::to_string(nv) + ")");
     if (status == TR_OK) {
         for (int k = 0; k < 3; k++) {
             uint32_t e0 = hb[k], e1 = hb[3 + k];
@@ -557,7 +601,11 @@ int tr_build_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_
     }
     int rs = tr_build_temp_release(st);   // the stream is drained: the next build may reuse the buffer
     if (rs != TR_OK && status == TR_OK) status = rs;
-    (void)nv;
+    if (status != TR_OK) {   // never leave a half-built hierarchy reachable (keep the error message)
+        const std::string msg = tr_last_error();
+        tr_bvh_reset(bvh);
+        tr_set_error(msg);
+    }
     return status;
 }
 
@@ -570,10 +618,11 @@ int tr_refit_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_
     if (nf != bvh->num_tris) return tr_fail(TR_ERR_INVALID_ARG, "refit needs the same number of faces as the build");
     if (nf == 0) return TR_OK;
     if (!d_vertices || !d_faces) return tr_fail(TR_ERR_INVALID_ARG, "null mesh pointer");
-    (void)nv;
+    if (nv < 0) return tr_fail(TR_ERR_INVALID_ARG, "negative mesh size");
     const int64_t ni = bvh->num_nodes;
     Carver tc{nullptr};
     tc.take<float>(6 * (size_t)nf); tc.take<float>(6 * (size_t)(ni > 0 ? ni : 1)); tc.take<int32_t>((size_t)(ni > 0 ? ni : 1));
+    tc.take<uint32_t>(4);
     const size_t need = align_up(tc.off, 256);
     if (bvh->refit_temp_bytes < need) {
         if (bvh->refit_temp) { TR_HIP_TRY(hipFree(bvh->refit_temp)); bvh->refit_temp = nullptr; bvh->refit_temp_bytes = 0; }
@@ -584,14 +633,18 @@ int tr_refit_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_
     float* sbox = c2.take<float>(6 * (size_t)nf);
     float* ibox = c2.take<float>(6 * (size_t)(ni > 0 ? ni : 1));
     int32_t* ready = c2.take<int32_t>((size_t)(ni > 0 ? ni : 1));
+    uint32_t* bad = c2.take<uint32_t>(4);   // smallest face id with an out-of-range vertex index
+    uint32_t hbad = 0xffffffffu;
     int status = TR_OK;
     auto check = [&](hipError_t e, const char* what) {
         if (e != hipSuccess && status == TR_OK)
             status = tr_fail(TR_ERR_HIP, std::string(what) + ": " + hipGetErrorName(e));
     };
     const int TB = 256;
-    hipLaunchKernelGGL(k_regather, dim3((unsigned)cdiv(nf, TB)), dim3(TB), 0, stream, d_vertices, d_faces, nf, bvh->tris, sbox);
+    check(hipMemsetAsync(bad, 0xff, sizeof(uint32_t), stream), "memset bad-face word");
+    hipLaunchKernelGGL(k_regather, dim3((unsigned)cdiv(nf, TB)), dim3(TB), 0, stream, d_vertices, nv, d_faces, nf, bvh->tris, sbox, bad);
     check(hipGetLastError(), "k_regather");
+    check(hipMemcpyAsync(&hbad, bad, sizeof(uint32_t), hipMemcpyDeviceToHost, stream), "memcpy bad-face word");
     if (ni > 0) {
         const unsigned gI = (unsigned)cdiv(ni, TB);
         check(hipMemsetAsync(ready, 0, sizeof(int32_t) * (size_t)ni, stream), "memset ready");
@@ -610,6 +663,14 @@ int tr_refit_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_
         check(hipStreamSynchronize(stream), "sync refit");
         if (status == TR_OK)
             for (int k = 0; k < 3; k++) { bvh->aabb_min[k] = box[k]; bvh->aabb_max[k] = box[3 + k]; }
+    }
+    if (status == TR_OK && hbad != 0xffffffffu)
+        status = tr_fail(TR_ERR_INVALID_ARG, "face " + std::to_string(hbad) + " has a vertex index outside [0, " +
+                                                 std::to_string(nv) + ")");
+    if (status != TR_OK) {   // the triangle records are partly rewritten: drop the hierarchy
+        const std::string msg = tr_last_error();
+        tr_bvh_reset(bvh);
+        tr_set_error(msg);
     }
     return status;
 }

@@ -89,10 +89,36 @@ int tr_build_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_
                   int64_t nf, hipStream_t stream);
 
 int tr_arena_alloc(tr_bvh* bvh, int64_t nf);
+// bytes of the arena that `nf` triangles actually use (<= arena_bytes, the capacity)
+int64_t tr_arena_used_bytes(int64_t nf);
+// forget the current hierarchy: queries on the handle return misses (used when a build or
+// refit fails half way, so that nothing ever traverses a half-written arena)
+void tr_bvh_reset(tr_bvh* bvh);
 int tr_refit_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_t* d_faces,
                   int64_t nf, hipStream_t stream);
 
+// Makes `device` current for the lifetime of the guard (every entry point that launches on or
+// copies from a handle's arena runs under one: a C caller may be on another current device).
+struct tr_device_guard {
+    int prev = -1;
+    bool changed = false;
+    int enter(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) return TR_ERR_NO_DEVICE;
+        if (prev != device) {
+            if (hipSetDevice(device) != hipSuccess) return TR_ERR_NO_DEVICE;
+            changed = true;
+        }
+        return TR_OK;
+    }
+    ~tr_device_guard() {
+        if (changed) (void)hipSetDevice(prev);
+    }
+};
+
 // options ---------------------------------------------------------------------------------
+// Process-wide tuning knobs (tr_set_option).  Stored as relaxed atomics; every entry point takes
+// ONE snapshot (tr_opts()) and works from that copy, so a concurrent tr_set_option can never be
+// seen half-way through a launch decision.
 struct tr_options {
     int persistent = 0;
     int blocks_per_cu = 8;
@@ -109,4 +135,4 @@ struct tr_options {
     int build_cache = 1;  // keep the builder's temporaries (about 130 B/triangle) per device between builds
     int leaf_min = 0;     // refill kernel only: lanes with a queued leaf that fire its leaf phase (0 = any)
 };
-tr_options& tr_opts();
+tr_options tr_opts();   // snapshot by value

@@ -11,6 +11,8 @@
 //                work counter (option, not faster at the measured sizes); `refill` adds
 //                per-lane refill ("active-ray repacking", experimental, slower).
 // Kernel parameters travel by value (no per-call malloc/memcpy/free as in ray.cpp:279-287).
+#include <atomic>
+
 #include "tr_internal.h"
 
 namespace {
@@ -190,8 +192,12 @@ __device__ __forceinline__ bool wave_traverse_steal(const tr_bvh_view& b, tr_ray
             if (res.best_face >= 0) vsum[owner] = 1;      // any hit of any worker
         } else {
             const bool have = res.best_slot >= 0;
-            const unsigned long long key = ((unsigned long long)__float_as_uint(res.best_t) << 32) |
-                                           (unsigned)res.best_face;   // t_key >= 0: bits order like values
+            // t_key >= 0, but tr_tri_mt can return -0.0f (a ray that starts exactly in a triangle's
+            // plane): its bit pattern 0x80000000 would sort above every positive distance while
+            // tr_closer treats it as equal to +0.0f.  Dropping the sign bit is exact for t_key >= 0
+            // and makes the integer order of the key the (t_key, face) order of tr_closer.
+            const unsigned long long key = ((unsigned long long)(__float_as_uint(res.best_t) & 0x7fffffffu) << 32) |
+                                           (unsigned)res.best_face;
             if (have) atomicMin(&keys[owner], key);
             __builtin_amdgcn_wave_barrier();
             if (have && vkeys[owner] == key) vslots[owner] = res.best_slot;   // faces are distinct: one winner
@@ -813,18 +819,37 @@ tr_bvh_view make_view(const tr_bvh* bvh) {
     return v;
 }
 
+// Every query runs on the device that owns the BVH arena, whatever device is current in the
+// calling thread (tr_device_guard restores it), and refuses rays that live on another GPU:
+// the kernel would dereference them (or the arena) across devices -- a memory fault that kills
+// the process, or silent peer traffic.  The pointer query is skipped when the caller is already
+// on the handle's device (the common, checked-by-the-binding case costs nothing extra).
+int enter_bvh_device(const tr_bvh* bvh, const tr_rays* rays, tr_device_guard* guard) {
+    if (guard->enter(bvh->device) != TR_OK) return tr_fail(TR_ERR_NO_DEVICE, "hipSetDevice failed");
+    if (guard->changed && rays && rays->nray > 0) {
+        for (const float* p : {rays->d_origins, rays->d_directions}) {
+            hipPointerAttribute_t attr;
+            if (hipPointerGetAttributes(&attr, p) != hipSuccess) { (void)hipGetLastError(); continue; }
+            if (attr.type == hipMemoryTypeDevice && attr.device != bvh->device)
+                return tr_fail(TR_ERR_INVALID_ARG, "rays are on device " + std::to_string(attr.device) +
+                                                       " but the BVH lives on device " + std::to_string(bvh->device));
+        }
+    }
+    return TR_OK;
+}
+
 // Adaptive launch order: the blocks of the previous launch on the same (handle, stream) with the
 // same block count are started most-expensive-first, so the longest rays of a batch -- its
 // critical path -- do not start last.  Hints never affect results; each stream has its own
 // buffers, so overlapping launches cannot see a half-written order.  Returns cost != NULL when
 // this launch should record block costs (and be followed by k_sched_sort), order != NULL when a
 // measured order exists for this block count.
-void sched_acquire(const tr_bvh* bvh, hipStream_t stream, int64_t nblocks, const uint32_t** order,
-                   uint32_t** cost) {
+void sched_acquire(const tr_bvh* bvh, const tr_options& opt, hipStream_t stream, int64_t nblocks,
+                   const uint32_t** order, uint32_t** cost) {
     *order = nullptr;
     *cost = nullptr;
     tr_bvh* mb = const_cast<tr_bvh*>(bvh);
-    if (!tr_opts().adaptive || !mb->sched_mutex || nblocks < 64 || nblocks > TR_SCHED_MAX) return;
+    if (!opt.adaptive || !mb->sched_mutex || nblocks < 64 || nblocks > TR_SCHED_MAX) return;
     tr_sched_slot* slot = nullptr;
     std::lock_guard<std::mutex> lock(*mb->sched_mutex);
     for (int k = 0; k < TR_SCHED_SLOTS && !slot; k++)
@@ -857,23 +882,27 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
     RayFetch rf;
     TR_TRY(make_fetch(rays, &rf));
     if (rf.n == 0) return TR_OK;
+    tr_device_guard guard;
+    TR_TRY(enter_bvh_device(bvh, rays, &guard));
     tr_device_state* st;
     TR_TRY(tr_get_device_state(bvh->device, &st));
     tr_bvh_view view = make_view(bvh);
-    const tr_options& opt = tr_opts();
+    const tr_options opt = tr_opts();   // one snapshot per call
     const int bs = opt.block_size;
     const int64_t nblocks_direct = (rf.n + bs - 1) / bs;
     int64_t pgrid = (int64_t)st->num_cus * opt.blocks_per_cu;
     if (opt.persistent && Q != TR_Q_LOCATION) {   // the multi-hit list query has only the direct shape
         // size the persistent grid by what is actually resident (4 waves per block = 1 per SIMD)
-        static int occ_refill = 0, occ_plain = 0;   // per instantiation <Q, STATS>
-        int& occ = opt.refill ? occ_refill : occ_plain;
+        static std::atomic<int> occ_refill{0}, occ_plain{0};   // per instantiation <Q, STATS>
+        std::atomic<int>& occ_a = opt.refill ? occ_refill : occ_plain;
+        int occ = occ_a.load(std::memory_order_relaxed);
         if (occ == 0) {
             int nb = 0;
             hipError_t e = opt.refill
                 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_query_refill<Q, STATS>, 256, 0)
                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_query_persistent<Q, STATS>, 256, 0);
             occ = (e == hipSuccess && nb > 0) ? nb : 4;
+            occ_a.store(occ, std::memory_order_relaxed);
         }
         int bpc = opt.blocks_per_cu < occ ? opt.blocks_per_cu : occ;
         pgrid = (int64_t)st->num_cus * bpc;
@@ -894,7 +923,7 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
                              bvh->num_tris * (int64_t)sizeof(tr_tri) < ((int64_t)1 << 32);
         const uint32_t* order = nullptr;
         uint32_t* cost = nullptr;
-        if (!STATS) sched_acquire(bvh, stream, nblocks_direct, &order, &cost);
+        if (!STATS) sched_acquire(bvh, opt, stream, nblocks_direct, &order, &cost);
         // chunk size of the XCD map: the option is in units of 256 rays; at least 4 chunks per
         // XCD so that the XCDs' shares of an uneven image stay comparable
         int xc = opt.xcd_chunk * (256 / bs);
@@ -1041,6 +1070,8 @@ int tr_intersects_location_fill(const tr_bvh* bvh, const tr_rays* rays, int32_t 
     TR_TRY(make_fetch(rays, &rf));
     if (rf.n == 0 || cap == 0) return TR_OK;
     if (!d_offsets) return tr_fail(TR_ERR_INVALID_ARG, "d_offsets == NULL");
+    tr_device_guard guard;
+    TR_TRY(enter_bvh_device(bvh, rays, &guard));
     tr_bvh_view view = make_view(bvh);
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)((rf.n + 255) / 256)), block(256);
@@ -1075,6 +1106,8 @@ int tr_location_fill_slots(const tr_bvh* bvh, const tr_rays* rays, int32_t cap, 
     TR_TRY(make_fetch(rays, &rf));
     if (rf.n == 0) return TR_OK;
     if (!d_count || !d_offsets || !d_hits) return tr_fail(TR_ERR_INVALID_ARG, "null input pointer");
+    tr_device_guard guard;
+    TR_TRY(enter_bvh_device(bvh, rays, &guard));
     tr_bvh_view view = make_view(bvh);
     const int64_t threads = rf.n * cap;
     hipLaunchKernelGGL(k_fill_list, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,

@@ -190,10 +190,16 @@ def make_rays(origins: torch.Tensor, dirs: torch.Tensor) -> TrRays:
     return r
 
 
-def _handle(accel_structure):
+def _handle(accel_structure, rays_tensor=None):
     h = accel_structure._inner
     if not h:
         raise RuntimeError("acceleration structure has not been built")
+    if rays_tensor is not None:
+        # the kernels dereference both the rays and the BVH arena: they must share a GPU
+        bdev = getattr(accel_structure, "device_index", None)
+        if bdev is not None and rays_tensor.device.index != bdev:
+            raise ValueError(f"rays are on {rays_tensor.device} but the acceleration structure lives on "
+                             f"cuda:{bdev}; move the rays or build the intersector on that device")
     return h
 
 
@@ -203,7 +209,7 @@ def intersects_any(accel_structure, origins, dirs) -> torch.Tensor:
     check_rays(origins, dirs)
     out = torch.empty(origins.shape[:-1], dtype=torch.bool, device=origins.device)
     with torch.cuda.device(origins.device):
-        _check(get_module().tr_intersects_any(_handle(accel_structure), C.byref(make_rays(origins, dirs)),
+        _check(get_module().tr_intersects_any(_handle(accel_structure, origins), C.byref(make_rays(origins, dirs)),
                                               out.data_ptr(), _stream_ptr(origins.device)))
     return out
 
@@ -213,7 +219,7 @@ def intersects_first(accel_structure, origins, dirs) -> torch.Tensor:
     check_rays(origins, dirs)
     out = torch.empty(origins.shape[:-1], dtype=torch.int32, device=origins.device)
     with torch.cuda.device(origins.device):
-        _check(get_module().tr_intersects_first(_handle(accel_structure), C.byref(make_rays(origins, dirs)),
+        _check(get_module().tr_intersects_first(_handle(accel_structure, origins), C.byref(make_rays(origins, dirs)),
                                                 out.data_ptr(), _stream_ptr(origins.device)))
     return out
 
@@ -229,7 +235,7 @@ def intersects_closest(accel_structure, origins, dirs) -> Tuple[torch.Tensor, ..
     uv = torch.empty((*b, 2), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _check(get_module().tr_intersects_closest(
-            _handle(accel_structure), C.byref(make_rays(origins, dirs)), hit.data_ptr(), front.data_ptr(),
+            _handle(accel_structure, origins), C.byref(make_rays(origins, dirs)), hit.data_ptr(), front.data_ptr(),
             tri.data_ptr(), loc.data_ptr(), uv.data_ptr(), _stream_ptr(dev)))
     return hit, front, tri, loc, uv
 
@@ -239,7 +245,7 @@ def intersects_count(accel_structure, origins, dirs) -> torch.Tensor:
     check_rays(origins, dirs)
     out = torch.empty(origins.shape[:-1], dtype=torch.int32, device=origins.device)
     with torch.cuda.device(origins.device):
-        _check(get_module().tr_intersects_count(_handle(accel_structure), C.byref(make_rays(origins, dirs)),
+        _check(get_module().tr_intersects_count(_handle(accel_structure, origins), C.byref(make_rays(origins, dirs)),
                                                 out.data_ptr(), _stream_ptr(origins.device)))
     return out
 
@@ -262,7 +268,7 @@ def intersects_location(accel_structure, origins, dirs, ray_base: int = 0, fused
             rays = make_rays(origins, dirs)
             count = torch.empty(n, dtype=torch.int32, device=dev)
             slots = torch.empty((n, MAX_ANYHIT_SIZE, 2), dtype=torch.int32, device=dev)   # tr_hit_entry {t_key, slot}
-            _check(lib.tr_intersects_count_topk(_handle(accel_structure), C.byref(rays), MAX_ANYHIT_SIZE,
+            _check(lib.tr_intersects_count_topk(_handle(accel_structure, origins), C.byref(rays), MAX_ANYHIT_SIZE,
                                                 count.data_ptr(), slots.data_ptr(), stream))
             offsets = torch.empty(n, dtype=torch.int64, device=dev)
             total_d = torch.empty(1, dtype=torch.int64, device=dev)
@@ -273,7 +279,7 @@ def intersects_location(accel_structure, origins, dirs, ray_base: int = 0, fused
             loc = torch.empty((nhits, 3), dtype=torch.float32, device=dev)
             tri = torch.empty(nhits, dtype=torch.int32, device=dev)
             ray = torch.empty(nhits, dtype=torch.int32, device=dev)
-            _check(lib.tr_location_fill_slots(_handle(accel_structure), C.byref(rays), MAX_ANYHIT_SIZE,
+            _check(lib.tr_location_fill_slots(_handle(accel_structure, origins), C.byref(rays), MAX_ANYHIT_SIZE,
                                               count.data_ptr(), offsets.data_ptr(), slots.data_ptr(),
                                               loc.data_ptr(), ray.data_ptr(), tri.data_ptr(), ray_base, stream))
         return loc, ray, tri
@@ -281,7 +287,7 @@ def intersects_location(accel_structure, origins, dirs, ray_base: int = 0, fused
         stream = _stream_ptr(dev)
         rays = make_rays(origins, dirs)
         count = torch.empty(n, dtype=torch.int32, device=dev)
-        _check(lib.tr_intersects_count(_handle(accel_structure), C.byref(rays), count.data_ptr(), stream))
+        _check(lib.tr_intersects_count(_handle(accel_structure, origins), C.byref(rays), count.data_ptr(), stream))
         offsets = torch.empty(n, dtype=torch.int64, device=dev)
         total_d = torch.empty(1, dtype=torch.int64, device=dev)
         total = C.c_int64(0)
@@ -291,7 +297,7 @@ def intersects_location(accel_structure, origins, dirs, ray_base: int = 0, fused
         loc = torch.empty((nhits, 3), dtype=torch.float32, device=dev)
         tri = torch.empty(nhits, dtype=torch.int32, device=dev)
         ray = torch.empty(nhits, dtype=torch.int32, device=dev)
-        _check(lib.tr_intersects_location_fill(_handle(accel_structure), C.byref(rays), MAX_ANYHIT_SIZE,
+        _check(lib.tr_intersects_location_fill(_handle(accel_structure, origins), C.byref(rays), MAX_ANYHIT_SIZE,
                                                offsets.data_ptr(), loc.data_ptr(), ray.data_ptr(),
                                                tri.data_ptr(), ray_base, stream))
     return loc, ray, tri
@@ -327,7 +333,7 @@ def trace_stats_closest(accel_structure, origins, dirs) -> dict:
     check_rays(origins, dirs)
     st = TrTraceStats()
     with torch.cuda.device(origins.device):
-        _check(get_module().tr_trace_stats_closest(_handle(accel_structure), C.byref(make_rays(origins, dirs)),
+        _check(get_module().tr_trace_stats_closest(_handle(accel_structure, origins), C.byref(make_rays(origins, dirs)),
                                                    C.byref(st), _stream_ptr(origins.device)))
     return dict(rays=st.rays, node_visits=st.node_visits, tri_tests=st.tri_tests, climb_steps=st.climb_steps)
 

@@ -205,6 +205,7 @@ class OptixAccelStructureWrapper:
 
     def __init__(self):
         self._inner = None
+        self.device_index = None   # GPU that owns the arena (queries check the rays against it)
 
     def __del__(self):
         try:
@@ -235,6 +236,7 @@ class OptixAccelStructureWrapper:
                 hops._check(lib.tr_bvh_build(vertices.data_ptr(), vertices.shape[0], faces.data_ptr(),
                                              faces.shape[0], stream, C.byref(handle)))
                 self._inner = handle.value
+        self.device_index = vertices.device.index
 
     def refit(self, vertices: torch.Tensor, faces: torch.Tensor):
         if not self._inner:
@@ -259,6 +261,7 @@ class OptixAccelStructureWrapper:
             hops._check(hops.get_module().tr_bvh_deserialize(blob.ctypes.data, blob.nbytes,
                                                              torch.cuda.current_stream(device).cuda_stream, C.byref(handle)))
         self._inner = handle.value
+        self.device_index = self.info()["device"]
 
     def info(self) -> dict:
         inf = hops.TrBvhInfo()
