@@ -1,19 +1,31 @@
 #!/usr/bin/env python3
 """Headline benchmark: Mrays/s closest-hit, 1M-tri mesh, 1024^2 ray batch (BASELINE.json).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c5i|c5ii]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A step = one `RayMeshIntersector.intersects_closest` call (the reference's timed call,
-test/performance_test.py:54-57) over one 1024x1024 pinhole ray batch against the 1 310 720-
-triangle headline mesh; rays and BVH are resident in HBM before the
-timed region.  With N > 1 every rank owns a BVH replica and its own 1024^2-ray shard (weak
-scaling; the path has no exchange step -- `--gather` adds the RCCL gather of the results to
-rank 0 to the timed region).  Rank 0 prints ONE JSON line.
+test/performance_test.py:54-57); rays and BVH are resident in HBM before the timed region.
+
+Workloads
+  c5i  (default, the metric's config): one 1024x1024 pinhole ray batch per GPU against the
+       1 310 720-triangle headline mesh.  N > 1: every rank owns a BVH replica
+       and its own 1024^2 batch -> "scaling": "weak" (`--gather` adds the RCCL gather of the
+       results to rank 0 to the timed region).
+  c5ii (BASELINE.json config 5): ONE batch of 100 000 000 hash rays (seed 99) split into N
+       contiguous shards (triro.ray.sharded.shard_bounds), BVH replicated, results gathered to
+       rank 0 INSIDE the timed region -> "scaling": "strong".
+
+`--gpus N` with N > 1 and no launcher environment: this process never touches the GPU; it checks
+that N devices are visible, starts N ranks with `python -m torch.distributed.run` (one per GPU,
+RCCL) as a child process and relays rank 0's JSON line.  Under a launcher (RANK/WORLD_SIZE set)
+it is one of those ranks.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,35 +33,81 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "trimesh-ray-optix_amd"))
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
-import workloads as W  # noqa: E402
-
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s spec (6.29 TB/s achievable)
+GATHER_PEAK_GBPS = 8500.0       # profiles/r01_gather64.jsonl: random 64-B records from a 147 MB table, 8.3-8.8 TB/s
 BYTES_PER_RAY_CLOSEST = 50      # 24 B in + 26 B out
+C5II_RAYS = 100_000_000
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--workload", choices=["c5i", "c5ii"], default="c5i")
     ap.add_argument("--subdiv", type=int, default=8, help="icosphere subdivisions (8 = 1 310 720 tris)")
-    ap.add_argument("--res", type=int, default=1024, help="ray grid is res x res")
-    ap.add_argument("--rays", choices=["pinhole", "hash"], default="pinhole")
-    ap.add_argument("--gather", action="store_true", help="gather results to rank 0 inside the timed region")
+    ap.add_argument("--res", type=int, default=1024, help="c5i: ray grid is res x res")
+    ap.add_argument("--rays", choices=["pinhole", "hash"], default="pinhole", help="c5i ray family")
+    ap.add_argument("--total-rays", type=int, default=C5II_RAYS, help="c5ii: size of the one sharded batch")
+    ap.add_argument("--gather", action="store_true", help="c5i: gather results to rank 0 inside the timed region")
+    ap.add_argument("--min-warmup-ms", type=float, default=50.0, help="keep warming up until this much time has passed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--persistent", type=int, default=None)
-    ap.add_argument("--blocks-per-cu", type=int, default=None)
+    ap.add_argument("--no-companions", action="store_true", help="skip the cold / moving-camera / gather-ceiling companions")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (tr_set_option)")
     ap.add_argument("--stats", action="store_true", help="also print traversal counters (diagnostic kernel)")
-    return ap.parse_args()
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo = launcher/sharding self-test on CPU with --stub (measures nothing)")
+    ap.add_argument("--stub", default=None, help="module:factory of a stand-in tracer (only with --backend gloo; tests)")
+    return ap.parse_args(argv)
 
 
+# ---- launcher --------------------------------------------------------------------------------
+def free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv) -> int:
+    """Parent of an N-rank run.  Touches no GPU (device_count() does not initialise HIP on this
+    image); the ranks are fresh child processes started by torch.distributed.run."""
+    n = args.gpus
+    if args.backend == "nccl":
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"bench.py: --gpus {n} needs {n} visible GPUs, this node shows {have}; "
+                  f"refusing to report an {n}-GPU number from fewer devices", file=sys.stderr)
+            return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes on this driver)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, env=env)
+    line = None
+    for ln in proc.stdout:
+        if ln.startswith('{"metric"'):
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if rc != 0:
+        print(f"bench.py: the {n}-rank run failed (exit code {rc})", file=sys.stderr)
+        return rc
+    if line is None:
+        print("bench.py: rank 0 printed no result line", file=sys.stderr)
+        return 1
+    print(line, flush=True)
+    return 0
+
+
+# ---- CPU baseline ----------------------------------------------------------------------------
 def cpu_baseline(v, f, o, d, budget_s=20.0):
     """The oracle's BVH mode ("port": our CPU restatement, NOT Embree -- trimesh/pyembree are
     not installed in this image) on the host cores, same mesh, same rays, bounded time."""
+    import numpy as np
     from oracle.oracle import OracleIntersector, num_threads
     try:   # BASELINE.md 4(1): trimesh + Embree if the GPU box happens to have them
         import trimesh  # noqa: F401
@@ -83,108 +141,181 @@ def cpu_baseline(v, f, o, d, budget_s=20.0):
             break
     return {"value": round(len(o) * passes / el / 1e6, 3), "unit": "Mrays/s", "cores": num_threads(),
             "kind": "port",
-            "sample": f"full {len(o)}-ray batch x {passes} passes, oracle median-split BVH + contract "
+            "sample": f"{len(o)}-ray sample of the workload x {passes} passes, oracle median-split BVH + contract "
                       f"arithmetic, OpenMP over {num_threads()} host threads"}
 
 
-def main():
-    args = parse()
+# ---- one rank --------------------------------------------------------------------------------
+def rotate_y(x, deg):
+    import numpy as np
+    a = np.radians(deg)
+    c, s = np.float32(np.cos(a)), np.float32(np.sin(a))
+    out = x.copy()
+    out[..., 0] = c * x[..., 0] + s * x[..., 2]
+    out[..., 2] = -s * x[..., 0] + c * x[..., 2]
+    return out
+
+
+def run_rank(args):
+    import numpy as np
+    import torch
+    import workloads as W
+    from triro.ray.sharded import ShardedRayMeshIntersector, shard_bounds
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist_on = "RANK" in os.environ and "WORLD_SIZE" in os.environ   # launched by torch.distributed.run
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    stub = args.backend == "gloo"
+    if stub:
+        if not args.stub:
+            raise SystemExit("--backend gloo is the CPU self-test of the launcher / sharding path and needs --stub")
+        dev = torch.device("cpu")
+    else:
+        if args.stub:
+            raise SystemExit("--stub is only accepted with --backend gloo (a stand-in tracer is never measured)")
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    dist = None
     if dist_on:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if stub:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+        world = dist.get_world_size()          # the ranks the communicator actually has
+        if world != args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks; reporting n_gpus={world}",
+                  file=sys.stderr)
+    elif args.gpus != 1:
+        raise SystemExit("internal error: run_rank with --gpus > 1 outside a launcher")
 
-    import triro.backend.ops as hops
-    from triro.ray.ray_optix import RayMeshIntersector
-    if args.persistent is not None:
-        hops.set_option("persistent", args.persistent)
-    if args.blocks_per_cu is not None:
-        hops.set_option("blocks_per_cu", args.blocks_per_cu)
-    for kv in args.opt:
-        k, v_ = kv.split("=", 1)
-        hops.set_option(k, int(v_))
+    def sync():
+        if not stub:
+            torch.cuda.synchronize()
+
+    if stub:
+        import importlib
+        modname, fname = args.stub.split(":")
+        factory = getattr(importlib.import_module(modname), fname)
+        hops = None
+    else:
+        import triro.backend.ops as hops
+        from triro.ray.ray_optix import RayMeshIntersector
+        for kv in args.opt:
+            k, v_ = kv.split("=", 1)
+            hops.set_option(k, int(v_))
 
     # ---- workload (synthetic, deterministic) -------------------------------------------------
     v, f = W.headline_mesh(args.subdiv)
     rad = float(np.linalg.norm(v, axis=1).max())
-    n = args.res * args.res
-    if args.rays == "pinhole":
-        o_np, d_np = W.pinhole_grid(args.res, args.res, distance=2.5 * rad)
-        # every rank traces its own shard: same camera, rolled by `rank` rows so shards differ
-        o_np = np.ascontiguousarray(o_np)
-        d_np = np.roll(d_np, rank * 7, axis=0)
-        origins = torch.from_numpy(np.ascontiguousarray(o_np)).to(dev)
-        dirs = torch.from_numpy(np.ascontiguousarray(d_np)).to(dev)
+    o_np = d_np = None
+    if args.workload == "c5i":
+        n_total = args.res * args.res * world
+        n = args.res * args.res
+        lo_ray = rank * n
+        if args.rays == "pinhole":
+            o_np, d_np = W.pinhole_grid(args.res, args.res, distance=2.5 * rad)
+            # every rank traces its own batch: same camera, rolled by `rank` rows so shards differ
+            d_np = np.roll(d_np, rank * 7, axis=0)
+            origins = torch.from_numpy(np.ascontiguousarray(o_np)).to(dev)
+            dirs = torch.from_numpy(np.ascontiguousarray(d_np)).to(dev)
+        else:
+            lo, hi = v.min(0) * 1.5, v.max(0) * 1.5
+            origins, dirs = W.hash_rays_torch(n, 99, lo, hi, start=rank * n, device=dev)
     else:
+        n_total = args.total_rays
+        lo_ray, hi_ray = shard_bounds(n_total, world, rank)
+        n = hi_ray - lo_ray
         lo, hi = v.min(0) * 1.5, v.max(0) * 1.5
-        origins, dirs = W.hash_rays_torch(n, 99, lo, hi, start=rank * n, device=dev)
-        o_np, d_np = None, None
+        parts_o, parts_d = [], []
+        for s in range(lo_ray, hi_ray, 1 << 23):                       # bounded temporaries
+            po, pd = W.hash_rays_torch(min(1 << 23, hi_ray - s), 99, lo, hi, start=s, device=dev)
+            parts_o.append(po)
+            parts_d.append(pd)
+        origins = torch.cat(parts_o) if parts_o else torch.zeros((0, 3), device=dev)
+        dirs = torch.cat(parts_d) if parts_d else torch.zeros((0, 3), device=dev)
+        del parts_o, parts_d
     vt, ft = torch.from_numpy(v).to(dev), torch.from_numpy(f).to(dev)
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
-    r = RayMeshIntersector(vertices=vt, faces=ft)
-    torch.cuda.synchronize()
+    r = factory(v, f, dev) if stub else RayMeshIntersector(vertices=vt, faces=ft)
+    sync()
     build_ms = (time.perf_counter() - t0) * 1e3
     info = r.bvh_info()
 
-    gather_bufs = None
-    if dist_on and args.gather:
-        import torch.distributed as dist
-        shapes = [((n,), torch.uint8), ((n,), torch.uint8), ((n,), torch.int32), ((n, 3), torch.float32),
-                  ((n, 2), torch.float32)]
-        if rank == 0:
-            gather_bufs = [[torch.empty(s, dtype=t, device=dev) for _ in range(world)] for s, t in shapes]
-
+    gather_on = dist_on and (args.workload == "c5ii" or args.gather)
+    S = ShardedRayMeshIntersector(r) if dist_on else None
     lead = origins.dim() - 1
 
     def flat(x):
-        x = x.contiguous()
-        if x.dtype == torch.bool:
-            x = x.view(torch.uint8)
         return x.reshape(n, *x.shape[lead:])
 
     def step():
         out = r.intersects_closest(origins, dirs)
-        if dist_on and args.gather:
-            import torch.distributed as dist
-            for k, x in enumerate(out):
-                dist.gather(flat(x), gather_bufs[k] if rank == 0 else None, dst=0)
+        if gather_on:
+            if args.workload == "c5ii":
+                # ONE batch of n_total rays: chunks land in slices of rank 0's full-size outputs
+                return [S._gather_fixed(flat(x), n_total, 0) for x in out]
+            # c5i + --gather: each rank's own batch, collected on rank 0 (world x n rows)
+            return [S._gather_fixed(flat(x), n * world, 0) for x in out]
         return out
 
     def barrier():
         if dist_on:
-            import torch.distributed as dist
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
-    torch.cuda.synchronize()
+    def event_pair():
+        if stub:
+            return None
+        return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def timed_steps(count, fn):
+        """`count` calls of fn, each bracketed by a pair of events recorded on the stream the
+        kernels are launched on (torch's current stream); returns per-call GPU milliseconds."""
+        ev = [event_pair() for _ in range(count)]
+        for k in range(count):
+            if ev[k]:
+                ev[k][0].record()
+            fn(k)
+            if ev[k]:
+                ev[k][1].record()
+        sync()
+        return [a.elapsed_time(b) for a, b in ev] if not stub else [0.0] * count
+
+    sync()
     t_first = time.perf_counter()
-    out = step()                      # very first call: no learned launch order yet
-    torch.cuda.synchronize()
+    out = step()                      # very first call: lazy initialisation + no learned launch order yet
+    sync()
     first_call_ms = (time.perf_counter() - t_first) * 1e3
-    for _ in range(args.warmup):
+    # warm-up: W steps AND at least --min-warmup-ms of work, so that a short driver run (--steps 20
+    # --warmup 5) starts its timed region in the same steady state as a long one
+    t_w = time.perf_counter()
+    w_done = 0
+    while w_done < args.warmup or (time.perf_counter() - t_w) * 1e3 < args.min_warmup_ms:
         out = step()
+        w_done += 1
+        if w_done % 8 == 0 or w_done >= args.warmup:
+            sync()
     barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = [event_pair() for _ in range(args.steps)]
     import gc
     gc.collect()
     gc.disable()            # a step is ~0.3 ms: keep collector pauses out of the timed region
     t0 = time.perf_counter()
     for k in range(args.steps):
-        ev[k][0].record()
+        if ev[k]:
+            ev[k][0].record()
         out = step()
-        ev[k][1].record()
+        if ev[k]:
+            ev[k][1].record()
     barrier()
     elapsed = time.perf_counter() - t0
     gc.enable()
-    kernel_ms = [a.elapsed_time(b) for a, b in ev]
+    kernel_ms = [a.elapsed_time(b) for a, b in ev] if not stub else [elapsed / args.steps * 1e3] * args.steps
     if os.environ.get("TRIRO_BENCH_TRACE") and rank == 0:   # per-step durations, launch order
         print("per-step ms:", " ".join(f"{x:.3f}" for x in kernel_ms), file=sys.stderr)
     kernel_ms.sort()
@@ -192,55 +323,117 @@ def main():
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if dist_on:
-        import torch.distributed as dist
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
 
     if rank == 0:
-        total_rays = n * world * args.steps
-        value = total_rays / elapsed / 1e6
+        value = n_total * args.steps / elapsed / 1e6
         bvh_bytes = info["node_bytes"] + info["tri_bytes"]
-        algo_bytes = n * BYTES_PER_RAY_CLOSEST + bvh_bytes
+        algo_bytes = n * BYTES_PER_RAY_CLOSEST + bvh_bytes          # per launch (= per rank and step)
         achieved = algo_bytes / (kernel_avg_ms * 1e-3) / 1e9
-        traffic = None
+        compulsory = n * BYTES_PER_RAY_CLOSEST / (kernel_avg_ms * 1e-3) / 1e9
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if args.workload == "c5i" and args.res == 1024 and args.rays == "pinhole" and os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("closest_hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("closest_hbm_bytes_per_launch")
+                traffic_src = f"profiles/traffic.json (static: rocprofv3 PMC passes of {tj.get('round', 'an earlier round')}, not measured in this run)"
             except Exception:
                 traffic = None
+        hit0 = out[0] if out[0] is not None else None
+        if args.workload == "c5i":
+            wl = (f"C5(i): icosphere({args.subdiv})+displacement seed 0, {len(f)} tris; {args.res}x{args.res} "
+                  f"{args.rays} rays per GPU; intersects_closest (stream_compaction=False)")
+            par = f"ray-sharded x{world}, BVH replicated" + (", results gathered to rank 0" if gather_on else "")
+            scaling = "weak"
+        else:
+            wl = (f"C5(ii): icosphere({args.subdiv})+displacement seed 0, {len(f)} tris; ONE batch of {n_total} hash rays "
+                  f"(seed 99) in {world} contiguous shard(s); intersects_closest (stream_compaction=False)")
+            par = f"ray-sharded x{world}, BVH replicated" + (", results gathered to rank 0 inside the timed region" if gather_on else "")
+            scaling = "strong"
         res = {
             "metric": "Mrays/s closest-hit, 1M-tri mesh, 1024^2 ray batch",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": f"C5(i): icosphere({args.subdiv})+displacement seed 0, {len(f)} tris; "
-                                   f"{args.res}x{args.res} {args.rays} rays per GPU; intersects_closest "
-                                   f"(stream_compaction=False)",
-                       "rays_per_gpu": n, "triangles": int(len(f)),
-                       "parallelism": f"ray-sharded x{world}, BVH replicated" + (", results gathered to rank 0" if (dist_on and args.gather) else ""),
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic" if not stub else "stub tracer: launcher self-test, NOT a measurement",
+            "config": {"workload": wl, "rays_per_gpu": n, "rays_total": n_total, "triangles": int(len(f)),
+                       "parallelism": par, "warmup_steps_done": w_done,
                        "bvh_depth": info["depth"], "bvh_bytes": int(bvh_bytes), "bvh_build_ms": round(build_ms, 2),
-                       "hit_fraction": round(float(out[0].float().mean().item()), 4)},
+                       "hit_fraction": round(float(hit0.float().mean().item()), 4) if hit0 is not None else None},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_query_direct<CLOSEST>", "kernel_avg_ms": round(kernel_avg_ms, 4),
                          "kernel_min_ms": round(kernel_ms[0], 4), "first_call_ms": round(first_call_ms, 4),
                          "algorithmic_bytes": int(algo_bytes),
-                         "note": "50 B/ray compulsory I/O + one read of the BVH arena per launch; the path "
-                                 "is cache-latency/divergence bound, not HBM-bandwidth bound (DESIGN.md)"},
+                         "compulsory_frac": round(compulsory / HBM_PEAK_GBPS, 5),
+                         "note": "achieved = (50 B/ray compulsory I/O + one read of the BVH arena) per launch / "
+                                 "event-timed kernel_avg_ms; compulsory_frac counts the 50 B/ray only; the path is "
+                                 "cache-latency / instruction-issue bound, not HBM-bandwidth bound (DESIGN.md 5)"},
         }
-        if args.stats:
+        if gather_on:
+            res["roofline"]["note"] += "; kernel_avg_ms here includes the result gather"
+        single = world == 1 and not stub
+        if single and not args.no_companions and args.workload == "c5i":
+            # honest companions of the steady-state figure: the same launch
+            # without a learned block order, and with an order that is always one frame stale
+            rl = res["roofline"]
+            hops.set_option("adaptive", 0)
+            for _ in range(5):
+                r.intersects_closest(origins, dirs)
+            cold = timed_steps(100, lambda k: r.intersects_closest(origins, dirs))
+            hops.set_option("adaptive", 1)
+            rl["cold_kernel_ms"] = round(float(np.mean(cold)), 4)
+            if args.rays == "pinhole":
+                frames = []
+                for k in range(8):      # camera orbiting by 0.25 degrees per frame
+                    frames.append((torch.from_numpy(np.ascontiguousarray(rotate_y(np.ascontiguousarray(o_np), 0.25 * k))).to(dev),
+                                   torch.from_numpy(rotate_y(d_np, 0.25 * k)).to(dev)))
+                seq = list(range(8)) + list(range(6, 0, -1))      # ping-pong: every step moves by one frame
+                for k in range(2 * len(seq)):
+                    r.intersects_closest(*frames[seq[k % len(seq)]])
+                mov = timed_steps(140, lambda k: r.intersects_closest(*frames[seq[k % len(seq)]]))
+                rl["moving_camera_kernel_ms"] = round(float(np.mean(mov)), 4)
+                rl["moving_camera_note"] = "camera orbits 0.25 deg per step: the learned launch order is one frame stale"
+                del frames
+            st = hops.trace_stats_closest(r.as_wrapper, origins, dirs)
+            gbytes = st["node_visits"] * 64 + st["tri_tests"] * 48
+            gach = gbytes / (kernel_avg_ms * 1e-3) / 1e9
+            res["gather_ceiling"] = {"bound": "cache gather", "achieved": round(gach, 1), "peak": GATHER_PEAK_GBPS,
+                                     "unit": "GB/s", "frac": round(gach / GATHER_PEAK_GBPS, 4),
+                                     "bytes_per_launch": int(gbytes),
+                                     "node_visits_per_ray": round(st["node_visits"] / st["rays"], 2),
+                                     "tri_tests_per_ray": round(st["tri_tests"] / st["rays"], 2),
+                                     "note": "traversal fetch stream (node visits x 64 B + triangle tests x 48 B, "
+                                             "instrumented kernel) / kernel_avg_ms against the measured random-64-B-gather "
+                                             "ceiling of a 147 MB table (profiles/r01_gather64.jsonl); mostly L1/L2 hits"}
+        if args.stats and single:
             st = hops.trace_stats_closest(r.as_wrapper, origins, dirs)
             res["trace_stats"] = {k: (v_ / st["rays"] if k != "rays" else v_) for k, v_ in st.items()}
-        if world == 1 and not args.no_cpu_baseline and o_np is not None:
-            res["cpu_baseline"] = cpu_baseline(v, f, o_np, d_np)
+        if single and not args.no_cpu_baseline:
+            if o_np is not None:
+                res["cpu_baseline"] = cpu_baseline(v, f, o_np, d_np)
+            else:
+                m = min(n, 1 << 20)
+                res["cpu_baseline"] = cpu_baseline(v, f, origins[:m].cpu().numpy(), dirs[:m].cpu().numpy())
         print(json.dumps(res), flush=True)
     if dist_on:
-        import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not under_launcher:
+        return launch_ranks(args, argv)
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -1,0 +1,59 @@
+"""bench.py's multi-rank launcher on CPU: `--gpus 2` must start two ranks through
+torch.distributed.run and relay rank 0's JSON line (gloo + a stub tracer stand in for RCCL + the
+HIP path, which need GPUs); with the real backend it must refuse loudly when fewer than N devices
+are visible instead of silently running one GPU."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def run_bench(*args, timeout=240):
+    env = dict(os.environ)
+    env["PYTHONPATH"] = os.pathsep.join([os.path.join(ROOT, "tests"), env.get("PYTHONPATH", "")])
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    return subprocess.run([sys.executable, BENCH, *args], capture_output=True, text=True, timeout=timeout, env=env)
+
+
+@pytest.mark.timeout(300)
+def test_gpus2_launches_two_ranks_strong_scaling_c5ii():
+    p = run_bench("--gpus", "2", "--backend", "gloo", "--stub", "bench_stub:make", "--workload", "c5ii",
+                  "--total-rays", "10001", "--subdiv", "2", "--steps", "3", "--warmup", "1", "--min-warmup-ms", "0")
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, "exactly one JSON line on stdout"
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["steps"] == 3
+    assert r["config"]["rays_total"] == 10001 and r["config"]["rays_per_gpu"] == 5001     # rank 0's shard
+    assert "gathered to rank 0 inside the timed region" in r["config"]["parallelism"]
+    assert r["value"] > 0 and r["metric"].startswith("Mrays/s closest-hit")
+    assert "stub" in r["data"]                       # a stand-in tracer is labelled, never a measurement
+
+
+@pytest.mark.timeout(300)
+def test_gpus2_weak_scaling_default_workload():
+    p = run_bench("--gpus", "2", "--backend", "gloo", "--stub", "bench_stub:make", "--subdiv", "2", "--res", "64",
+                  "--steps", "2", "--warmup", "1", "--min-warmup-ms", "0", "--gather")
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads(p.stdout.strip().splitlines()[-1])
+    assert r["n_gpus"] == 2 and r["scaling"] == "weak"
+    assert r["config"]["rays_per_gpu"] == 64 * 64 and r["config"]["rays_total"] == 2 * 64 * 64
+
+
+@pytest.mark.skipif(torch.cuda.device_count() >= 2, reason="needs a node with fewer than 2 GPUs")
+def test_gpus2_refuses_when_fewer_devices_are_visible():
+    p = run_bench("--gpus", "2", "--steps", "2", "--warmup", "1")
+    assert p.returncode == 2
+    assert "needs 2 visible GPUs" in p.stderr and p.stdout.strip() == ""
+
+
+def test_stub_is_rejected_with_the_real_backend():
+    p = run_bench("--stub", "bench_stub:make", "--steps", "1")
+    assert p.returncode != 0 and "only accepted with --backend gloo" in (p.stderr + p.stdout)

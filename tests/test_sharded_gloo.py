@@ -56,8 +56,23 @@ def _worker(rank, world, port, q):
         o, d = torch.from_numpy(np.ascontiguousarray(o_np)), torch.from_numpy(d_np)
         S = ShardedRayMeshIntersector(CpuLocal(v, f))
         ref = CpuLocal(v, f)
+        # every allocation of the gather path is recorded: receives must land in the final
+        # outputs (no padded per-rank buffers, no concatenation copies)
+        allocs = []
+        real_alloc = ShardedRayMeshIntersector._alloc
+
+        def counting_alloc(shape, dtype, device):
+            allocs.append((tuple(shape), dtype))
+            return real_alloc(shape, dtype, device)
+        S._alloc = counting_alloc
         out = {}
         out["closest"] = S.intersects_closest(o, d, dst=0)
+        # dst=0 gather of the five closest-hit outputs: rank 0 allocates exactly the five full
+        # outputs, the other rank nothing at all
+        want = [((851,), torch.uint8), ((851,), torch.uint8), ((851,), torch.int32),
+                ((851, 3), torch.float32), ((851, 2), torch.float32)]
+        alloc_ok = (allocs == want) if rank == 0 else (allocs == [])
+        allocs.clear()
         out["closest_all"] = S.intersects_closest(o, d, dst=None)
         out["compact"] = S.intersects_closest(o, d, stream_compaction=True, dst=0)
         out["count"] = S.intersects_count(o, d, dst=0)
@@ -85,6 +100,23 @@ def _worker(rank, world, port, q):
         for a, e in zip(out["closest_all"], exp):          # all_gather variant: every rank
             ok &= torch.equal(a.reshape(e.shape), e)
         ok &= torch.equal(out["any"].reshape(-1), ref.intersects_any(fo, fd))
+        ok &= alloc_ok
+        # equal chunks (850 rays over 2 ranks) take the single-collective path
+        o2, d2 = fo[:850], fd[:850]
+        allocs.clear()
+        e2 = ref.intersects_closest(o2, d2)
+        for dst_ in (0, 1, None):
+            g2 = S.intersects_closest(o2, d2, dst=dst_)
+            if dst_ is None or dst_ == rank:
+                for a, e in zip(g2, e2):
+                    ok &= torch.equal(a, e)
+            else:
+                ok &= g2 is None
+        c2 = S.intersects_count(o2, d2, dst=1)
+        ok &= (torch.equal(c2, ref.intersects_count(o2, d2)) if rank == 1 else c2 is None)
+        l2 = S.intersects_location(o2, d2, dst=None)          # variable-size rows to every rank
+        for a, e in zip(l2, ref.intersects_location(o2, d2)):
+            ok &= torch.equal(a, e)
         covered = sum(hi - lo for lo, hi in (shard_bounds(851, world, r) for r in range(world)))
         ok &= covered == 851 and shard_bounds(851, world, 0)[0] == 0
         q.put((rank, bool(ok)))

@@ -7,12 +7,12 @@ path shards by rays: every ray is independent, so the flat ray range [0, n) is c
 (the builder is deterministic, so replicas built from the same mesh are identical) and there is
 no exchange during traversal.  The only collective is the optional result gather:
 
-  fixed-size outputs (any/first/closest/count): one padded `gather` (or `all_gather`) per
-      output tensor, straight into slices of the destination;
+  fixed-size outputs (any/first/closest/count): one `gather` (or `all_gather_into_tensor`)
+      per output tensor whose receive buffers are slices of the preallocated destination
+      (grouped point-to-point receives when the chunks are ragged);
   variable-size outputs (location, stream compaction): `all_gather` of the per-rank row
-      counts, then a padded gather of the rows; `ray_idx` is already global because the
-      kernels add `ray_base` (include/triro_hip.h: tr_intersects_location_fill,
-      tr_compact_closest).
+      counts, then the same receive-into-place exchange with per-rank lengths; `ray_idx` is
+      made global before the exchange.
 
 `local` can be any object with the RayMeshIntersector query methods (tests inject a CPU
 stand-in so the sharding logic runs under gloo without a GPU).
@@ -50,28 +50,57 @@ class ShardedRayMeshIntersector:
         d = directions.expand(*b, 3).reshape(-1, 3)[lo:hi]
         return b, n, lo, hi, o, d
 
+    # Gathers write straight into slices of the preallocated destination: no padded per-rank
+    # buffers, no torch.cat -- at the 100 M-ray config those were two extra full copies of up to
+    # 2.6 GB.  Every allocation of this module goes through _alloc (tests count them).
+    @staticmethod
+    def _alloc(shape, dtype, device):
+        return torch.empty(shape, dtype=dtype, device=device)
+
+    def _exchange(self, src: torch.Tensor, out: Optional[torch.Tensor], bounds, dst: Optional[int]):
+        """rows [bounds[r][0], bounds[r][1]) of `out` <- rank r's `src`, for every r; `out` exists
+        on dst (all ranks when dst is None).  Receives land in views of `out`; the local chunk
+        is one device copy.  Equal chunks use one collective (RCCL gather / all-gather =
+        grouped send/recv over distinct xGMI links), ragged ones grouped point-to-point ops."""
+        world, rank = self.world, self.rank
+        sizes = [hi - lo for lo, hi in bounds]
+        equal = len(set(sizes)) == 1
+        want = dst is None or rank == dst
+        if equal and sizes[0] > 0:
+            if dst is None:
+                dist.all_gather_into_tensor(out, src.contiguous(), group=self.group)
+            else:
+                views = [out[lo:hi] for lo, hi in bounds] if want else None
+                dist.gather(src.contiguous(), views, dst=dst, group=self.group)
+            return
+        ops = []
+        src = src.contiguous()
+        if want:
+            lo, hi = bounds[rank]
+            out[lo:hi].copy_(src)
+            for r in range(world):
+                if r != rank and sizes[r] > 0:
+                    ops.append(dist.P2POp(dist.irecv, out[bounds[r][0]:bounds[r][1]], r, group=self.group))
+        if sizes[rank] > 0:
+            targets = [r for r in range(world) if r != rank] if dst is None else ([dst] if rank != dst else [])
+            for r in targets:
+                ops.append(dist.P2POp(dist.isend, src, r, group=self.group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+
     def _gather_fixed(self, x: torch.Tensor, n: int, dst: Optional[int]):
         """x: this rank's [m, ...] rows -> [n, ...] on dst (None = all ranks)"""
         if self.world == 1:
             return x
-        per = (n + self.world - 1) // self.world
         isbool = x.dtype == torch.bool
         src = x.view(torch.uint8) if isbool else x
-        pad = torch.zeros((per, *src.shape[1:]), dtype=src.dtype, device=src.device)
-        pad[: src.shape[0]] = src
         want = dst is None or self.rank == dst
-        bufs = [torch.empty_like(pad) for _ in range(self.world)] if want else None
-        if dst is None:
-            dist.all_gather(bufs, pad, group=self.group)
-        else:
-            dist.gather(pad, bufs, dst=dst, group=self.group)
+        out = self._alloc((n, *src.shape[1:]), src.dtype, src.device) if want else None
+        bounds = [shard_bounds(n, self.world, r) for r in range(self.world)]
+        self._exchange(src, out, bounds, dst)
         if not want:
             return None
-        parts = []
-        for r in range(self.world):
-            lo, hi = shard_bounds(n, self.world, r)
-            parts.append(bufs[r][: hi - lo])
-        out = torch.cat(parts, 0)
         return out.view(torch.bool) if isbool else out
 
     def _gather_rows(self, xs: Sequence[torch.Tensor], dst: Optional[int]):
@@ -79,28 +108,23 @@ class ShardedRayMeshIntersector:
         if self.world == 1:
             return list(xs)
         dev = xs[0].device
+        # the only extra exchange of the variable-size outputs: `world` row counts
         cnt = torch.tensor([xs[0].shape[0]], dtype=torch.int64, device=dev)
-        cnts = [torch.zeros_like(cnt) for _ in range(self.world)]
-        dist.all_gather(cnts, cnt, group=self.group)
-        counts = [int(c.item()) for c in cnts]
-        mx = max(counts) if counts else 0
-        outs = []
+        cnts = self._alloc((self.world,), torch.int64, dev)
+        dist.all_gather_into_tensor(cnts, cnt, group=self.group)
+        counts = [int(c) for c in cnts.tolist()]
+        bounds, acc = [], 0
+        for c in counts:
+            bounds.append((acc, acc + c))
+            acc += c
         want = dst is None or self.rank == dst
+        outs = []
         for x in xs:
             isbool = x.dtype == torch.bool
             src = x.view(torch.uint8) if isbool else x
-            pad = torch.zeros((mx, *src.shape[1:]), dtype=src.dtype, device=dev)
-            pad[: src.shape[0]] = src
-            bufs = [torch.empty_like(pad) for _ in range(self.world)] if want else None
-            if dst is None:
-                dist.all_gather(bufs, pad, group=self.group)
-            else:
-                dist.gather(pad, bufs, dst=dst, group=self.group)
-            if want:
-                o = torch.cat([bufs[r][: counts[r]] for r in range(self.world)], 0)
-                outs.append(o.view(torch.bool) if isbool else o)
-            else:
-                outs.append(None)
+            out = self._alloc((acc, *src.shape[1:]), src.dtype, dev) if want else None
+            self._exchange(src, out, bounds, dst)
+            outs.append((out.view(torch.bool) if isbool else out) if want else None)
         return outs
 
     # ---- queries (same names / return orders as RayMeshIntersector) -------------------------
