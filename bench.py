@@ -291,6 +291,14 @@ def run_rank(args):
     out = step()                      # very first call: lazy initialisation + no learned launch order yet
     sync()
     first_call_ms = (time.perf_counter() - t_first) * 1e3
+    # Everything that would leave the GPU idle between warm-up and the timed region (creating the
+    # event objects, a garbage collection) happens BEFORE the warm-up: after a few milliseconds of
+    # idleness the chip needs ~50 launches to come back to its steady clock, which is all a
+    # 20-step run ever sees (measured: 0.275 instead of 0.256 ms per launch).
+    ev = [event_pair() for _ in range(args.steps)]
+    import gc
+    gc.collect()
+    gc.disable()            # a step is ~0.3 ms: keep collector pauses out of the timed region
     # warm-up: W steps AND at least --min-warmup-ms of work, so that a short driver run (--steps 20
     # --warmup 5) starts its timed region in the same steady state as a long one
     t_w = time.perf_counter()
@@ -298,13 +306,9 @@ def run_rank(args):
     while w_done < args.warmup or (time.perf_counter() - t_w) * 1e3 < args.min_warmup_ms:
         out = step()
         w_done += 1
-        if w_done % 8 == 0 or w_done >= args.warmup:
+        if w_done % 8 == 0:
             sync()
     barrier()
-    ev = [event_pair() for _ in range(args.steps)]
-    import gc
-    gc.collect()
-    gc.disable()            # a step is ~0.3 ms: keep collector pauses out of the timed region
     t0 = time.perf_counter()
     for k in range(args.steps):
         if ev[k]:
