@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define TR_ABI_VERSION 2
+#define TR_ABI_VERSION 3
 #define TR_MAX_ANYHIT_SIZE 8 /* LaunchParams.h:8  (per-ray cap of intersects_location) */
 #define TR_MAX_SIZE_LENGTH 4 /* LaunchParams.h:9  (ray tensors have <= 4 dims)         */
 #define TR_MAX_HITS_CAP 32   /* largest `cap` tr_intersects_location_fill accepts      */
@@ -171,6 +171,9 @@ int tr_compact_closest(const uint8_t *d_hit, const int64_t *d_offsets, int64_t n
  *    (synchronises).  Not on the hot path.                                               */
 int tr_trace_stats_closest(const tr_bvh *bvh, const tr_rays *rays, tr_trace_stats *h_stats,
                            void *stream);
+/*    the same for any query: query = 0 any, 1 first, 2 closest, 3 count, 4 location (cap 8)   */
+int tr_trace_stats_query(const tr_bvh *bvh, const tr_rays *rays, int query, tr_trace_stats *h_stats,
+                   void *stream);
 
 /* -- tuning knob (process-wide): kernel variant for the query launchers.
  *    name = "adaptive" (0/1: learn the launch order from the previous launch), "compact",
@@ -182,7 +185,10 @@ int tr_trace_stats_closest(const tr_bvh *bvh, const tr_rays *rays, tr_trace_stat
  *    image-shaped batches [..., H, W, 3] with W % 8 == 0 are traced in 8x8 pixel tiles per wave),
  *    "scramble" (0/1: launches without a measured order visit each
  *    XCD's blocks in a scrambled order), "build_cache" (0/1: keep the builder's temporaries, about 130 B/triangle per
- *    device, between builds so a rebuild costs no allocation; default 1).
+ *    device, between builds so a rebuild costs no allocation; default 1),
+ *    "unordered" (0/1/2: count and location -- with 2 also any -- queue box-hit leaves and test
+ *    them in separate wave-level leaf phases instead of on every trip; default 1), "leaf_vote"
+ *    (1..64 lanes with a queued leaf that trigger such a phase).
  *    Returns TR_ERR_INVALID_ARG for unknown names.                                         */
 int tr_set_option(const char *name, int64_t value);
 

@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Run ONE query of one BASELINE.json config repeatedly (timing and rocprofv3 target).
+
+  python scripts/run_query.py --config c4 --query count [--steps 20] [--warmup 4] [--opt name=value ...]
+  configs: c2 (bunny stand-in 81 920 tris, 1024^2 pinhole), c3 (10 M hash shadow rays vs the stand-in),
+           c4 (4 nested shells 1 310 720 tris, 1024^2 pinhole), c5i (headline mesh, 1024^2 pinhole; --res),
+           c5s (headline mesh, one 12.5 M-ray shard of the 100 M hash rays)
+  queries: closest any first count location closest_compact
+Prints one JSON line: ms per call (HIP events on the launch stream, mean and min) and Mrays/s."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "trimesh-ray-optix_amd")]
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import workloads as W  # noqa: E402
+from triro.backend import ops as hops  # noqa: E402
+from triro.ray.ray_optix import RayMeshIntersector  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--config", default="c4")
+ap.add_argument("--query", default="count")
+ap.add_argument("--steps", type=int, default=20)
+ap.add_argument("--warmup", type=int, default=4)
+ap.add_argument("--res", type=int, default=1024)
+ap.add_argument("--opt", action="append", default=[])
+ap.add_argument("--stats", action="store_true", help="also run the instrumented kernel (traversal counters)")
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)  # noqa: E731
+for kv in a.opt:
+    k, v_ = kv.split("=", 1)
+    hops.set_option(k, int(v_))
+
+if a.config in ("c2", "c3"):
+    v, f = W.bunny_standin()
+elif a.config == "c4":
+    v, f = W.nested_shells(7)
+else:
+    v, f = W.headline_mesh(8)
+r = RayMeshIntersector(vertices=T(v), faces=T(f))
+rad = float(np.linalg.norm(v, axis=1).max())
+if a.config == "c3":
+    n = 10_000_000
+    o, d = W.hash_rays_torch(n, 1234, v.min(0) * 1.5, v.max(0) * 1.5, device=dev)
+elif a.config == "c5s":
+    n = 100_000_000 // 8
+    o, d = W.hash_rays_torch(n, 99, v.min(0) * 1.5, v.max(0) * 1.5, device=dev)
+else:
+    dist = 2.5 if a.config == "c4" else 2.5 * rad
+    on, dn = W.pinhole_grid(a.res, a.res, distance=dist)
+    o, d = T(on), T(dn)
+    n = a.res * a.res
+fn = {"closest": lambda: r.intersects_closest(o, d), "any": lambda: r.intersects_any(o, d),
+      "first": lambda: r.intersects_first(o, d), "count": lambda: r.intersects_count(o, d),
+      "location": lambda: r.intersects_location(o, d),
+      "closest_compact": lambda: r.intersects_closest(o, d, stream_compaction=True)}[a.query]
+for _ in range(a.warmup):
+    out = fn()
+torch.cuda.synchronize()
+ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+t0 = time.perf_counter()
+for e0, e1 in ev:
+    e0.record()
+    out = fn()
+    e1.record()
+torch.cuda.synchronize()
+wall = (time.perf_counter() - t0) / a.steps
+ms = [e0.elapsed_time(e1) for e0, e1 in ev]
+res = {"config": a.config, "query": a.query, "rays": n, "tris": int(len(f)), "opts": a.opt,
+       "ms_mean": round(float(np.mean(ms)), 4), "ms_min": round(min(ms), 4), "wall_ms": round(wall * 1e3, 4),
+       "mrays_per_s": round(n / np.mean(ms) / 1e3, 1)}
+if a.query == "location":
+    res["hits"] = int(out[0].shape[0])
+if a.stats:
+    q = a.query if a.query in hops.QUERY_IDS else "closest"
+    st = hops.trace_stats(r.as_wrapper, o, d, q)
+    res["stats_per_ray"] = {k: round(v_ / max(st["rays"], 1), 3) for k, v_ in st.items() if k != "rays"}
+print(json.dumps(res), flush=True)

@@ -141,6 +141,7 @@ static tr_bvh_view view_of(const tr_node* nodes, const tr_link* links, const tr_
 
 static int g_use_ring = 1;
 static int g_fused = 0;   // 0 generic node/leaf schedule, 1 fused trip (64-bit state), 2 fused compact (32-bit)
+static int g_unordered = 0;   // 1: any / count / location run the unordered two-phase schedule (tr_unord_step)
 
 template <int Q>
 static void run_query(const tr_bvh_view& v, const float* o, const float* d, int64_t n, uint8_t* hit,
@@ -155,7 +156,11 @@ static void run_query(const tr_bvh_view& v, const float* o, const float* d, int6
         cnt.nodes = cnt.tris = cnt.climbs = 0;
         int32_t ring_mem[TR_RING];
         tr_ring ring = {g_use_ring ? ring_mem : nullptr, 1};
-        if (v.num_tris >= 2 && (g_fused & 3)) {
+        int32_t leafq_mem[TR_LEAFQ];
+        tr_leafq lq = {leafq_mem, 1};
+        if (v.num_tris >= 2 && g_unordered && (Q == TR_Q_ANY || Q == TR_Q_COUNT)) {
+            tr_traverse_unordered<Q, 1, true>(v, r, valid, res, top, &cnt, ring, lq);
+        } else if (v.num_tris >= 2 && (g_fused & 3)) {
             tr_result_init(res);
             if (valid) {
                 if ((g_fused & 3) == 1) {
@@ -198,6 +203,7 @@ static void run_query(const tr_bvh_view& v, const float* o, const float* d, int6
 extern "C" {
 void sim_use_ring(int on) { g_use_ring = on; }
 void sim_use_fused(int mode) { g_fused = mode; }
+void sim_use_unordered(int on) { g_unordered = on; }
 void sim_query(int q, const void* nodes, const void* links, const void* tris, int64_t nf, const float* o,
                const float* d, int64_t n, uint8_t* hit, uint8_t* front, int32_t* tri, float* loc, float* uv,
                int32_t* count, uint64_t* stats) {
@@ -235,7 +241,10 @@ void sim_location(const void* nodes, const void* links, const void* tris, int64_
         tr_result res; tr_topk<8> top; tr_counters cnt;
         int32_t ring_mem[TR_RING];
         tr_ring ring = {g_use_ring ? ring_mem : nullptr, 1};
-        tr_traverse<TR_Q_LOCATION, 8, false>(v, r, valid, res, top, &cnt, ring);
+        int32_t leafq_mem[TR_LEAFQ];
+        tr_leafq lq = {leafq_mem, 1};
+        if (g_unordered) tr_traverse_unordered<TR_Q_LOCATION, 8, false>(v, r, valid, res, top, &cnt, ring, lq);
+        else tr_traverse<TR_Q_LOCATION, 8, false>(v, r, valid, res, top, &cnt, ring);
         count[i] = res.count;
         for (int k = 0; k < 8 && k < cap; k++) { tri_out[i * cap + k] = k < res.count ? top.face[k] : -1; t_out[i * cap + k] = top.t[k]; }
     }

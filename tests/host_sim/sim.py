@@ -34,6 +34,7 @@ def lib():
         L.sim_location.argtypes = [C.c_void_p] * 3 + [C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 3
         L.sim_use_ring.argtypes = [C.c_int]
         L.sim_use_fused.argtypes = [C.c_int]
+        L.sim_use_unordered.argtypes = [C.c_int]
         L.sim_steps.argtypes = [C.c_void_p] * 3 + [C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         _LIB = L
     return _LIB
@@ -102,3 +103,8 @@ def use_ring(on: bool):
 def use_fused(mode: int):
     """0 = generic node/leaf schedule, 1 = fused trip, 2 = fused trip with 32-bit state/offsets"""
     lib().sim_use_fused(mode)
+
+
+def use_unordered(on: bool):
+    """any / count / location through the unordered two-phase schedule (queued leaves)"""
+    lib().sim_use_unordered(1 if on else 0)

@@ -117,6 +117,33 @@ def test_fused_trip_variants(mode):
         sim.use_fused(0)
 
 
+@pytest.mark.parametrize("ring", [True, False])
+def test_unordered_two_phase_schedule(ring):
+    """any / count / location through tr_unord_step (leaves queued, tested late): same answers as
+    the oracle on coherent, incoherent, multi-layer (> 8 hits: list replacement) and deep trees"""
+    import sim
+    sim.use_unordered(True)
+    sim.use_ring(ring)
+    try:
+        v, f = W.icosphere(4)
+        compare_all(v, f, *W.pinhole_grid(96, 96))
+        v, f = W.random_soup(2500, seed=8)
+        o, d = W.hash_rays(12000, 4, v.min(0) * 1.5, v.max(0) * 1.5)
+        compare_all(v, f, o, d)
+        compare_all(v, f, o, d, morton_shift=63)
+        v, f = W.nested_shells(3, radii=(1.0, 0.8, 0.6, 0.4, 0.3))
+        o, d = W.pinhole_grid(96, 96)
+        compare_all(v, f, np.ascontiguousarray(o), d)
+        v, f = W.deep_tree_mesh(3000)
+        o, d = W.hash_rays(2000, 3, [-0.1] * 3, [1.1] * 3)
+        o[:500] = [1e-10, 1e-10, 1.0]
+        d[:500] = [0, 0, -1]
+        compare_all(v, f, o, d)
+    finally:
+        sim.use_unordered(False)
+        sim.use_ring(True)
+
+
 def test_nested_shells_multihit():
     v, f = W.nested_shells(3, radii=(1.0, 0.8, 0.6, 0.4, 0.3))
     o, d = W.pinhole_grid(96, 96)

@@ -36,6 +36,8 @@ const opt_desc OPTS[] = {
     {"scramble", &tr_options::scramble, 0, 1, true},
     {"build_cache", &tr_options::build_cache, 0, 1, true},
     {"leaf_min", &tr_options::leaf_min, 0, 64, false},
+    {"unordered", &tr_options::unordered, 0, 2, false},
+    {"leaf_vote", &tr_options::leaf_vote, 1, 64, false},
 };
 constexpr int NUM_OPTS = (int)(sizeof(OPTS) / sizeof(OPTS[0]));
 struct opt_store {

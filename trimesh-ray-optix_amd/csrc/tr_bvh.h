@@ -492,6 +492,143 @@ TR_HD void tr_fused_step(const tr_bvh_view& b, const tr_ray& r, tr_state_t<W>& s
     }
 }
 
+// ---- unordered two-phase schedule (any / count / location) --------------------------------------
+// Queries that do not prune by distance gain nothing from near-first order or from testing a
+// leaf as soon as it is found -- and the fused trip pays for both: its Moller-Trumbore block and
+// its three triangle loads run on (almost) every trip of the wave although only ~5 % of the
+// lanes have a leaf to test (profiles/r01j: the texture path, TA/TD, is the busiest unit of the
+// launch and costs ~18 cycles per wave-instruction however few lanes take part).  Here box-hit
+// leaves are only QUEUED (per-lane LIFO of triangle slots in LDS: slot s of lane t at
+// base[s * stride]); the wave tests them in a separate leaf phase that runs when it is worth a
+// wave-instruction: a lane's queue is nearly full, enough lanes have something queued, or no lane
+// has a node left.  Any order of the leaf tests gives the same count / hit set, so results are
+// bit-identical to the fused trip and to the oracle.  The triangle's own slab interval (the
+// [tn, tf] of the hit predicate) is recomputed from its vertices (tr_tri_hit: the same
+// tr_tri_box + tr_slab the builder stored in the parent), so the queue holds 4 bytes per leaf.
+#ifndef TR_LEAFQ
+#define TR_LEAFQ 6
+#endif
+struct tr_leafq {
+    int32_t* base;
+    int32_t stride;
+};
+
+template <typename W>
+struct tr_ustate_t {
+    int32_t node;     // next internal node to visit, -1 = hierarchy exhausted
+    uint32_t depth;
+    W trail, owned;   // as in tr_state_t
+    int32_t nq;       // queued leaves
+};
+
+template <typename W>
+TR_HD void tr_ustate_init(tr_ustate_t<W>& st) { st.node = 0; st.depth = 0; st.trail = 0; st.owned = 0; st.nq = 0; }
+template <typename W>
+TR_HD bool tr_udone(const tr_ustate_t<W>& st) { return st.node < 0 && st.nq == 0; }
+// a lane may visit its node only while the queue can take both children
+template <typename W>
+TR_HD bool tr_ucan_node(const tr_ustate_t<W>& st) { return st.node >= 0 && st.nq <= TR_LEAFQ - 2; }
+
+// One trip of the unordered schedule.  `go_node`: this lane visits its node (tr_ucan_node);
+// `leaf_phase`: WAVE-UNIFORM, the lanes that have a queued leaf pop and test one.  The node's four
+// loads are issued before the leaf phase so that both fetches share one memory round trip.
+// Children are entered c0 first; for ANY the nearer one first (a hit found sooner ends the ray
+// sooner).
+template <int Q, int K, bool STATS, bool COMPACT, typename W>
+TR_HD void tr_unord_step(const tr_bvh_view& b, const tr_ray& r, bool go_node, bool leaf_phase,
+                         tr_ustate_t<W>& st, tr_result& res, tr_topk<K>& top, tr_counters* cnt,
+                         const tr_ring ring, const tr_leafq lq) {
+    const int32_t nidx = go_node ? st.node : 0;
+    const tr_f4* np = tr_node_ptr<COMPACT>(b, nidx);
+    const tr_f4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+    if (STATS && go_node) cnt->nodes++;
+    bool fin = false;
+    if (leaf_phase) {
+        // pop one slot, fetch the triangle, evaluate the full predicate (box of the triangle ->
+        // slab -> Moller-Trumbore); lanes without a queued leaf compute on record 0 and discard
+        const bool gl = st.nq > 0;
+        int32_t slot = 0;
+        if (gl) { st.nq--; slot = lq.base[st.nq * lq.stride]; }
+        tr_counters* nc = nullptr;
+        const tr_tri t = tr_load_tri<false, COMPACT>(b, slot, nc);
+        if (STATS && gl) cnt->tris++;
+        tr_hit h;
+        const bool hit = tr_tri_hit(r, t.ax, t.ay, t.az, t.bx, t.by, t.bz, t.cx, t.cy, t.cz, h) && gl;
+        if (Q == TR_Q_ANY) {
+            if (hit) { res.best_face = t.face; fin = true; }   // first accepted hit ends the ray
+        } else if (Q == TR_Q_COUNT) {
+            res.count += hit ? 1 : 0;
+        } else {
+            if (hit) { res.count++; top.insert(h.t, t.face, slot); }
+        }
+    }
+    if (Q == TR_Q_ANY && fin) { st.node = -1; st.nq = 0; }
+    const bool go = go_node && !fin;
+    float tn0, tf0, tn1, tf1;
+    tr_node_slabs(r, n0, n1, n2, tn0, tf0, tn1, tf1);
+    union { float f; int32_t i; } u0, u1, u2, u3;
+    u0.f = n3.x; u1.f = n3.y; u2.f = n3.z; u3.f = n3.w;
+    const int32_t c0 = u0.i, c1 = u1.i;
+    int32_t parent = u2.i, sibling = u3.i;
+    bool h0 = tr_slab_hit(tn0, tf0, TR_TMAX) && go;
+    bool h1 = tr_slab_hit(tn1, tf1, TR_TMAX) && go;
+    if (h0 && c0 < 0) { lq.base[st.nq * lq.stride] = ~c0; st.nq++; h0 = false; }
+    if (h1 && c1 < 0) { lq.base[st.nq * lq.stride] = ~c1; st.nq++; h1 = false; }
+    if (go) {
+        if (h0 || h1) {
+            const bool both = h0 && h1;
+            const bool swap = (Q == TR_Q_ANY) ? ((both && tn1 < tn0) || !h0) : !h0;   // descend into c1?
+            if (both) {
+                st.trail |= (W(1) << st.depth);
+                if (ring.base) {
+                    const uint32_t slot = st.depth & (TR_RING - 1);
+                    ring.base[slot * ring.stride] = swap ? c0 : c1;
+                    st.owned = (st.owned & ~(tr_ring_mask(W(0)) << slot)) | (W(1) << st.depth);
+                }
+            }
+            st.node = swap ? c1 : c0;
+            st.depth++;
+        } else if (st.trail == 0) {
+            st.node = -1;
+        } else {
+            const uint32_t j = tr_top_bit(st.trail);
+            st.trail &= ~(W(1) << j);
+            if (ring.base && ((st.owned >> j) & W(1))) {
+                st.node = ring.base[(j & (TR_RING - 1)) * ring.stride];
+            } else {
+                int32_t node = st.node;
+                uint32_t depth = st.depth;
+                while (depth > j + 1) {
+                    node = parent;
+                    const tr_link l = b.links[node];
+                    parent = l.parent; sibling = l.sibling;
+                    depth--;
+                    if (STATS) cnt->climbs++;
+                }
+                st.node = sibling;
+            }
+            st.depth = j + 1;
+        }
+    }
+}
+
+// one ray: node trips while the queue has room, a leaf test otherwise (host simulation; this is
+// the schedule with the LATEST possible leaf tests, so it exercises the queue limits)
+template <int Q, int K, bool STATS>
+TR_HD void tr_traverse_unordered(const tr_bvh_view& b, const tr_ray& r, bool valid, tr_result& res,
+                                 tr_topk<K>& top, tr_counters* cnt, const tr_ring ring, const tr_leafq lq) {
+    tr_result_init(res);
+    if (Q == TR_Q_LOCATION) top.init();
+    if (!valid || b.num_tris < 2) return;
+    tr_ustate_t<uint64_t> st;
+    tr_ustate_init(st);
+    while (!tr_udone(st)) {
+        const bool cn = tr_ucan_node(st);
+        tr_unord_step<Q, K, STATS, false, uint64_t>(b, r, cn, !cn, st, res, top, cnt, ring, lq);
+        TR_CONVERGE();
+    }
+}
+
 // Full traversal of one ray (generic schedule: leaf phase whenever something is queued).
 // The wave-level kernels run the two phases under votes instead (traverse.hip).
 template <int Q, int K, bool STATS>

@@ -133,6 +133,8 @@ struct tr_options {
     int tile = 1;         // image-shaped batches: waves take 8x8 pixel tiles (0 never, 1 from 4 M rays on, 2 always)
     int scramble = 1;     // launches without a measured order visit each XCD's blocks in a scrambled order
     int build_cache = 1;  // keep the builder's temporaries (about 130 B/triangle) per device between builds
+    int unordered = 1;    // count / location (2: also any) use the unordered two-phase schedule (queued leaves)
+    int leaf_vote = 16;   // unordered schedule: lanes with a queued leaf that fire a leaf phase
     int leaf_min = 0;     // refill kernel only: lanes with a queued leaf that fire its leaf phase (0 = any)
 };
 tr_options tr_opts();   // snapshot by value

@@ -334,6 +334,54 @@ __device__ __forceinline__ void process_ray_steal(const tr_bvh_view& b, const Ra
     if (in_range) write_result<Q>(b, out, i, r, res);
 }
 
+// ---- unordered two-phase schedule (tr_unord_step): any / count / location --------------------
+// Wave-level vote per trip: the leaf phase (three triangle loads + the full predicate) runs only
+// when a lane's queue is nearly full ("parked": it could not take both children of its node),
+// when at least `leaf_min` lanes have something queued, or when no lane has a node left.
+template <int Q, int K, bool STATS, bool COMPACT>
+__device__ __forceinline__ void wave_traverse_unordered(const tr_bvh_view& b, const tr_ray& r, bool go,
+                                                        tr_result& res, tr_topk<K>& top, tr_counters* cnt,
+                                                        const tr_ring ring, const tr_leafq lq, int leaf_min) {
+    typedef typename tr_word<COMPACT>::T W;
+    tr_result_init(res);
+    if (Q == TR_Q_LOCATION) top.init();
+    tr_ustate_t<W> st;
+    tr_ustate_init(st);
+    if (!go) st.node = -1;
+    for (;;) {
+        const bool can_node = tr_ucan_node(st);
+        const unsigned long long mn = __ballot(can_node), ml = __ballot(st.nq > 0);
+        if ((mn | ml) == 0ull) break;
+        const bool parked = st.node >= 0 && !can_node;
+        const bool leaf_phase = mn == 0ull || __ballot(parked) != 0ull || __popcll(ml) >= leaf_min;
+        tr_unord_step<Q, K, STATS, COMPACT, W>(b, r, can_node, leaf_phase, st, res, top, cnt, ring, lq);
+        TR_CONVERGE();
+    }
+}
+
+template <int Q, bool STATS, bool COMPACT>
+__device__ __forceinline__ void process_ray_unordered(const tr_bvh_view& b, const RayFetch& rf,
+                                                      const QueryOut& out, int64_t i, bool in_range,
+                                                      tr_counters* cnt, const tr_ring ring,
+                                                      const tr_leafq lq, int leaf_min) {
+    float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
+    if (in_range) fetch_ray(rf, i, o, d);
+    tr_ray r;
+    const bool valid = tr_ray_setup(r, o[0], o[1], o[2], d[0], d[1], d[2]) && in_range;
+    tr_result res;
+    if (Q == TR_Q_LOCATION) {
+        tr_topk<0> top;
+        top.ent = out.hits + (in_range ? i : 0) * out.cap;
+        top.tris = b.tris;
+        top.cap = out.cap;
+        wave_traverse_unordered<Q, 0, STATS, COMPACT>(b, r, valid, res, top, cnt, ring, lq, leaf_min);
+    } else {
+        tr_topk<1> top;
+        wave_traverse_unordered<Q, 1, STATS, COMPACT>(b, r, valid, res, top, cnt, ring, lq, leaf_min);
+    }
+    if (in_range) write_result<Q>(b, out, i, r, res);
+}
+
 template <bool STATS>
 __device__ __forceinline__ void flush_stats(const tr_counters& c, unsigned long long* stats) {
     if (!STATS) return;
@@ -347,7 +395,9 @@ __device__ __forceinline__ void flush_stats(const tr_counters& c, unsigned long 
     }
 }
 
-template <int Q, bool STATS, bool COMPACT, int BS, bool STEAL = false>
+// MODE: 0 fused ordered trip, 1 fused trip + intra-wave work stealing, 2 unordered two-phase
+// schedule (any / count / location on hierarchies of at least two triangles)
+template <int Q, bool STATS, bool COMPACT, int BS, int MODE = 0>
 __global__ __launch_bounds__(BS) void k_query_direct(tr_bvh_view b, RayFetch rf, QueryOut out,
                                                       int xcd_map, int scramble, int tile_w, int steal_min,
                                                       const uint32_t* __restrict__ order,
@@ -386,7 +436,12 @@ __global__ __launch_bounds__(BS) void k_query_direct(tr_bvh_view b, RayFetch rf,
         i = (ty * 8 + (lane >> 3)) * tile_w + tx * 8 + (lane & 7);
     }
     tr_counters cnt = {0, 0, 0};
-    if (STEAL) {
+    if (MODE == 2) {
+        // the steal_min argument carries the leaf-phase vote threshold of this schedule
+        __shared__ int32_t leafq_lds[TR_LEAFQ * BS];
+        const tr_leafq lq = {leafq_lds + threadIdx.x, BS};
+        process_ray_unordered<Q, STATS, COMPACT>(b, rf, out, i, i < rf.n, &cnt, ring, lq, steal_min);
+    } else if (MODE == 1) {
         __shared__ alignas(8) int32_t steal_lds[(BS / 64) * 384];
         // the scramble argument is not needed by launches that steal: it carries the trip
         // threshold from which a closest/first ray without a hit may give subtrees away
@@ -957,12 +1012,28 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
         const bool steal = !STATS && bs == 128 &&
                            ((opt.steal == 1 && rf.n <= ((int64_t)1 << 22) && (Q == TR_Q_CLOSEST || Q == TR_Q_FIRST || Q == TR_Q_ANY)) ||
                             (opt.steal > 1 && (Q == TR_Q_CLOSEST || Q == TR_Q_FIRST || Q == TR_Q_COUNT || Q == TR_Q_ANY)));
+        // Unordered two-phase schedule for the queries that do not prune by distance (count, location;
+        // any where stealing is not in play).  Hierarchies only (a single triangle has none).
+        const bool unord = opt.unordered && !steal && bvh->num_tris >= 2 &&
+                           (Q == TR_Q_COUNT || Q == TR_Q_LOCATION || (Q == TR_Q_ANY && opt.unordered > 1));
+        if (unord) {
+            if constexpr (Q == TR_Q_COUNT || Q == TR_Q_LOCATION || Q == TR_Q_ANY) {
+                const int leaf_min = opt.leaf_vote;
+#define TR_LAUNCH_UNORD(C, B)                                                                            \
+    hipLaunchKernelGGL((k_query_direct<Q, STATS, C, B, 2>), dim3((unsigned)nblocks_direct), dim3(B), 0, stream, \
+                       view, rf, out, xc, scramble, tile_w, leaf_min, order, cost, d_stats)
+                if (bs == 64) { if (compact) TR_LAUNCH_UNORD(true, 64); else TR_LAUNCH_UNORD(false, 64); }
+                else if (bs == 128) { if (compact) TR_LAUNCH_UNORD(true, 128); else TR_LAUNCH_UNORD(false, 128); }
+                else { if (compact) TR_LAUNCH_UNORD(true, 256); else TR_LAUNCH_UNORD(false, 256); }
+#undef TR_LAUNCH_UNORD
+            }
+        } else
         if (steal) {
             if (compact)
-                hipLaunchKernelGGL((k_query_direct<Q, false, true, 128, true>), dim3((unsigned)nblocks_direct), dim3(128), 0, stream,
+                hipLaunchKernelGGL((k_query_direct<Q, false, true, 128, 1>), dim3((unsigned)nblocks_direct), dim3(128), 0, stream,
                                    view, rf, out, xc, scramble, tile_w, steal_min, order, cost, d_stats);
             else
-                hipLaunchKernelGGL((k_query_direct<Q, false, false, 128, true>), dim3((unsigned)nblocks_direct), dim3(128), 0, stream,
+                hipLaunchKernelGGL((k_query_direct<Q, false, false, 128, 1>), dim3((unsigned)nblocks_direct), dim3(128), 0, stream,
                                    view, rf, out, xc, scramble, tile_w, steal_min, order, cost, d_stats);
         } else
         if (bs == 64) { if (compact) TR_LAUNCH_DIRECT(true, 64); else TR_LAUNCH_DIRECT(false, 64); }
@@ -1133,20 +1204,23 @@ int tr_compact_closest(const uint8_t* d_hit, const int64_t* d_offsets, int64_t n
     return TR_OK;
 }
 
-int tr_trace_stats_closest(const tr_bvh* bvh, const tr_rays* rays, tr_trace_stats* h_stats,
-                           void* stream) {
+int tr_trace_stats_query(const tr_bvh* bvh, const tr_rays* rays, int query, tr_trace_stats* h_stats,
+                   void* stream) {
     if (!bvh || !rays || !h_stats) return tr_fail(TR_ERR_INVALID_ARG, "null argument");
+    if (query < TR_Q_ANY || query > TR_Q_LOCATION) return tr_fail(TR_ERR_INVALID_ARG, "unknown query id");
     hipStream_t s = (hipStream_t)stream;
+    tr_device_guard guard;
+    TR_TRY(enter_bvh_device(bvh, rays, &guard));
     int64_t n = rays->nray;
     unsigned long long* d_stats = nullptr;
-    uint8_t *hit = nullptr;
-    size_t per_ray = 1 + 1 + 4 + 12 + 8;
+    uint8_t* buf = nullptr;
+    // scratch outputs of the instrumented launch: closest 26 B/ray, multi-hit 4 + 8*cap B/ray
+    const size_t per_ray = 4 + 8 * (size_t)TR_MAX_ANYHIT_SIZE;
     TR_HIP_TRY(hipMalloc((void**)&d_stats, 64));
-    hipError_t e = hipMalloc((void**)&hit, per_ray * (size_t)(n > 0 ? n : 1) + 64);
+    hipError_t e = hipMalloc((void**)&buf, per_ray * (size_t)(n > 0 ? n : 1) + 64);
     if (e != hipSuccess) { (void)hipFree(d_stats); return tr_fail(TR_ERR_OUT_OF_MEMORY, "stats outputs"); }
-    // carve 4-byte aligned outputs
     size_t nn = (size_t)(n > 0 ? n : 1);
-    float* loc = (float*)hit;                       // 12 n
+    float* loc = (float*)buf;                       // 12 n
     float* uv = loc + 3 * nn;                       // 8 n
     int32_t* tri = (int32_t*)(uv + 2 * nn);         // 4 n
     uint8_t* hitp = (uint8_t*)(tri + nn);           // n
@@ -1154,17 +1228,31 @@ int tr_trace_stats_closest(const tr_bvh* bvh, const tr_rays* rays, tr_trace_stat
     int status = TR_OK;
     if (hipMemsetAsync(d_stats, 0, 64, s) != hipSuccess) status = tr_fail(TR_ERR_HIP, "memset stats");
     if (status == TR_OK) {
-        QueryOut out = {hitp, front, tri, loc, uv, nullptr};
-        status = launch_query<TR_Q_CLOSEST, true>(bvh, rays, out, d_stats, s);
+        QueryOut out = {hitp, front, tri, loc, uv, nullptr, nullptr, 0};
+        switch (query) {
+            case TR_Q_ANY: status = launch_query<TR_Q_ANY, true>(bvh, rays, out, d_stats, s); break;
+            case TR_Q_FIRST: status = launch_query<TR_Q_FIRST, true>(bvh, rays, out, d_stats, s); break;
+            case TR_Q_CLOSEST: status = launch_query<TR_Q_CLOSEST, true>(bvh, rays, out, d_stats, s); break;
+            case TR_Q_COUNT: out.count = (int32_t*)buf; status = launch_query<TR_Q_COUNT, true>(bvh, rays, out, d_stats, s); break;
+            default:
+                out.count = (int32_t*)buf;
+                out.hits = (tr_hit_entry*)(buf + 4 * ((nn + 1) / 2 * 2));   // 8-byte aligned
+                out.cap = TR_MAX_ANYHIT_SIZE;
+                status = launch_query<TR_Q_LOCATION, true>(bvh, rays, out, d_stats, s);
+        }
     }
     unsigned long long h[4] = {0, 0, 0, 0};
     if (status == TR_OK && hipMemcpyAsync(h, d_stats, 32, hipMemcpyDeviceToHost, s) != hipSuccess)
         status = tr_fail(TR_ERR_HIP, "memcpy stats");
     if (hipStreamSynchronize(s) != hipSuccess && status == TR_OK) status = tr_fail(TR_ERR_HIP, "sync stats");
     (void)hipFree(d_stats);
-    (void)hipFree(hit);
+    (void)hipFree(buf);
     h_stats->rays = (uint64_t)n; h_stats->node_visits = h[1]; h_stats->tri_tests = h[2]; h_stats->climb_steps = h[3];
     return status;
+}
+
+int tr_trace_stats_closest(const tr_bvh* bvh, const tr_rays* rays, tr_trace_stats* h_stats, void* stream) {
+    return tr_trace_stats_query(bvh, rays, TR_Q_CLOSEST, h_stats, stream);
 }
 
 }  // extern "C"

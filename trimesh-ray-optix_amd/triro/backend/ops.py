@@ -30,7 +30,7 @@ MAX_ANYHIT_SIZE = 8   # LaunchParams.h:8
 MAX_SIZE_LENGTH = 4   # LaunchParams.h:9
 
 _LIB_NAME = "libtriro_hip.so"
-ABI_VERSION = 2     # TR_ABI_VERSION of include/triro_hip.h this binding was written against
+ABI_VERSION = 3     # TR_ABI_VERSION of include/triro_hip.h this binding was written against
 _lib = None
 _lib_error = None
 
@@ -87,6 +87,7 @@ ABI = {
     "tr_mask_scan": (_int, [_vp, _i64, _vp, _vp, C.POINTER(_i64), _vp]),
     "tr_compact_closest": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tr_trace_stats_closest": (_int, [_vp, C.POINTER(TrRays), C.POINTER(TrTraceStats), _vp]),
+    "tr_trace_stats_query": (_int, [_vp, C.POINTER(TrRays), _int, C.POINTER(TrTraceStats), _vp]),
     "tr_set_option": (_int, [C.c_char_p, _i64]),
 }
 
@@ -335,6 +336,19 @@ def trace_stats_closest(accel_structure, origins, dirs) -> dict:
     with torch.cuda.device(origins.device):
         _check(get_module().tr_trace_stats_closest(_handle(accel_structure, origins), C.byref(make_rays(origins, dirs)),
                                                    C.byref(st), _stream_ptr(origins.device)))
+    return dict(rays=st.rays, node_visits=st.node_visits, tri_tests=st.tri_tests, climb_steps=st.climb_steps)
+
+
+QUERY_IDS = {"any": 0, "first": 1, "closest": 2, "count": 3, "location": 4}
+
+
+def trace_stats(accel_structure, origins, dirs, query: str = "closest") -> dict:
+    """Diagnostic: traversal counters of the instrumented kernel of any query."""
+    check_rays(origins, dirs)
+    st = TrTraceStats()
+    with torch.cuda.device(origins.device):
+        _check(get_module().tr_trace_stats_query(_handle(accel_structure, origins), C.byref(make_rays(origins, dirs)),
+                                           QUERY_IDS[query], C.byref(st), _stream_ptr(origins.device)))
     return dict(rays=st.rays, node_visits=st.node_visits, tri_tests=st.tri_tests, climb_steps=st.climb_steps)
 
 
