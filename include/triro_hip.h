@@ -177,8 +177,8 @@ int tr_trace_stats_query(const tr_bvh *bvh, const tr_rays *rays, int query, tr_t
 
 /* -- tuning knob (process-wide): kernel variant for the query launchers.
  *    name = "adaptive" (0/1: learn the launch order from the previous launch), "compact",
- *    "xcd_chunk", "persistent" (0/1), "refill" (0/1), "refill_min" (1..64 idle lanes that
- *    trigger a refill), "blocks_per_cu" (int), "block_size" (64/128/256 threads of the direct
+ *    "xcd_chunk", "persistent" (0/1: 64-ray batches from a work counter instead of one block per
+ *    128 rays), "blocks_per_cu" (int), "block_size" (64/128/256 threads of the direct
  *    kernel), "steal" (intra-wave work stealing: 0 off / 1 closest, first and any up to
  *    4 M rays / >= 2 forced, the value is the trip count from which a ray gives subtrees away),
  *    "tile" (0 never / 1 from 4 M rays on / 2 always:

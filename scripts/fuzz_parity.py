@@ -17,7 +17,8 @@ rng = np.random.default_rng(a.seed)
 dev = torch.device("cuda:0")
 T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
 DEFAULTS = {"steal": 1, "tile": 1, "block_size": 128, "adaptive": 1, "xcd_chunk": 128, "compact": 1, "scramble": 1,
-            "persistent": 0, "refill": 1, "refill_min": 16, "xcd_segments": 1, "leaf_min": 0, "blocks_per_cu": 8}
+            "persistent": 0, "blocks_per_cu": 8,
+            "unordered": 1, "leaf_vote": 16, "stream": 1, "stream_rays": 512, "stream_refill": 16}
 bad = 0
 for it in range(a.iters):
     kind = rng.integers(0, 5)
@@ -52,9 +53,13 @@ for it in range(a.iters):
     opts = {"steal": int(rng.choice([0, 1, 2, 5, 17, 64])), "tile": int(rng.choice([0, 1, 2])),
             "block_size": int(rng.choice([64, 128, 128, 128, 128, 256])), "adaptive": int(rng.choice([0, 1, 1])),
             "xcd_chunk": int(rng.choice([0, 16, 128, 300])), "compact": int(rng.choice([0, 1, 1])), "scramble": int(rng.choice([0, 1])),
-            # optional launch shapes (persistent batches / per-lane refill engage on batches larger than the resident grid)
-            "persistent": int(rng.choice([0, 0, 1])), "refill": int(rng.choice([0, 1])), "refill_min": int(rng.choice([1, 16, 48])),
-            "xcd_segments": int(rng.choice([0, 1])), "leaf_min": int(rng.choice([0, 16, 64])), "blocks_per_cu": int(rng.choice([1, 8]))}
+            # optional launch shape (persistent batches engage on batches larger than the resident grid)
+            "persistent": int(rng.choice([0, 0, 1])), "blocks_per_cu": int(rng.choice([1, 8])),
+            # unordered two-phase schedule of count / location (2: any as well) and its leaf-phase vote
+            "unordered": int(rng.choice([0, 1, 1, 2])), "leaf_vote": int(rng.choice([1, 4, 16, 48, 64])),
+            # streaming launch with wave-level ray refill (2 = forced at any size and shape)
+            "stream": int(rng.choice([0, 1, 2, 2])), "stream_rays": int(rng.choice([64, 100, 512, 4096])),
+            "stream_refill": int(rng.choice([1, 8, 16, 40, 64]))}
     for k, val in opts.items(): hops.set_option(k, val)
     try:
         r = RayMeshIntersector(vertices=T(v), faces=T(f)); R = OracleIntersector(v, f, 1)

@@ -29,6 +29,7 @@ ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--warmup", type=int, default=4)
 ap.add_argument("--res", type=int, default=1024)
 ap.add_argument("--opt", action="append", default=[])
+ap.add_argument("--flat", action="store_true", help="pass image-shaped rays as a flat [N, 3] batch")
 ap.add_argument("--stats", action="store_true", help="also run the instrumented kernel (traversal counters)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -55,6 +56,8 @@ else:
     dist = 2.5 if a.config == "c4" else 2.5 * rad
     on, dn = W.pinhole_grid(a.res, a.res, distance=dist)
     o, d = T(on), T(dn)
+    if a.flat:
+        o, d = o.reshape(-1, 3).contiguous(), d.reshape(-1, 3).contiguous()
     n = a.res * a.res
 fn = {"closest": lambda: r.intersects_closest(o, d), "any": lambda: r.intersects_any(o, d),
       "first": lambda: r.intersects_first(o, d), "count": lambda: r.intersects_count(o, d),

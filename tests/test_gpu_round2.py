@@ -5,8 +5,8 @@
 * C-ABI hardening: face indices outside [0, nv) are reported, not dereferenced; queries refuse
   rays on another device; save/load after a shrinking update_raw; a failed build leaves an
   empty (not a dangling) handle; options may change while other threads query;
-* every launch shape reachable through tr_set_option (persistent with and without refill,
-  refill_min, xcd_segments, leaf_min) against the oracle.
+* every launch shape reachable through tr_set_option (persistent work-counter launch; the
+  unordered two-phase schedule and its vote threshold) against the oracle.
 """
 import threading
 
@@ -213,22 +213,20 @@ def test_options_may_change_while_other_threads_query(device):
 
 
 SHAPES = [
-    {"persistent": 1, "refill": 0},
-    {"persistent": 1, "refill": 0, "blocks_per_cu": 2},
-    {"persistent": 1, "refill": 1},
-    {"persistent": 1, "refill": 1, "refill_min": 1},
-    {"persistent": 1, "refill": 1, "refill_min": 48, "xcd_segments": 0},
-    {"persistent": 1, "refill": 1, "refill_min": 8, "xcd_segments": 1, "leaf_min": 16},
-    {"persistent": 1, "refill": 1, "leaf_min": 64, "blocks_per_cu": 1},
+    {"persistent": 1},
+    {"persistent": 1, "blocks_per_cu": 2},
+    {"persistent": 1, "blocks_per_cu": 1, "block_size": 64},
 ]
-SHAPE_DEFAULTS = {"persistent": 0, "refill": 1, "refill_min": 16, "xcd_segments": 1, "leaf_min": 0, "blocks_per_cu": 8}
+SHAPE_DEFAULTS = {"persistent": 0, "blocks_per_cu": 8, "block_size": 128}
 
 
 @pytest.mark.parametrize("shape", SHAPES, ids=lambda s: ",".join(f"{k}={v}" for k, v in s.items()))
 def test_optional_launch_shapes_match_the_oracle(device, shape):
     """every kernel reachable through tr_set_option is compared with the
-    oracle (not with another GPU launch): persistent batches, per-lane refill and their knobs,
-    on a coherent and an incoherent batch large enough for the persistent grid to engage."""
+    oracle (not with another GPU launch): the persistent work-counter launch on a coherent and
+    an incoherent batch large enough for the persistent grid to engage.  (The per-lane refill
+    kernel of round 1 was deleted: the randomised sweep found a mismatch in it and it was 4x
+    slower than the direct launch.)"""
     import triro.backend.ops as hops
     cases = [
         (W.bunny_standin(), W.hash_rays(600_000, 31, [-1.6] * 3, [1.6] * 3)),
@@ -252,3 +250,113 @@ def test_optional_launch_shapes_match_the_oracle(device, shape):
     finally:
         for k_, v_ in SHAPE_DEFAULTS.items():
             hops.set_option(k_, v_)
+
+
+@pytest.mark.parametrize("unordered,leaf_vote", [(0, 16), (1, 1), (1, 16), (1, 64), (2, 8), (2, 64)])
+def test_unordered_schedule_matches_the_oracle(device, unordered, leaf_vote):
+    """count / location / any through the unordered two-phase schedule (leaves queued in LDS, tested
+    in wave-voted leaf phases), every vote threshold from "always" to "only when forced", against
+    the oracle: multi-layer scene with > 8 hits per ray (list replacement), incoherent rays on a
+    soup, the deep tree (64-bit trail), image-shaped batches (8x8 tiles) and flat ones."""
+    import triro.backend.ops as hops
+    cases = [
+        (W.nested_shells(4, radii=(1.0, 0.8, 0.6, 0.4, 0.3)), W.pinhole_grid(256, 192)),
+        (W.random_soup(6000, seed=13), W.hash_rays(150_000, 41, [-1.3] * 3, [1.3] * 3)),
+        (W.deep_tree_mesh(3000), W.hash_rays(40_000, 42, [-0.2] * 3, [1.2] * 3)),
+        (W.bunny_standin(), tuple(x.reshape(-1, 3) for x in W.pinhole_grid(320, 200))),
+    ]
+    try:
+        hops.set_option("unordered", unordered)
+        hops.set_option("leaf_vote", leaf_vote)
+        for (v, f), (o, d) in cases:
+            r = make(v, f, device)
+            R = OracleIntersector(v, f, 1)
+            ot, dt = T(o, device), T(d, device)
+            cnt = R.intersects_count(o, d)
+            for _ in range(2):
+                assert np.array_equal(r.intersects_count(ot, dt).cpu().numpy(), cnt)
+            assert np.array_equal(r.intersects_any(ot, dt).cpu().numpy(), cnt > 0)
+            loc, ray, tri = [x.cpu().numpy() for x in r.intersects_location(ot, dt)]
+            el, er, et = R.intersects_location(o, d)
+            assert np.array_equal(ray, er) and np.array_equal(tri, et) and np.array_equal(loc, el)
+    finally:
+        hops.set_option("unordered", 1)
+        hops.set_option("leaf_vote", 16)
+
+
+@pytest.mark.parametrize("rays_per_wave,refill", [(64, 1), (100, 16), (512, 16), (512, 64), (4096, 32)])
+def test_streaming_launch_with_ray_refill_matches_the_oracle(device, rays_per_wave, refill):
+    """The streaming launch (every wave owns a range of rays and refills its idle lanes from it)
+    forced on at sizes and shapes where the automatic policy would not use it: closest / first /
+    any / count against the oracle on incoherent and coherent rays, ragged tails (n not a
+    multiple of the range), strided and broadcast inputs, a single-triangle mesh, invalid rays."""
+    import triro.backend.ops as hops
+    cases = [
+        (W.bunny_standin(), W.hash_rays(200_001, 51, [-1.6] * 3, [1.6] * 3)),
+        (W.random_soup(5000, seed=17), W.hash_rays(77_777, 52, [-1.3] * 3, [1.3] * 3)),
+        (W.deep_tree_mesh(3000), W.hash_rays(30_000, 53, [-0.2] * 3, [1.2] * 3)),
+        (W.nested_shells(4), W.pinhole_grid(200, 136)),
+    ]
+    try:
+        hops.set_option("stream", 2)
+        hops.set_option("stream_rays", rays_per_wave)
+        hops.set_option("stream_refill", refill)
+        for (v, f), (o, d) in cases:
+            r = make(v, f, device)
+            R = OracleIntersector(v, f, 1)
+            ot, dt = T(o, device), T(d, device)
+            exp = R.closest_raw(o, d)
+            cnt = R.intersects_count(o, d)
+            for _ in range(2):
+                assert_closest_bitexact(r.intersects_closest(ot, dt), exp, "stream")
+            assert np.array_equal(r.intersects_first(ot, dt).cpu().numpy(), exp[2])
+            assert np.array_equal(r.intersects_count(ot, dt).cpu().numpy(), cnt)
+            assert np.array_equal(r.intersects_any(ot, dt).cpu().numpy(), cnt > 0)
+        # strided directions + broadcast origin + NaN rays + a single triangle
+        v, f = W.icosphere(4)
+        r = make(v, f, device)
+        R = OracleIntersector(v, f, 1)
+        rng = np.random.default_rng(5)
+        base = (rng.random((3000, 6)).astype(np.float32) * 2 - 1)
+        base[::97, 1] = np.nan
+        d_t = T(base, device)[:, ::2]
+        o_t = torch.tensor([0.1, 0.2, 2.5], device=device).expand(3000, 3)
+        exp = R.closest_raw(np.broadcast_to(np.array([0.1, 0.2, 2.5], np.float32), (3000, 3)), base[:, ::2])
+        assert_closest_bitexact(r.intersects_closest(o_t, d_t), exp, "stream strided")
+        r1 = make(v[f[0]], np.array([[0, 1, 2]], np.int32), device)
+        R1 = OracleIntersector(v[f[0]], np.array([[0, 1, 2]], np.int32), 0)
+        o1, d1 = W.hash_rays(5000, 54, [-1.5] * 3, [1.5] * 3)
+        d1 = (v[f[0]].mean(0) - o1 + rng.normal(0, 0.02, o1.shape)).astype(np.float32)
+        assert_closest_bitexact(r1.intersects_closest(T(o1, device), T(d1, device)), R1.closest_raw(o1, d1), "one triangle")
+    finally:
+        hops.set_option("stream", 1)
+        hops.set_option("stream_rays", 512)
+        hops.set_option("stream_refill", 16)
+
+
+def test_large_flat_batches_probe_and_both_launch_shapes(device):
+    """Flat batches of >= 2 M rays are enqueued in both launch shapes behind the coherence probe
+    (k_probe_coherence).  Whatever it selects -- direct for a flattened image, streaming for hash
+    rays -- and whatever is forced, the answers are the oracle's."""
+    import triro.backend.ops as hops
+    v, f = W.bunny_standin()
+    r = make(v, f, device)
+    R = OracleIntersector(v, f, 1)
+    o1, d1 = W.pinhole_grid(1536, 1408, distance=2.5 * 1.12)
+    o1, d1 = np.ascontiguousarray(o1).reshape(-1, 3), d1.reshape(-1, 3)          # coherent, flat, 2.16 M rays
+    o2, d2 = W.hash_rays(2_200_001, 61, v.min(0) * 1.5, v.max(0) * 1.5)           # incoherent
+    try:
+        for o, d in ((o1, d1), (o2, d2)):
+            ot, dt = T(o, device), T(d, device)
+            exp = R.closest_raw(o, d)
+            cnt = R.intersects_count(o, d)
+            for stream in (1, 0, 2):
+                hops.set_option("stream", stream)
+                assert_closest_bitexact(r.intersects_closest(ot, dt), exp, f"stream={stream}")
+                assert np.array_equal(r.intersects_any(ot, dt).cpu().numpy(), cnt > 0)
+                assert np.array_equal(r.intersects_count(ot, dt).cpu().numpy(), cnt)
+            hops.set_option("stream", 1)
+            st = hops.trace_stats(r.as_wrapper, ot, dt, "closest")              # the instrumented launch takes the same path
+            assert st["rays"] == len(o) and st["node_visits"] > 0
+    finally:
+        hops.set_option("stream", 1)

@@ -24,19 +24,18 @@ struct opt_desc {
 const opt_desc OPTS[] = {
     {"persistent", &tr_options::persistent, 0, 1, true},
     {"blocks_per_cu", &tr_options::blocks_per_cu, 1, 32, false},
-    {"refill", &tr_options::refill, 0, 1, true},
     {"block_size", &tr_options::block_size, 64, 256, false},
     {"adaptive", &tr_options::adaptive, 0, 1, true},
     {"compact", &tr_options::compact, 0, 1, true},
-    {"refill_min", &tr_options::refill_min, 1, 64, false},
-    {"xcd_segments", &tr_options::xcd_segments, 0, 1, true},
     {"xcd_chunk", &tr_options::xcd_chunk, 0, 65536, false},
     {"steal", &tr_options::steal, 0, 4096, false},
     {"tile", &tr_options::tile, 0, 2, false},
     {"scramble", &tr_options::scramble, 0, 1, true},
     {"build_cache", &tr_options::build_cache, 0, 1, true},
-    {"leaf_min", &tr_options::leaf_min, 0, 64, false},
     {"unordered", &tr_options::unordered, 0, 2, false},
+    {"stream", &tr_options::stream, 0, 2, false},
+    {"stream_rays", &tr_options::stream_rays, 64, 1 << 20, false},
+    {"stream_refill", &tr_options::stream_refill, 1, 64, false},
     {"leaf_vote", &tr_options::leaf_vote, 1, 64, false},
 };
 constexpr int NUM_OPTS = (int)(sizeof(OPTS) / sizeof(OPTS[0]));

@@ -122,19 +122,18 @@ struct tr_device_guard {
 struct tr_options {
     int persistent = 0;
     int blocks_per_cu = 8;
-    int refill = 1;
     int block_size = 128; // workgroup size of the direct kernel (64, 128 or 256)
     int adaptive = 1;     // start the blocks that were most expensive in the previous launch first
     int compact = 1;      // allow the 32-bit trail / 32-bit offset kernels when the BVH permits
-    int refill_min = 16;
-    int xcd_segments = 1;   // refill kernel: per-XCD work counters
     int xcd_chunk = 128;    // direct kernel: blocks per XCD-local chunk (0 = identity map)
     int steal = 1;        // intra-wave work stealing: 0 off, 1 auto (closest/first/any up to 4 M rays), >= 2 forced with that trip threshold
     int tile = 1;         // image-shaped batches: waves take 8x8 pixel tiles (0 never, 1 from 4 M rays on, 2 always)
     int scramble = 1;     // launches without a measured order visit each XCD's blocks in a scrambled order
     int build_cache = 1;  // keep the builder's temporaries (about 130 B/triangle) per device between builds
+    int stream = 1;       // streaming launch with wave-level ray refill: 0 never, 1 large non-image batches, 2 always
+    int stream_rays = 512;    // rays per wave of the streaming launch (its private range)
+    int stream_refill = 32;   // idle lanes that trigger a refill
     int unordered = 1;    // count / location (2: also any) use the unordered two-phase schedule (queued leaves)
     int leaf_vote = 16;   // unordered schedule: lanes with a queued leaf that fire a leaf phase
-    int leaf_min = 0;     // refill kernel only: lanes with a queued leaf that fire its leaf phase (0 = any)
 };
 tr_options tr_opts();   // snapshot by value

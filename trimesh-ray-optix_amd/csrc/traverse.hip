@@ -8,8 +8,9 @@
 //                per-XCD cost order of the previous launch (k_sched_sort), else the
 //                XCD-chunked, scrambled static map.
 //   persistent : grid = CUs x blocks_per_cu; each wave pulls 64-ray batches from a global
-//                work counter (option, not faster at the measured sizes); `refill` adds
-//                per-lane refill ("active-ray repacking", experimental, slower).
+//                work counter (option, not faster at the measured sizes).  The per-lane refill
+//                variant of round 1 ("active-ray repacking": 0.8 vs 3.6 Grays/s) was removed in
+//                round 2 after the randomised sweep found a mismatch in it.
 // Kernel parameters travel by value (no per-call malloc/memcpy/free as in ray.cpp:279-287).
 #include <atomic>
 
@@ -402,7 +403,10 @@ __global__ __launch_bounds__(BS) void k_query_direct(tr_bvh_view b, RayFetch rf,
                                                       int xcd_map, int scramble, int tile_w, int steal_min,
                                                       const uint32_t* __restrict__ order,
                                                       uint32_t* __restrict__ cost,
-                                                      unsigned long long* stats) {
+                                                      unsigned long long* stats,
+                                                      const int* __restrict__ sel) {
+    // dual launch (k_probe_coherence): this launch shape is the one for coherent batches (id 0)
+    if (sel && *sel != 0) return;
     const unsigned long long t_start = cost ? wall_clock64() : 0ull;
     __shared__ int32_t ring_lds[TR_RING * BS];
     const tr_ring ring = {ring_lds + threadIdx.x, BS};
@@ -531,114 +535,111 @@ __global__ __launch_bounds__(256) void k_query_persistent(tr_bvh_view b, RayFetc
     flush_stats<STATS>(cnt, stats);
 }
 
-// Persistent threads with per-lane refill ("active-ray repacking"): as soon as at least
-// `refill_min` lanes of a wave are idle, the wave stores their finished results together and
-// claims exactly that many new, consecutive rays with ONE atomic on a work counter, so lanes do
-// not wait for the slowest ray of a 64-ray batch and the launch has no tail of half-empty
-// waves.  There are 8 work counters: the ray range is cut into `nseg` contiguous segments and
-// a wave first drains the segment of the XCD it runs on (HW_REG_XCC_ID), so one XCD's L2 sees
-// one compact part of the image / BVH; when its segment is empty it steals from the next.
-// XCD placement only affects speed, never results.
-__device__ __forceinline__ uint32_t xcc_id() {
-    // s_getreg_b32 hwreg(HW_REG_XCC_ID = 20), bits [3:0]
-    return __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;
+// ---- streaming launch with wave-level ray refill ("active-ray repacking") -------------------------
+// For incoherent batches a wave of the direct launch runs until its slowest ray is done while most
+// of its lanes finished long ago: VALU lane utilisation is 10 of 64 on C3 and on a C5(ii) shard
+// (profiles/r02_c3any_summary.md, r02_c5s_summary.md) against 35-49 on coherent images.  Here
+// every wave owns a contiguous range of `rays_per_wave` rays and keeps its lanes busy: whenever at
+// least `refill_min` lanes are idle it stores their finished results and hands them the next rays
+// of ITS OWN range -- no atomics, no work counters (the round-1 refill kernel paid three dependent
+// round trips per refill: flush, atomic, ray fetch), just a wave-uniform cursor and a prefix rank
+// (v_mbcnt) among the idle lanes.  One refill costs about one trip and serves >= refill_min rays.
+// Results do not depend on the schedule: the per-ray state machine is the fused trip of the direct
+// launch (tr_fused_step), only the lane <-> ray assignment changes.
+// Which of the two launch shapes suits a large flat batch?  Coherent rays (a flattened image) run
+// 1.6-1.9x faster in the direct launch (XCD-local image pieces, measured launch order, lanes that
+// share nodes), incoherent ones 1.3-1.9x faster in the streaming launch
+// (profiles/r02_sweep_stream*.jsonl).  One workgroup samples 256 pairs of NEIGHBOURING rays
+// spread over the batch: a pair is coherent when the directions are within ~2.5 degrees and the
+// origins within 1 % of the scene diagonal.  *sel = 0 (direct) when at least 3/4 of the pairs
+// are, else 1 (stream).  Both kernels are then enqueued and the one not selected returns at its
+// first instruction -- no host round trip; a wrong guess costs speed, never correctness.
+__global__ __launch_bounds__(256) void k_probe_coherence(RayFetch rf, float scene_diag, int* __restrict__ sel) {
+    __shared__ int votes;
+    if (threadIdx.x == 0) votes = 0;
+    __syncthreads();
+    const int64_t stride = rf.n / 256 > 0 ? rf.n / 256 : 1;
+    const int64_t i = (int64_t)threadIdx.x * stride;
+    if (i + 1 < rf.n) {
+        float o0[3], d0[3], o1[3], d1[3];
+        fetch_ray(rf, i, o0, d0);
+        fetch_ray(rf, i + 1, o1, d1);
+        const float dd = d0[0] * d1[0] + d0[1] * d1[1] + d0[2] * d1[2];
+        const float n0 = d0[0] * d0[0] + d0[1] * d0[1] + d0[2] * d0[2];
+        const float n1 = d1[0] * d1[0] + d1[1] * d1[1] + d1[2] * d1[2];
+        const float ox = o1[0] - o0[0], oy = o1[1] - o0[1], oz = o1[2] - o0[2];
+        const bool par = dd > 0.f && dd * dd >= 0.998f * n0 * n1;                    // cos^2 >= 0.998
+        const bool near = ox * ox + oy * oy + oz * oz <= 1e-4f * scene_diag * scene_diag;
+        if (par && near) atomicAdd(&votes, 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *sel = votes >= 192 ? 0 : 1;
 }
 
-template <int Q, bool STATS>
-__global__ __launch_bounds__(256) void k_query_refill(tr_bvh_view b, RayFetch rf, QueryOut out,
-                                                      unsigned long long* counters,   // [8]
-                                                      int refill_min, int nseg, int leaf_min,
-                                                      unsigned long long* stats) {
-    __shared__ int32_t ring_lds[TR_RING * 256];
-    const tr_ring ring = {ring_lds + threadIdx.x, 256};
-    const int lane = threadIdx.x & 63;
-    tr_counters cnt = {0, 0, 0};
-    const int64_t n = rf.n;
-    const int64_t seg_len = (n + nseg - 1) / nseg;
-    uint32_t seg = xcc_id() % (uint32_t)nseg;
-    int segs_tried = 0;       // wave-uniform
-    bool exhausted = false;   // wave-uniform
-    bool active = false;
-    bool unwritten = false;   // lane holds a finished result that has not been stored yet
-    int64_t rid = 0;
-    tr_ray r;
-    tr_state st;
-    tr_result res;
-    tr_topk<1> top;
-    tr_state_init(st);
-    tr_result_init(res);
-    for (;;) {
-        unsigned long long idle = __ballot(!active);
-        int nidle = __popcll(idle);
-        const bool refill_now = !exhausted && (nidle >= refill_min || nidle == 64);
-        if (refill_now || (exhausted && nidle == 64)) {
-            // write-back of all finished lanes together (one divergent pass, not one per ray)
-            if (unwritten) {
-                write_result<Q>(b, out, rid, r, res);
-                unwritten = false;
-            }
-        }
-        if (refill_now) {
-            int rank = (int)__popcll(idle & ((1ull << lane) - 1ull));   // rank among idle lanes
-            int64_t my = -1;
-            while (nidle > 0 && segs_tried < nseg) {
-                unsigned long long base = 0;
-                if (lane == 0) base = atomicAdd(&counters[seg], (unsigned long long)nidle);
-                base = __shfl(base, 0);
-                const int64_t seg_start = (int64_t)seg * seg_len;
-                int64_t seg_end = seg_start + seg_len;
-                if (seg_end > n) seg_end = n;
-                int64_t got = seg_end - (seg_start + (int64_t)base);   // rays this claim yields
-                if (got > nidle) got = nidle;
-                if (got > 0) {
-                    if (!active && my < 0 && rank >= 0 && rank < got) my = seg_start + (int64_t)base + rank;
-                    rank -= (int)got;
-                    nidle -= (int)got;
-                }
-                if (nidle > 0) {   // segment drained: steal from the next one
-                    seg = (seg + 1) % (uint32_t)nseg;
-                    segs_tried++;
-                }
-            }
-            if (segs_tried >= nseg) exhausted = true;
-            if (my >= 0) {
-                float o[3], d[3];
-                fetch_ray(rf, my, o, d);
-                const bool valid = tr_ray_setup(r, o[0], o[1], o[2], d[0], d[1], d[2]);
-                rid = my;
-                tr_state_init(st);
-                tr_result_init(res);
-                if (valid && b.num_tris >= 2) {
-                    active = true;
-                } else {
-                    if (b.num_tris < 2) brute_one<Q>(b, r, valid, res);
-                    unwritten = true;   // stored at the next refill point
-                }
-            }
-        }
-        if (__ballot(active) == 0ull) {
-            if (exhausted && __ballot(unwritten) == 0ull) break;
-            continue;
-        }
-        // traverse until enough lanes have gone idle to make a refill worthwhile
-        for (;;) {
-            const bool pend = active && tr_pending(st);
-            const bool can_node = active && !pend && st.node >= 0;
-            const unsigned long long ml = __ballot(pend), mn = __ballot(can_node);
-            if (ml != 0ull && (mn == 0ull || (int)__popcll(ml) >= leaf_min)) {
-                if (pend) tr_leaf_step<Q, 1, STATS>(b, r, st, res, top, &cnt);
-            } else {
-                if (can_node) tr_node_step<Q, STATS>(b, r, st, res, &cnt, ring);
-            }
-            if (active && tr_done(st)) {
-                active = false;
-                unwritten = true;
-            }
-            const unsigned long long act = __ballot(active);
-            if (act == 0ull) break;
-            if (!exhausted && (64 - (int)__popcll(act)) >= refill_min) break;
+template <int Q, bool STATS, bool COMPACT, int BS>
+__global__ __launch_bounds__(BS) void k_query_stream(tr_bvh_view b, RayFetch rf, QueryOut out,
+                                                     int rays_per_wave, int refill_min, int xcd_map,
+                                                     unsigned long long* stats,
+                                                     const int* __restrict__ sel) {
+    if (sel && *sel != 1) return;      // dual launch: this is the shape for incoherent batches (id 1)
+    typedef typename tr_word<COMPACT>::T W;
+    __shared__ int32_t ring_lds[TR_RING * BS];
+    const tr_ring ring = {ring_lds + threadIdx.x, BS};
+    // the XCD-chunked block -> range map of the direct launch: consecutive ranges stay on one
+    // XCD's L2 in chunks of `xcd_map` blocks (matters for coherent batches; speed only)
+    int64_t blk = blockIdx.x;
+    if (xcd_map > 0) {
+        const int64_t T = xcd_map, span = 8 * T;
+        const int64_t nfull = (int64_t)gridDim.x / span * span;
+        if (blk < nfull) {
+            const int64_t x = blk & 7, k = blk >> 3;
+            blk = ((k / T) * 8 + x) * T + (k % T);
         }
     }
+    const int64_t wave = blk * (BS / 64) + (threadIdx.x >> 6);
+    int64_t next = wave * rays_per_wave;                 // wave-uniform cursor into the wave's range
+    int64_t end = next + rays_per_wave;
+    if (end > rf.n) end = rf.n;
+    tr_counters cnt = {0, 0, 0};
+    int64_t rid = -1;          // ray this lane holds (-1 none); its result is stored when the lane is refilled
+    bool busy = false;         // still traversing
+    tr_ray r;
+    tr_state_t<W> fs;
+    tr_result res;
+    tr_topk<1> top;
+    tr_state_init(fs);
+    tr_result_init(res);
+    tr_ray_setup(r, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f);
+    for (;;) {
+        const unsigned long long idle = __ballot(!busy);
+        const int nidle = __popcll(idle);
+        const bool more = next < end;
+        if (!more && nidle == 64) break;
+        if (more && (nidle >= refill_min || nidle == 64)) {
+            if (!busy) {
+                if (rid >= 0) write_result<Q>(b, out, rid, r, res);      // the finished ray of this lane
+                const int64_t cand = next + lane_rank(idle);
+                rid = -1;
+                if (cand < end) {
+                    rid = cand;
+                    float o[3], d[3];
+                    fetch_ray(rf, cand, o, d);
+                    const bool valid = tr_ray_setup(r, o[0], o[1], o[2], d[0], d[1], d[2]);
+                    tr_state_init(fs);
+                    tr_result_init(res);
+                    if (b.num_tris >= 2) busy = valid;
+                    else brute_one<Q>(b, r, valid, res);                 // no hierarchy below two triangles
+                }
+            }
+            next += nidle;     // lanes past `end` took nothing; the cursor only has to reach `end`
+        }
+        if (busy) {
+            tr_fused_step<Q, 1, STATS, COMPACT, W>(b, r, fs, res, top, &cnt, ring);
+            busy = !tr_done(fs);
+        }
+        TR_CONVERGE();
+    }
+    if (rid >= 0) write_result<Q>(b, out, rid, r, res);
     flush_stats<STATS>(cnt, stats);
 }
 
@@ -948,14 +949,11 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
     int64_t pgrid = (int64_t)st->num_cus * opt.blocks_per_cu;
     if (opt.persistent && Q != TR_Q_LOCATION) {   // the multi-hit list query has only the direct shape
         // size the persistent grid by what is actually resident (4 waves per block = 1 per SIMD)
-        static std::atomic<int> occ_refill{0}, occ_plain{0};   // per instantiation <Q, STATS>
-        std::atomic<int>& occ_a = opt.refill ? occ_refill : occ_plain;
+        static std::atomic<int> occ_a{0};   // per instantiation <Q, STATS>
         int occ = occ_a.load(std::memory_order_relaxed);
         if (occ == 0) {
             int nb = 0;
-            hipError_t e = opt.refill
-                ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_query_refill<Q, STATS>, 256, 0)
-                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_query_persistent<Q, STATS>, 256, 0);
+            hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_query_persistent<Q, STATS>, 256, 0);
             occ = (e == hipSuccess && nb > 0) ? nb : 4;
             occ_a.store(occ, std::memory_order_relaxed);
         }
@@ -966,16 +964,45 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
         unsigned slot = __atomic_fetch_add(&st->next_counter, 1u, __ATOMIC_RELAXED) % (TR_NUM_COUNTERS / 8);
         unsigned long long* counter = reinterpret_cast<unsigned long long*>(st->counters) + 8 * slot;
         TR_HIP_TRY(hipMemsetAsync(counter, 0, 8 * sizeof(unsigned long long), stream));
-        if (opt.refill)
-            hipLaunchKernelGGL((k_query_refill<Q, STATS>), dim3((unsigned)pgrid), dim3(256), 0, stream,
-                               view, rf, out, counter, opt.refill_min, opt.xcd_segments ? 8 : 1, opt.leaf_min, d_stats);
-        else
-            hipLaunchKernelGGL((k_query_persistent<Q, STATS>), dim3((unsigned)pgrid), dim3(256), 0, stream,
-                               view, rf, out, counter, d_stats);
+        hipLaunchKernelGGL((k_query_persistent<Q, STATS>), dim3((unsigned)pgrid), dim3(256), 0, stream,
+                           view, rf, out, counter, d_stats);
     } else {
         const bool compact = opt.compact && bvh->depth <= 32 &&
                              bvh->num_nodes * (int64_t)sizeof(tr_node) < ((int64_t)1 << 32) &&
                              bvh->num_tris * (int64_t)sizeof(tr_tri) < ((int64_t)1 << 32);
+        // Streaming launch with ray refill for large batches that are not image-shaped (stream: 0
+        // never, 1 auto, 2 always).  Auto: flat or non-tileable batches of at least 2 M rays get BOTH
+        // launch shapes enqueued behind a coherence probe that selects one on the device
+        // (k_probe_coherence); image-shaped batches keep the direct launch (8x8 tiles).  The multi-hit
+        // list query keeps the direct launch (its per-ray list pointer belongs to a launch slot).
+        const bool image = rf.s1 > 1 && rf.s2 % 8 == 0 && rf.s2 >= 8 && rf.n % (8 * rf.s2) == 0;
+        const int* sel = nullptr;
+        if constexpr (Q != TR_Q_LOCATION) {
+            const bool auto_stream = opt.stream == 1 && !image && rf.n >= ((int64_t)1 << 21) && bvh->num_tris >= 2;
+            if (opt.stream == 2 || auto_stream) {
+                if (auto_stream) {
+                    unsigned slot = __atomic_fetch_add(&st->next_counter, 1u, __ATOMIC_RELAXED) % (TR_NUM_COUNTERS / 8);
+                    int* d_sel = reinterpret_cast<int*>(reinterpret_cast<unsigned long long*>(st->counters) + 8 * slot);
+                    float diag2 = 0.f;
+                    for (int k = 0; k < 3; k++) { const float e = bvh->aabb_max[k] - bvh->aabb_min[k]; diag2 += e * e; }
+                    hipLaunchKernelGGL(k_probe_coherence, dim3(1), dim3(256), 0, stream, rf, sqrtf(diag2), d_sel);
+                    sel = d_sel;
+                }
+                const int rpw = opt.stream_rays;
+                const int64_t nwaves = (rf.n + rpw - 1) / rpw;
+                const unsigned grid = (unsigned)((nwaves + 1) / 2);
+                int sxc = opt.xcd_chunk > 0 ? 16 : 0;       // blocks (2 ranges each) per XCD-local chunk
+                while (sxc > 0 && (int64_t)sxc * 32 > grid) sxc >>= 1;
+                if (compact)
+                    hipLaunchKernelGGL((k_query_stream<Q, STATS, true, 128>), dim3(grid), dim3(128), 0, stream,
+                                       view, rf, out, rpw, opt.stream_refill, sxc, d_stats, sel);
+                else
+                    hipLaunchKernelGGL((k_query_stream<Q, STATS, false, 128>), dim3(grid), dim3(128), 0, stream,
+                                       view, rf, out, rpw, opt.stream_refill, sxc, d_stats, sel);
+                TR_HIP_TRY(hipGetLastError());
+                if (!sel) return TR_OK;
+            }
+        }
         const uint32_t* order = nullptr;
         uint32_t* cost = nullptr;
         if (!STATS) sched_acquire(bvh, opt, stream, nblocks_direct, &order, &cost);
@@ -991,7 +1018,11 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
         // lanes all stay active through hundreds of trips, each trip then gathering 64
         // distinct nodes: the critical path of a small launch gets longer (-25 % at 1 M rays).
         // Hence tiles only from 4 M rays on (option tile: 0 never, 1 auto, 2 always).
-        if (opt.tile && (opt.tile == 2 || rf.n >= ((int64_t)1 << 22)) && rf.s1 > 1 && rf.s2 % 8 == 0 && rf.s2 >= 8 && rf.s2 < (1 << 30) && rf.n % (8 * rf.s2) == 0)
+        // Queries without distance pruning (count, location) have no such critical path -- every ray
+        // of a tile costs about the same -- and take tiles at any size: C4 count 1.12 -> 0.93 ms,
+        // location 1.38 -> 1.18 ms at 1 M rays (profiles/r02_sweep_c4.jsonl).
+        const bool tile_any_size = opt.tile == 2 || ((Q == TR_Q_COUNT || Q == TR_Q_LOCATION) && opt.unordered);
+        if (opt.tile && (tile_any_size || rf.n >= ((int64_t)1 << 22)) && rf.s1 > 1 && rf.s2 % 8 == 0 && rf.s2 >= 8 && rf.s2 < (1 << 30) && rf.n % (8 * rf.s2) == 0)
             tile_w = (int)rf.s2;
         int scramble = 0;
         if (xc > 0 && opt.scramble) {
@@ -1001,7 +1032,7 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
         }
 #define TR_LAUNCH_DIRECT(C, B)                                                                          \
     hipLaunchKernelGGL((k_query_direct<Q, STATS, C, B>), dim3((unsigned)nblocks_direct), dim3(B), 0, stream, \
-                       view, rf, out, xc, scramble, tile_w, steal_min, order, cost, d_stats)
+                       view, rf, out, xc, scramble, tile_w, steal_min, order, cost, d_stats, sel)
         // intra-wave work stealing (wave_traverse_steal).  steal = 1 (default): closest / first / any
         // launches of up to 4 M rays, donors from their 64th trip on -- +11 % on the headline, +45 % at
         // 262 k rays, +25 % on the 4-shell scene, -3 % on 1 M incoherent rays; larger launches are
@@ -1021,7 +1052,7 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
                 const int leaf_min = opt.leaf_vote;
 #define TR_LAUNCH_UNORD(C, B)                                                                            \
     hipLaunchKernelGGL((k_query_direct<Q, STATS, C, B, 2>), dim3((unsigned)nblocks_direct), dim3(B), 0, stream, \
-                       view, rf, out, xc, scramble, tile_w, leaf_min, order, cost, d_stats)
+                       view, rf, out, xc, scramble, tile_w, leaf_min, order, cost, d_stats, sel)
                 if (bs == 64) { if (compact) TR_LAUNCH_UNORD(true, 64); else TR_LAUNCH_UNORD(false, 64); }
                 else if (bs == 128) { if (compact) TR_LAUNCH_UNORD(true, 128); else TR_LAUNCH_UNORD(false, 128); }
                 else { if (compact) TR_LAUNCH_UNORD(true, 256); else TR_LAUNCH_UNORD(false, 256); }
@@ -1031,10 +1062,10 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
         if (steal) {
             if (compact)
                 hipLaunchKernelGGL((k_query_direct<Q, false, true, 128, 1>), dim3((unsigned)nblocks_direct), dim3(128), 0, stream,
-                                   view, rf, out, xc, scramble, tile_w, steal_min, order, cost, d_stats);
+                                   view, rf, out, xc, scramble, tile_w, steal_min, order, cost, d_stats, sel);
             else
                 hipLaunchKernelGGL((k_query_direct<Q, false, false, 128, 1>), dim3((unsigned)nblocks_direct), dim3(128), 0, stream,
-                                   view, rf, out, xc, scramble, tile_w, steal_min, order, cost, d_stats);
+                                   view, rf, out, xc, scramble, tile_w, steal_min, order, cost, d_stats, sel);
         } else
         if (bs == 64) { if (compact) TR_LAUNCH_DIRECT(true, 64); else TR_LAUNCH_DIRECT(false, 64); }
         else if (bs == 128) { if (compact) TR_LAUNCH_DIRECT(true, 128); else TR_LAUNCH_DIRECT(false, 128); }
