@@ -633,11 +633,18 @@ __global__ __launch_bounds__(BS) void k_query_stream(tr_bvh_view b, RayFetch rf,
             }
             next += nidle;     // lanes past `end` took nothing; the cursor only has to reach `end`
         }
-        if (busy) {
-            tr_fused_step<Q, 1, STATS, COMPACT, W>(b, r, fs, res, top, &cnt, ring);
-            busy = !tr_done(fs);
-        }
-        TR_CONVERGE();
+        // trips until the next refill is due (or, once the range is used up, until all lanes are
+        // done): a plain single-exit loop like the direct launch's, with a wave-uniform exit test
+        const int stop = next < end ? refill_min : 64;
+        int idle_now;
+        do {
+            if (busy) {
+                tr_fused_step<Q, 1, STATS, COMPACT, W>(b, r, fs, res, top, &cnt, ring);
+                busy = !tr_done(fs);
+            }
+            TR_CONVERGE();
+            idle_now = __popcll(__ballot(!busy));
+        } while (idle_now < stop);
     }
     if (rid >= 0) write_result<Q>(b, out, rid, r, res);
     flush_stats<STATS>(cnt, stats);
