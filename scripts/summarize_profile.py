@@ -47,10 +47,30 @@ if trace:
     durs = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(trace[0]))
             if kernel_key in r["Kernel_Name"]]
     steps = int(os.environ.get("PROFILE_STEPS", "20"))
-    if len(durs) >= steps:
-        tail = durs[-steps:]
-        out["timed_region"] = {"kernel": kernel_key, "steps": steps, "avg_us": sum(tail) / len(tail) / 1e3,
-                               "min_us": min(tail) / 1e3, "max_us": max(tail) / 1e3,
+    # bench.py: dispatch 0 = first call, then `warmup_steps_done` warm-up calls, then `steps` timed
+    # calls, then (default flags) the cold / moving-camera / instrumented companions.  The count of
+    # warm-up calls is in the JSON line bench.py printed (trace.log); without it fall back to "the
+    # last `steps` dispatches" (run_query.py, bench.py --no-companions).
+    skip = None
+    tlog = os.path.join(root, "trace.log")
+    if os.path.exists(tlog):
+        for ln in open(tlog, errors="replace"):
+            if ln.startswith('{"metric"'):
+                try:
+                    j = json.loads(ln)
+                    skip = 1 + int(j["config"]["warmup_steps_done"])
+                    steps = int(j["steps"])
+                except Exception:
+                    pass
+    if skip is not None and len(durs) >= skip + steps:
+        win = durs[skip:skip + steps]
+    elif len(durs) >= steps:
+        win = durs[-steps:]
+    else:
+        win = []
+    if win:
+        out["timed_region"] = {"kernel": kernel_key, "steps": steps, "avg_us": sum(win) / len(win) / 1e3,
+                               "min_us": min(win) / 1e3, "max_us": max(win) / 1e3,
                                "first_call_us": durs[0] / 1e3}
 pmc = defaultdict(list)
 meta = {}
@@ -93,8 +113,8 @@ with open(os.path.join("profiles", f"{tag}_summary.md"), "w") as f:
         f.write(f"| `{k['name']}` | {k['calls']} | {k['avg_ns']/1e3:.1f} | {k['min_ns']/1e3:.1f} | {k['max_ns']/1e3:.1f} | {k['pct']:.2f} |\n")
     if "timed_region" in out:
         t = out["timed_region"]
-        f.write(f"\nTimed region (last {t['steps']} dispatches of `{t['kernel']}`, i.e. without the first call "
-                f"({t['first_call_us']:.1f} us, no learned launch order yet) and the warm-up): "
+        f.write(f"\nTimed region ({t['steps']} timed dispatches of `{t['kernel']}`, i.e. without the first call "
+                f"({t['first_call_us']:.1f} us, no learned launch order yet), the warm-up and bench.py's companions): "
                 f"avg {t['avg_us']:.1f} us, min {t['min_us']:.1f}, max {t['max_us']:.1f}.\n")
     f.write(f"\n## PMC (separate passes), kernel filter `{kernel_key}`, averages per launch\n\nlaunch: {meta}\n\n| counter | value |\n|---|---|\n")
     for k, v in sorted(p.items()):
