@@ -407,6 +407,12 @@ __global__ __launch_bounds__(BS) void k_query_direct(tr_bvh_view b, RayFetch rf,
                                                       const int* __restrict__ sel) {
     // dual launch (k_probe_coherence): this launch shape is the one for coherent batches (id 0)
     if (sel && *sel != 0) return;
+#ifdef TR_LDS_PAD
+    // experiment (scripts/exp_lds_budget.sh): what would a per-workgroup LDS table of TR_LDS_PAD
+    // bytes (e.g. the top levels of the tree staged once per workgroup) cost in occupancy alone?
+    __shared__ volatile int32_t pad_lds[TR_LDS_PAD / 4];
+    pad_lds[threadIdx.x] = (int32_t)blockIdx.x;      // volatile: the allocation must survive
+#endif
     const unsigned long long t_start = cost ? wall_clock64() : 0ull;
     __shared__ int32_t ring_lds[TR_RING * BS];
     const tr_ring ring = {ring_lds + threadIdx.x, BS};
