@@ -10,7 +10,7 @@ from triro.backend import ops as hops
 from triro.ray.ray_optix import RayMeshIntersector
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=1 << 20); ap.add_argument("--mesh", default="headline"); ap.add_argument("--query", default="closest")
-ap.add_argument("--steps", type=int, default=20); ap.add_argument("--opt", action="append", default=[])
+ap.add_argument("--steps", type=int, default=20); ap.add_argument("--shape", default="", help="e.g. 8,-1 : reshape the batch to [8, n/8, 3]"); ap.add_argument("--opt", action="append", default=[])
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 for kv in a.opt:
@@ -19,6 +19,9 @@ v, f = W.headline_mesh(8) if a.mesh == "headline" else W.bunny_standin()
 T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
 r = RayMeshIntersector(vertices=T(v), faces=T(f))
 o, d = W.hash_rays_torch(a.n, 99, v.min(0) * 1.5, v.max(0) * 1.5, device=dev)
+if a.shape:
+    dims = [int(x) for x in a.shape.split(",")]
+    o, d = o.reshape(*dims, 3), d.reshape(*dims, 3)
 fn = {"closest": lambda: r.intersects_closest(o, d), "any": lambda: r.intersects_any(o, d), "count": lambda: r.intersects_count(o, d)}[a.query]
 for _ in range(4): fn()
 torch.cuda.synchronize()

@@ -345,8 +345,11 @@ def test_large_flat_batches_probe_and_both_launch_shapes(device):
     o1, d1 = W.pinhole_grid(1536, 1408, distance=2.5 * 1.12)
     o1, d1 = np.ascontiguousarray(o1).reshape(-1, 3), d1.reshape(-1, 3)          # coherent, flat, 2.16 M rays
     o2, d2 = W.hash_rays(2_200_001, 61, v.min(0) * 1.5, v.max(0) * 1.5)           # incoherent
+    o3, d3 = W.hash_rays(2_228_224, 62, v.min(0) * 1.5, v.max(0) * 1.5)           # incoherent but "image-shaped"
+    o3, d3 = o3.reshape(17, 131072, 3), d3.reshape(17, 131072, 3)
+    o4, d4 = W.pinhole_grid(1536, 1408, distance=2.5 * 1.12)                     # a real image (tiles)
     try:
-        for o, d in ((o1, d1), (o2, d2)):
+        for o, d in ((o1, d1), (o2, d2), (o3, d3), (np.ascontiguousarray(o4), d4)):
             ot, dt = T(o, device), T(d, device)
             exp = R.closest_raw(o, d)
             cnt = R.intersects_count(o, d)
@@ -357,6 +360,6 @@ def test_large_flat_batches_probe_and_both_launch_shapes(device):
                 assert np.array_equal(r.intersects_count(ot, dt).cpu().numpy(), cnt)
             hops.set_option("stream", 1)
             st = hops.trace_stats(r.as_wrapper, ot, dt, "closest")              # the instrumented launch takes the same path
-            assert st["rays"] == len(o) and st["node_visits"] > 0
+            assert st["rays"] == o.size // 3 and st["node_visits"] > 0
     finally:
         hops.set_option("stream", 1)

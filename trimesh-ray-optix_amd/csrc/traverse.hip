@@ -983,15 +983,15 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
         const bool compact = opt.compact && bvh->depth <= 32 &&
                              bvh->num_nodes * (int64_t)sizeof(tr_node) < ((int64_t)1 << 32) &&
                              bvh->num_tris * (int64_t)sizeof(tr_tri) < ((int64_t)1 << 32);
-        // Streaming launch with ray refill for large batches that are not image-shaped (stream: 0
-        // never, 1 auto, 2 always).  Auto: flat or non-tileable batches of at least 2 M rays get BOTH
-        // launch shapes enqueued behind a coherence probe that selects one on the device
-        // (k_probe_coherence); image-shaped batches keep the direct launch (8x8 tiles).  The multi-hit
-        // list query keeps the direct launch (its per-ray list pointer belongs to a launch slot).
-        const bool image = rf.s1 > 1 && rf.s2 % 8 == 0 && rf.s2 >= 8 && rf.n % (8 * rf.s2) == 0;
+        // Streaming launch with ray refill for large incoherent batches (stream: 0 never, 1 auto,
+        // 2 always).  Auto: every batch of at least 2 M rays gets BOTH launch shapes enqueued behind a
+        // coherence probe that selects one on the device (k_probe_coherence): a camera image -- flat
+        // or [H, W, 3] -- keeps the direct launch (and its 8x8 tiles), a batch of unrelated rays
+        // takes the streaming launch whatever its tensor shape.  The multi-hit list query keeps the
+        // direct launch (its per-ray list pointer belongs to a launch slot).
         const int* sel = nullptr;
         if constexpr (Q != TR_Q_LOCATION) {
-            const bool auto_stream = opt.stream == 1 && !image && rf.n >= ((int64_t)1 << 21) && bvh->num_tris >= 2;
+            const bool auto_stream = opt.stream == 1 && rf.n >= ((int64_t)1 << 21) && bvh->num_tris >= 2;
             if (opt.stream == 2 || auto_stream) {
                 if (auto_stream) {
                     unsigned slot = __atomic_fetch_add(&st->next_counter, 1u, __ATOMIC_RELAXED) % (TR_NUM_COUNTERS / 8);
