@@ -363,3 +363,33 @@ def test_large_flat_batches_probe_and_both_launch_shapes(device):
             assert st["rays"] == o.size // 3 and st["node_visits"] > 0
     finally:
         hops.set_option("stream", 1)
+
+
+def test_queries_can_be_captured_in_a_hip_graph(device):
+    """The query entry points allocate nothing and never synchronise once the per-(handle, stream)
+    scheduling buffers exist, so a warmed-up call can be captured with torch.cuda.graph and replayed
+    (HIP graph): same results as the eager call, also after the rays in the captured buffers change."""
+    v, f = W.bunny_standin()
+    r = make(v, f, device)
+    o, d = W.pinhole_grid(256, 256, distance=2.5 * 1.12)
+    ot, dt = T(o, device), T(d, device)
+    R = OracleIntersector(v, f, 1)
+    side = torch.cuda.Stream(device=device)
+    side.wait_stream(torch.cuda.current_stream(device))
+    with torch.cuda.stream(side):
+        for _ in range(3):                       # warm-up on the capture stream: creates its hint buffers
+            r.intersects_closest(ot, dt)
+            r.intersects_count(ot, dt)
+    torch.cuda.current_stream(device).wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        out = r.intersects_closest(ot, dt)
+        cnt = r.intersects_count(ot, dt)
+    for k in range(3):
+        ot.copy_(T(o, device) + 0.01 * k)        # new rays in the captured input buffers
+        g.replay()
+        torch.cuda.synchronize()
+        exp = R.closest_raw((o + np.float32(0.01 * k)).astype(np.float32), d)
+        assert_closest_bitexact(out, exp, f"graph replay {k}")
+        assert np.array_equal(cnt.cpu().numpy(), R.intersects_count((o + np.float32(0.01 * k)).astype(np.float32), d))
