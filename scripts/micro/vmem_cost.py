@@ -14,13 +14,17 @@ g = torch.Generator(device=dev); g.manual_seed(1)
 CLK = 2.4e9
 
 
-def run(table_bytes, stride, nq, nd, ns, waves_per_simd, lane_mask=(1 << 64) - 1, steps=512):
+def run(table_bytes, stride, nq, nd, ns, waves_per_simd, lane_mask=(1 << 64) - 1, steps=512, share=1):
+    """share = number of neighbouring lanes that walk the SAME chain (same address every step):
+    64 // share distinct cache lines per wave-instruction"""
     nrec = table_bytes // stride
     table = torch.empty(nrec * stride // 4, dtype=torch.float32, device=dev).uniform_()
     nxt = torch.randint(0, nrec, (nrec,), device=dev, dtype=torch.int32, generator=g)
     table.view(torch.int32)[:: stride // 4] = nxt           # first dword of every record = next index
     nthreads = 256 * 4 * 64 * waves_per_simd
     idx = torch.randint(0, nrec, (nthreads,), device=dev, dtype=torch.int32, generator=g)
+    if share > 1:
+        idx = idx.reshape(-1, share)[:, :1].expand(-1, share).reshape(-1).contiguous()
     out = torch.empty(nthreads, device=dev)
     s = torch.cuda.current_stream().cuda_stream
 
@@ -39,7 +43,7 @@ def run(table_bytes, stride, nq, nd, ns, waves_per_simd, lane_mask=(1 << 64) - 1
     # CU-cycles per wave-step (all waves of a CU share its TA/TD): time * clk / (steps * waves on the CU)
     cyc = best * 1e-3 * CLK / (steps * waves_per_cu)
     active = bin(lane_mask).count("1")
-    rec = {"table_KiB": table_bytes // 1024, "stride": stride, "loads": f"{nq}x16+{nd}x8+{ns}x4", "waves_per_simd": waves_per_simd,
+    rec = {"distinct_lines_per_instr": 64 // share, "table_KiB": table_bytes // 1024, "stride": stride, "loads": f"{nq}x16+{nd}x8+{ns}x4", "waves_per_simd": waves_per_simd,
            "active_lanes": active, "ms": round(best, 4), "cu_cycles_per_wave_step@2.4GHz": round(cyc, 1),
            "G_lane_steps_per_s": round(nthreads * (active / 64) * steps / best / 1e6, 1)}
     print(json.dumps(rec), flush=True)
@@ -48,6 +52,13 @@ def run(table_bytes, stride, nq, nd, ns, waves_per_simd, lane_mask=(1 << 64) - 1
 FULL = (1 << 64) - 1
 # per-instruction floor by width: ONE active lane per wave (and 4 instructions per step so that the
 # chain latency does not dominate): dwordx4 vs dwordx2
+if len(sys.argv) > 1 and sys.argv[1] == "share":
+    # coherence: 64 active lanes, 64 / share distinct lines per wave-instruction (the traversal's case:
+    # neighbouring rays visit the same node)
+    for tb in (16 << 10, 2 << 20):
+        for share in (64, 32, 16, 8, 4, 2, 1):
+            run(tb, 64, 4, 0, 0, 7, share=share)
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "floor":
     for tb in (16 << 10,):
         for mask in (0x1, 0x0001000100010001, FULL):
