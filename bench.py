@@ -286,6 +286,11 @@ def run_rank(args):
         sync()
         return [a.elapsed_time(b) for a, b in ev] if not stub else [0.0] * count
 
+    # bring the communicator up BEFORE the warm-up (the first collective builds the RCCL rings: hundreds
+    # of milliseconds with an idle GPU); the barrier in front of the timed region is then a few tens of
+    # microseconds and does not let the clocks drop
+    barrier()
+    barrier()
     sync()
     t_first = time.perf_counter()
     out = step()                      # very first call: lazy initialisation + no learned launch order yet
