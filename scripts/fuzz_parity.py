@@ -18,7 +18,7 @@ dev = torch.device("cuda:0")
 T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
 DEFAULTS = {"steal": 1, "tile": 1, "block_size": 128, "adaptive": 1, "xcd_chunk": 128, "compact": 1, "scramble": 1,
             "persistent": 0, "blocks_per_cu": 8,
-            "unordered": 1, "leaf_vote": 16, "stream": 1, "stream_rays": 512, "stream_refill": 16}
+            "tile_small": 4, "unordered": 1, "leaf_vote": 16, "stream": 1, "stream_rays": 512, "stream_refill": 16}
 bad = 0
 for it in range(a.iters):
     kind = rng.integers(0, 5)
@@ -58,6 +58,7 @@ for it in range(a.iters):
             # unordered two-phase schedule of count / location (2: any as well) and its leaf-phase vote
             "unordered": int(rng.choice([0, 1, 1, 2])), "leaf_vote": int(rng.choice([1, 4, 16, 48, 64])),
             # streaming launch with wave-level ray refill (2 = forced at any size and shape)
+            "tile_small": int(rng.choice([0, 1, 2, 3, 4])),
             "stream": int(rng.choice([0, 1, 2, 2])), "stream_rays": int(rng.choice([64, 100, 512, 4096])),
             "stream_refill": int(rng.choice([1, 8, 16, 40, 64]))}
     for k, val in opts.items(): hops.set_option(k, val)

@@ -29,6 +29,7 @@ ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--warmup", type=int, default=4)
 ap.add_argument("--res", type=int, default=1024)
 ap.add_argument("--opt", action="append", default=[])
+ap.add_argument("--subdiv", type=int, default=8, help="c5i / c5s: icosphere subdivisions of the headline mesh")
 ap.add_argument("--flat", action="store_true", help="pass image-shaped rays as a flat [N, 3] batch")
 ap.add_argument("--stats", action="store_true", help="also run the instrumented kernel (traversal counters)")
 a = ap.parse_args()
@@ -43,7 +44,7 @@ if a.config in ("c2", "c3"):
 elif a.config == "c4":
     v, f = W.nested_shells(7)
 else:
-    v, f = W.headline_mesh(8)
+    v, f = W.headline_mesh(a.subdiv)
 r = RayMeshIntersector(vertices=T(v), faces=T(f))
 rad = float(np.linalg.norm(v, axis=1).max())
 if a.config == "c3":

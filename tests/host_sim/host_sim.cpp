@@ -70,6 +70,67 @@ static int build_hierarchy(SimBvh& b, const std::vector<uint64_t>& keys, const s
     return round;
 }
 
+// EXPERIMENT (scripts/exp_tree_shape.py): hierarchy over the Morton-sorted leaves that splits every
+// range [a, b] at a chosen index instead of at the highest differing Morton bit.
+//   split_mode 2: the middle index (count-balanced, depth = ceil(log2 n))
+//   split_mode 3: the Karras split if it is not too lopsided (both sides >= 1/8 of the range), else the middle
+static int32_t build_split_rec(SimBvh& b, const std::vector<uint64_t>& keys, const std::vector<float>& sbox,
+                               std::vector<float>& ibox, std::vector<int32_t>& cl, std::vector<int32_t>& cr,
+                               std::vector<int32_t>& par, int64_t a, int64_t z, int32_t& next, int split_mode,
+                               int depth, int& maxdepth) {
+    // returns child id of the subtree over leaves [a, z]
+    if (a == z) return ~(int32_t)a;
+    const int32_t me = next++;
+    if (depth + 1 > maxdepth) maxdepth = depth + 1;
+    int64_t m = (a + z) / 2;
+    if (split_mode == 3) {
+        const uint64_t ka = keys[a], kz = keys[z];
+        if (ka != kz) {
+            const int prefix = __builtin_clzll(ka ^ kz);
+            int64_t lo = a, hi = z;                 // last index whose key shares more than `prefix` bits with ka
+            while (lo < hi) {
+                const int64_t mid = (lo + hi + 1) / 2;
+                if (__builtin_clzll(ka ^ keys[mid]) > prefix) lo = mid; else hi = mid - 1;
+            }
+            const int64_t n = z - a + 1, left = lo - a + 1;
+            if (left * 8 >= n && (n - left) * 8 >= n) m = lo;
+        }
+    }
+    const int32_t l = build_split_rec(b, keys, sbox, ibox, cl, cr, par, a, m, next, split_mode, depth + 1, maxdepth);
+    const int32_t r = build_split_rec(b, keys, sbox, ibox, cl, cr, par, m + 1, z, next, split_mode, depth + 1, maxdepth);
+    cl[me] = l; cr[me] = r;
+    if (l >= 0) par[l] = me;
+    if (r >= 0) par[r] = me;
+    const float* A = l < 0 ? &sbox[6 * (int64_t)(~l)] : &ibox[6 * (int64_t)l];
+    const float* C = r < 0 ? &sbox[6 * (int64_t)(~r)] : &ibox[6 * (int64_t)r];
+    for (int k = 0; k < 3; k++) { ibox[6 * me + k] = fminf(A[k], C[k]); ibox[6 * me + 3 + k] = fmaxf(A[3 + k], C[3 + k]); }
+    return me;
+}
+static int build_hierarchy_split(SimBvh& b, const std::vector<uint64_t>& keys, const std::vector<float>& sbox, int split_mode) {
+    const int64_t n = (int64_t)keys.size(), ni = n - 1;
+    std::vector<int32_t> cl(ni), cr(ni), par(ni, -1);
+    std::vector<float> ibox(6 * ni);
+    int32_t next = 0;
+    int maxdepth = 0;
+    build_split_rec(b, keys, sbox, ibox, cl, cr, par, 0, n - 1, next, split_mode, 0, maxdepth);
+    b.nodes.resize(ni);
+    b.links.resize(ni);
+    for (int64_t i = 0; i < ni; i++) {
+        const float* a = cl[i] < 0 ? &sbox[6 * (int64_t)(~cl[i])] : &ibox[6 * (int64_t)cl[i]];
+        const float* c = cr[i] < 0 ? &sbox[6 * (int64_t)(~cr[i])] : &ibox[6 * (int64_t)cr[i]];
+        tr_node nd;
+        tr_node_set_box(nd.box0, a, a + 3);
+        tr_node_set_box(nd.box1, c, c + 3);
+        nd.c0 = cl[i]; nd.c1 = cr[i];
+        int32_t p = par[i], sib = 0;
+        if (p >= 0) sib = (cl[p] == (int32_t)i) ? cr[p] : cl[p];
+        nd.parent = p; nd.sibling = sib;
+        b.nodes[i] = nd;
+        b.links[i].parent = p; b.links[i].sibling = sib;
+    }
+    return maxdepth;
+}
+
 extern "C" {
 
 // force_mode: -1 = as the GPU builder decides (mode 0, fallback to 1 if height > 64), 0/1 force
@@ -115,8 +176,11 @@ void* sim_build(const float* verts, int64_t nv, const int32_t* faces, int64_t nf
     }
     if (nf >= 2) {
         int h = -1;
+        if (force_mode == 2 || force_mode == 3) { h = build_hierarchy_split(*b, skeys, sbox, force_mode); b->key_mode = force_mode; }
+        else {
         if (force_mode != 1) { h = build_hierarchy<0>(*b, skeys, sbox); b->key_mode = 0; }
         if (force_mode == 1 || (force_mode < 0 && h > 64)) { h = build_hierarchy<1>(*b, skeys, sbox); b->key_mode = 1; }
+        }
         b->depth = h;
     }
     return b;

@@ -451,8 +451,18 @@ def test_tile_mapping_is_a_pure_permutation(device):
                 for x, y in zip(got, ref):
                     assert torch.equal(x, y), name
             assert torch.equal(r.intersects_count(oo, dd), cref), name
+            hops.set_option("tile", 1)
+            for shape in (1, 2, 3, 4, 0):          # 2x32, 4x16, 8x8 tiles, by density, rows
+                hops.set_option("tile_small", shape)
+                for _ in range(2):
+                    got = r.intersects_closest(oo, dd)
+                    for x, y in zip(got, ref):
+                        assert torch.equal(x, y), (name, shape)
+                assert torch.equal(r.intersects_first(oo, dd), ref[2]), (name, shape)
+                assert torch.equal(r.intersects_any(oo, dd), ref[0]), (name, shape)
     finally:
         hops.set_option("tile", 1)
+        hops.set_option("tile_small", 4)
 
 
 def test_adaptive_launch_order_never_changes_results(device):

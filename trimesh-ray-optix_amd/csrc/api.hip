@@ -30,6 +30,7 @@ const opt_desc OPTS[] = {
     {"xcd_chunk", &tr_options::xcd_chunk, 0, 65536, false},
     {"steal", &tr_options::steal, 0, 4096, false},
     {"tile", &tr_options::tile, 0, 2, false},
+    {"tile_small", &tr_options::tile_small, 0, 4, false},
     {"scramble", &tr_options::scramble, 0, 1, true},
     {"build_cache", &tr_options::build_cache, 0, 1, true},
     {"unordered", &tr_options::unordered, 0, 2, false},

@@ -128,6 +128,7 @@ struct tr_options {
     int xcd_chunk = 128;    // direct kernel: blocks per XCD-local chunk (0 = identity map)
     int steal = 1;        // intra-wave work stealing: 0 off, 1 auto (closest/first/any up to 4 M rays), >= 2 forced with that trip threshold
     int tile = 1;         // image-shaped batches: waves take 8x8 pixel tiles (0 never, 1 from 4 M rays on, 2 always)
+    int tile_small = 4;   // image-shaped batches below the `tile` threshold: 0 rows of 64 pixels, 1 = 2x32, 2 = 4x16, 3 = 8x8 tiles, 4 = by triangles per ray
     int scramble = 1;     // launches without a measured order visit each XCD's blocks in a scrambled order
     int build_cache = 1;  // keep the builder's temporaries (about 130 B/triangle) per device between builds
     int stream = 1;       // streaming launch with wave-level ray refill: 0 never, 1 large non-image batches, 2 always

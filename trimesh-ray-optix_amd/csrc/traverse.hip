@@ -439,11 +439,14 @@ __global__ __launch_bounds__(BS) void k_query_direct(tr_bvh_view b, RayFetch rf,
     }
     int64_t i = blk * BS + threadIdx.x;
     if (tile_w > 0) {
-        // image-shaped batch: a wave takes an 8x8 pixel tile instead of 64 pixels of one row
-        const int64_t tile = i >> 6, tpr = tile_w >> 3;
+        // image-shaped batch: a wave takes a tile of 2^lgh rows x 2^(6-lgh) pixels (8x8, 4x16 or
+        // 2x32; lgh in bits 28-29 of the argument) instead of 64 pixels of one row
+        const int lgh = (tile_w >> 28) & 3, lgw = 6 - lgh;
+        const int64_t width = tile_w & 0x0fffffff;
+        const int64_t tile = i >> 6, tpr = width >> lgw;
         const int lane = (int)(i & 63);
         const int64_t ty = tile / tpr, tx = tile - ty * tpr;
-        i = (ty * 8 + (lane >> 3)) * tile_w + tx * 8 + (lane & 7);
+        i = ((ty << lgh) + (lane >> lgw)) * width + (tx << lgw) + (lane & ((1 << lgw) - 1));
     }
     tr_counters cnt = {0, 0, 0};
     if (MODE == 2) {
@@ -1035,8 +1038,22 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
         // of a tile costs about the same -- and take tiles at any size: C4 count 1.12 -> 0.93 ms,
         // location 1.38 -> 1.18 ms at 1 M rays (profiles/r02_sweep_c4.jsonl).
         const bool tile_any_size = opt.tile == 2 || ((Q == TR_Q_COUNT || Q == TR_Q_LOCATION) && opt.unordered);
-        if (opt.tile && (tile_any_size || rf.n >= ((int64_t)1 << 22)) && rf.s1 > 1 && rf.s2 % 8 == 0 && rf.s2 >= 8 && rf.s2 < (1 << 30) && rf.n % (8 * rf.s2) == 0)
-            tile_w = (int)rf.s2;
+        if (opt.tile && (tile_any_size || rf.n >= ((int64_t)1 << 22)) && rf.s1 > 1 && rf.s2 % 8 == 0 && rf.s2 >= 8 && rf.s2 < (1 << 28) && rf.n % (8 * rf.s2) == 0)
+            tile_w = (int)rf.s2 | (3 << 28);
+        // Smaller image-shaped batches of the pruning queries: flatter tiles where the triangles are
+        // large on screen (option tile_small: 0 rows, 1 = 2x32, 2 = 4x16, 3 = 8x8, 4 = auto).  Host
+        // simulation of the headline image (scripts/exp_tree_shape.py): 2x32 / 4x16 / 8x8 tiles need
+        // 11 / 15 / 16 % fewer wave-trips than rows of 64 pixels, but with a triangle per pixel a
+        // compact tile also packs the expensive silhouette rays into the same waves (1 M rays on
+        // 1.31 M triangles: 0.270 / 0.276 / 0.321 ms for rows / 2x32 / 4x16).  With triangles of many
+        // pixels that does not happen: 1 M rays on 82 k triangles 0.161 -> 0.149 ms (2x32), on 20 k
+        // triangles 0.130 -> 0.109 ms (4x16) (profiles/r02_sweep_tile_density.jsonl).
+        if (opt.tile && !tile_w && opt.tile_small > 0 && rf.s1 > 1 && rf.s2 < (1 << 28)) {
+            int lgh = opt.tile_small;
+            if (lgh == 4) lgh = rf.n >= 32 * bvh->num_tris ? 2 : (rf.n >= 8 * bvh->num_tris ? 1 : 0);
+            const int w = 64 >> lgh, h = 1 << lgh;
+            if (lgh > 0 && rf.s2 % w == 0 && rf.n % ((int64_t)h * rf.s2) == 0) tile_w = (int)rf.s2 | (lgh << 28);
+        }
         int scramble = 0;
         if (xc > 0 && opt.scramble) {
             const int64_t cnt = nblocks_direct / (8 * (int64_t)xc) * xc;   // blocks per XCD in whole spans
