@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define TR_ABI_VERSION 3
+#define TR_ABI_VERSION 4
 #define TR_MAX_ANYHIT_SIZE 8 /* LaunchParams.h:8  (per-ray cap of intersects_location) */
 #define TR_MAX_SIZE_LENGTH 4 /* LaunchParams.h:9  (ray tensors have <= 4 dims)         */
 #define TR_MAX_HITS_CAP 32   /* largest `cap` tr_intersects_location_fill accepts      */
@@ -63,7 +63,7 @@ typedef struct tr_bvh_info {
     int32_t depth;         /* height of the hierarchy in internal-node levels       */
     int32_t key_mode;      /* 0: 63-bit Morton keys, 1: depth-bounded fallback keys */
     int64_t arena_bytes;   /* bytes of device memory owned by the handle            */
-    int64_t node_bytes;    /* bytes of traversal nodes (64 B each)                  */
+    int64_t node_bytes;    /* bytes of traversal nodes (64 B + 32 B grid copy each) */
     int64_t tri_bytes;     /* bytes of leaf triangle records (48 B each)            */
     float aabb_min[3];     /* mesh bounds                                            */
     float aabb_max[3];
@@ -110,6 +110,10 @@ int tr_bvh_get_info(const tr_bvh *bvh, tr_bvh_info *info);
  *    nodes: num_nodes*16 words (64 B), links: num_nodes*2 int32, tris: num_tris*12 words. */
 int tr_bvh_download(const tr_bvh *bvh, void *h_nodes, void *h_links, void *h_tris,
                     void *stream);
+/*    test hook: the second node array (num_nodes*8 words: 32-byte nodes with both child boxes on
+ *    a 16-bit grid, used by the unordered count / location schedule) and its grid
+ *    (h_frame6 = base[3], scale[3]; plane q of axis k lies at fma(q, scale[k], base[k])).   */
+int tr_bvh_download_qnodes(const tr_bvh *bvh, void *h_qnodes, float *h_frame6, void *stream);
 
 /* -- queries: replace intersectsAny/First/Closest/Count/Location (ray.cpp:161-378,
  *    binding.cpp:49-58).  Output element i belongs to flat ray index i.

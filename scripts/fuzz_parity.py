@@ -18,7 +18,7 @@ dev = torch.device("cuda:0")
 T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
 DEFAULTS = {"steal": 1, "tile": 1, "block_size": 128, "adaptive": 1, "xcd_chunk": 128, "compact": 1, "scramble": 1,
             "persistent": 0, "blocks_per_cu": 8,
-            "tile_small": 4, "unordered": 1, "leaf_vote": 16, "stream": 1, "stream_rays": 512, "stream_refill": 16}
+            "tile_small": 4, "unordered": 1, "leaf_vote": 32, "stream": 1, "stream_rays": 512, "stream_refill": 16}
 bad = 0
 for it in range(a.iters):
     kind = rng.integers(0, 5)

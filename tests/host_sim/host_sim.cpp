@@ -13,6 +13,8 @@
 #include "../../trimesh-ray-optix_amd/csrc/tr_lbvh.h"
 
 struct SimBvh {
+    tr_qframe frame = {{0, 0, 0}, {1, 1, 1}};
+    std::vector<tr_qnode> qnodes;   // 32-byte grid nodes of the unordered schedule
     std::vector<tr_node> nodes;
     std::vector<tr_link> links;
     std::vector<tr_tri> tris;
@@ -54,6 +56,7 @@ static int build_hierarchy(SimBvh& b, const std::vector<uint64_t>& keys, const s
     if (ready[0] == 0) return -1;
     b.nodes.resize(ni);
     b.links.resize(ni);
+    b.qnodes.resize(ni);
     for (int64_t i = 0; i < ni; i++) {
         const float* a = cl[i] < 0 ? &sbox[6 * (int64_t)(~cl[i])] : &ibox[6 * (int64_t)cl[i]];
         const float* c = cr[i] < 0 ? &sbox[6 * (int64_t)(~cr[i])] : &ibox[6 * (int64_t)cr[i]];
@@ -66,6 +69,11 @@ static int build_hierarchy(SimBvh& b, const std::vector<uint64_t>& keys, const s
         nd.parent = p; nd.sibling = sib;
         b.nodes[i] = nd;
         b.links[i].parent = p; b.links[i].sibling = sib;
+        tr_qnode qn;
+        tr_qnode_set_box(qn.q, a, a + 3, b.frame);
+        tr_qnode_set_box(qn.q + 3, c, c + 3, b.frame);
+        qn.c0 = cl[i]; qn.c1 = cr[i];
+        b.qnodes[i] = qn;
     }
     return round;
 }
@@ -115,6 +123,7 @@ static int build_hierarchy_split(SimBvh& b, const std::vector<uint64_t>& keys, c
     build_split_rec(b, keys, sbox, ibox, cl, cr, par, 0, n - 1, next, split_mode, 0, maxdepth);
     b.nodes.resize(ni);
     b.links.resize(ni);
+    b.qnodes.resize(ni);
     for (int64_t i = 0; i < ni; i++) {
         const float* a = cl[i] < 0 ? &sbox[6 * (int64_t)(~cl[i])] : &ibox[6 * (int64_t)cl[i]];
         const float* c = cr[i] < 0 ? &sbox[6 * (int64_t)(~cr[i])] : &ibox[6 * (int64_t)cr[i]];
@@ -127,6 +136,11 @@ static int build_hierarchy_split(SimBvh& b, const std::vector<uint64_t>& keys, c
         nd.parent = p; nd.sibling = sib;
         b.nodes[i] = nd;
         b.links[i].parent = p; b.links[i].sibling = sib;
+        tr_qnode qn;
+        tr_qnode_set_box(qn.q, a, a + 3, b.frame);
+        tr_qnode_set_box(qn.q + 3, c, c + 3, b.frame);
+        qn.c0 = cl[i]; qn.c1 = cr[i];
+        b.qnodes[i] = qn;
     }
     return maxdepth;
 }
@@ -152,6 +166,7 @@ void* sim_build(const float* verts, int64_t nv, const int32_t* faces, int64_t nf
             mx[k] = fmaxf(mx[k], tribox[6 * f + 3 + k]);
         }
     }
+    tr_qframe_make(mn, mx, &b->frame);   // as the GPU builder: the grid of the 32-byte nodes from the mesh bounds
     std::vector<uint64_t> keys(nf);
     for (int64_t f = 0; f < nf; f++) keys[f] = (tr_morton63(&tribox[6 * f], mn, mx) >> morton_shift) << morton_shift;
     std::vector<uint32_t> order(nf);
@@ -190,6 +205,11 @@ void sim_destroy(void* h) { delete (SimBvh*)h; }
 int sim_depth(void* h) { return ((SimBvh*)h)->depth; }
 int sim_key_mode(void* h) { return ((SimBvh*)h)->key_mode; }
 int64_t sim_num_nodes(void* h) { return (int64_t)((SimBvh*)h)->nodes.size(); }
+void sim_get_qnodes(void* h, void* qnodes, float* frame6) {
+    SimBvh* b = (SimBvh*)h;
+    if (qnodes) memcpy(qnodes, b->qnodes.data(), b->qnodes.size() * sizeof(tr_qnode));
+    for (int k = 0; k < 3; k++) { frame6[k] = b->frame.base[k]; frame6[3 + k] = b->frame.scale[k]; }
+}
 void sim_get(void* h, void* nodes, void* links, void* tris) {
     SimBvh* b = (SimBvh*)h;
     if (nodes) memcpy(nodes, b->nodes.data(), b->nodes.size() * sizeof(tr_node));
@@ -199,8 +219,12 @@ void sim_get(void* h, void* nodes, void* links, void* tris) {
 }  // extern "C"
 
 // traverse with externally supplied arrays (e.g. downloaded from the GPU builder)
+static const tr_qnode* g_qnodes = nullptr;            // grid nodes + frame of the arrays handed to sim_query
+static tr_qframe g_frame = {{0, 0, 0}, {1, 1, 1}};    // (sim_set_qnodes; needed by the unordered schedule only)
 static tr_bvh_view view_of(const tr_node* nodes, const tr_link* links, const tr_tri* tris, int64_t nf) {
-    tr_bvh_view v; v.nodes = nodes; v.links = links; v.tris = tris; v.num_tris = nf; return v;
+    tr_bvh_view v; v.nodes = nodes; v.links = links; v.tris = tris; v.num_tris = nf;
+    v.qnodes = g_qnodes; v.frame = g_frame;
+    return v;
 }
 
 static int g_use_ring = 1;
@@ -265,6 +289,10 @@ static void run_query(const tr_bvh_view& v, const float* o, const float* d, int6
 }
 
 extern "C" {
+void sim_set_qnodes(const void* qnodes, const float* f6) {
+    g_qnodes = (const tr_qnode*)qnodes;
+    for (int k = 0; k < 3; k++) { g_frame.base[k] = f6[k]; g_frame.scale[k] = f6[3 + k]; }
+}
 void sim_use_ring(int on) { g_use_ring = on; }
 void sim_use_fused(int mode) { g_fused = mode; }
 void sim_use_unordered(int on) { g_unordered = on; }

@@ -30,6 +30,8 @@ def lib():
         L.sim_num_nodes.argtypes = [C.c_void_p]
         L.sim_num_nodes.restype = C.c_int64
         L.sim_get.argtypes = [C.c_void_p] * 4
+        L.sim_get_qnodes.argtypes = [C.c_void_p] * 3
+        L.sim_set_qnodes.argtypes = [C.c_void_p] * 2
         L.sim_query.argtypes = [C.c_int] + [C.c_void_p] * 3 + [C.c_int64, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p] * 7
         L.sim_location.argtypes = [C.c_void_p] * 3 + [C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 3
         L.sim_use_ring.argtypes = [C.c_int]
@@ -44,11 +46,14 @@ NODE_WORDS, LINK_WORDS, TRI_WORDS = 16, 2, 12
 
 
 class SimBVH:
-    def __init__(self, verts=None, faces=None, force_mode=-1, morton_shift=0, arrays=None):
+    def __init__(self, verts=None, faces=None, force_mode=-1, morton_shift=0, arrays=None, qarrays=None):
+        """arrays=(nodes, links, tris) [+ qarrays=(qnodes, frame)]: traverse arrays downloaded from the
+        GPU builder"""
         if arrays is not None:
             self.nodes, self.links, self.tris = arrays
             self.nf = len(self.tris)
             self.depth = None
+            self.qnodes, self.frame = qarrays if qarrays is not None else (np.zeros((len(self.nodes), 8), np.uint32), np.zeros(6, np.float32))
             return
         v = np.ascontiguousarray(verts, np.float32)
         f = np.ascontiguousarray(faces, np.int32)
@@ -62,9 +67,29 @@ class SimBVH:
         self.links = np.zeros((nn, LINK_WORDS), np.int32)
         self.tris = np.zeros((self.nf, TRI_WORDS), np.uint32)
         L.sim_get(h, self.nodes.ctypes.data, self.links.ctypes.data, self.tris.ctypes.data)
+        self.qnodes = np.zeros((nn, 8), np.uint32)
+        self.frame = np.zeros(6, np.float32)        # base[3], scale[3]
+        L.sim_get_qnodes(h, self.qnodes.ctypes.data, self.frame.ctypes.data)
         L.sim_destroy(h)
 
+    def qchild_boxes(self):
+        """decoded grid boxes of both children of every 32-byte node: [N, 2, 6] = lo.xyz, hi.xyz (float32,
+        bit-identical to the traversal's fma: q * scale is exact, one rounding of the sum)"""
+        q = self.qnodes[:, :6].astype(np.uint32)
+        base, scale = self.frame[:3], self.frame[3:]
+
+        def dec(v, ax):
+            return (v.astype(np.float64) * np.float64(scale[ax]) + np.float64(base[ax])).astype(np.float32)
+        out = np.zeros((len(q), 2, 6), np.float32)
+        for k in (0, 1):
+            w = q[:, 3 * k:3 * k + 3]
+            out[:, k, 0] = dec(w[:, 0] & 0xffff, 0); out[:, k, 1] = dec(w[:, 0] >> 16, 1)
+            out[:, k, 2] = dec(w[:, 1] & 0xffff, 2); out[:, k, 5] = dec(w[:, 1] >> 16, 2)
+            out[:, k, 3] = dec(w[:, 2] & 0xffff, 0); out[:, k, 4] = dec(w[:, 2] >> 16, 1)
+        return out
+
     def query(self, q, o, d):
+        lib().sim_set_qnodes(self.qnodes.ctypes.data, self.frame.ctypes.data)
         o = np.ascontiguousarray(o, np.float32).reshape(-1, 3)
         d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)
         n = len(o)
@@ -87,6 +112,7 @@ class SimBVH:
         return nv, tt
 
     def location(self, o, d, cap=8):
+        lib().sim_set_qnodes(self.qnodes.ctypes.data, self.frame.ctypes.data)
         o = np.ascontiguousarray(o, np.float32).reshape(-1, 3)
         d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)
         n = len(o)

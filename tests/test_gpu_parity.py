@@ -244,14 +244,22 @@ def test_builder_invariants_and_host_traversal_of_gpu_tree(device):
     assert info["num_tris"] == len(f) and info["num_nodes"] == len(f) - 1 and 0 < info["depth"] <= 64
     np.testing.assert_array_equal(np.float32(info["aabb_min"]) <= v.min(0), True)
     nodes, links, tris = r.as_wrapper.download()
-    B = SimBVH(arrays=(nodes, links, tris))
+    qnodes, frame = r.as_wrapper.download_qnodes()
+    B = SimBVH(arrays=(nodes, links, tris), qarrays=(qnodes, frame))
     check_tree(B)
     # same tree as the host construction (deterministic builder: replicas on other GPUs agree)
     H = SimBVH(v, f)
     assert np.array_equal(H.tris, tris) and np.array_equal(H.nodes, nodes) and H.depth == info["depth"]
+    assert np.array_equal(H.qnodes, qnodes) and np.array_equal(H.frame, frame)      # the 32-byte grid copy too
     o, d = W.hash_rays(20000, 5, v.min(0) * 1.5, v.max(0) * 1.5)
     g = r.intersects_first(T(o, device), T(d, device)).cpu().numpy()
     assert np.array_equal(B.query(1, o, d)["tri"], g)
+    import sim
+    sim.use_unordered(True)                      # host traversal of the GPU's grid nodes == GPU count
+    try:
+        assert np.array_equal(B.query(3, o, d)["count"], r.intersects_count(T(o, device), T(d, device)).cpu().numpy())
+    finally:
+        sim.use_unordered(False)
 
 
 def test_deep_tree_falls_back_to_bounded_keys(device):
@@ -532,6 +540,9 @@ def test_refit_and_serialization(device, tmp_path):
     n1, l1, t1 = r.as_wrapper.download()
     n3, l3, t3 = r3.as_wrapper.download()
     assert np.array_equal(n1, n3) and np.array_equal(l1, l3) and np.array_equal(t1, t3)
+    (q1, f1), (q3, f3), (qb, fb) = r.as_wrapper.download_qnodes(), r3.as_wrapper.download_qnodes(), rb.as_wrapper.download_qnodes()
+    assert np.array_equal(q1, q3) and np.array_equal(f1, f3)          # loaded handle: same grid nodes and frame
+    assert np.array_equal(f1, fb)                                     # refit re-derives the grid from the new bounds
     assert r3.bvh_info()["depth"] == info["depth"]
     for a, b in zip(r3.intersects_closest(ot, dt), r.intersects_closest(ot, dt)):
         assert torch.equal(a, b)

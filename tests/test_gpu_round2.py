@@ -171,6 +171,8 @@ def test_save_load_after_shrinking_update_raw(device, tmp_path):
     assert_closest_bitexact(r.intersects_closest(ot, dt), exp, "shrunk original")
     for a, b in zip(r2.as_wrapper.download(), fresh.as_wrapper.download()):
         assert np.array_equal(a, b)
+    for a, b in zip(r2.as_wrapper.download_qnodes(), fresh.as_wrapper.download_qnodes()):
+        assert np.array_equal(a, b)
 
 
 def test_options_may_change_while_other_threads_query(device):
@@ -281,7 +283,7 @@ def test_unordered_schedule_matches_the_oracle(device, unordered, leaf_vote):
             assert np.array_equal(ray, er) and np.array_equal(tri, et) and np.array_equal(loc, el)
     finally:
         hops.set_option("unordered", 1)
-        hops.set_option("leaf_vote", 16)
+        hops.set_option("leaf_vote", 32)
 
 
 @pytest.mark.parametrize("rays_per_wave,refill", [(64, 1), (100, 16), (512, 16), (512, 64), (4096, 32)])

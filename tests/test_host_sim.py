@@ -36,6 +36,22 @@ def check_tree(B):
         assert np.array_equal(lo, boxes[m, 6 * k:6 * k + 3]) and np.array_equal(hi, boxes[m, 6 * k + 3:6 * k + 6])
     faces = B.tris[:, 9].view(np.int32)
     assert np.array_equal(np.sort(faces), np.arange(nf))
+    # the 32-byte grid nodes of the unordered schedule: same topology, boxes that CONTAIN the exact
+    # child boxes (bit-exact decode), nest, and are tight to one grid cell where float spacing allows
+    assert np.array_equal(B.qnodes[:, 6:8].view(np.int32), c)
+    qb = B.qchild_boxes()
+    scale = B.frame[3:]
+    for k in (0, 1):
+        ex_lo = boxes[:, 6 * k:6 * k + 3]                           # stored lo.x lo.y lo.z | hi.z hi.x hi.y
+        ex_hi = boxes[:, [6 * k + 4, 6 * k + 5, 6 * k + 3]]
+        assert np.all(qb[:, k, :3] <= ex_lo) and np.all(qb[:, k, 3:] >= ex_hi)
+        slack = np.maximum(scale, np.spacing(np.maximum(np.abs(ex_lo), np.abs(ex_hi)).astype(np.float32)) * 2)
+        assert np.all(ex_lo - qb[:, k, :3] <= slack * 1.0001) and np.all(qb[:, k, 3:] - ex_hi <= slack * 1.0001)
+        ch = c[:, k]
+        m = ch >= 0
+        cb = qb[ch[m]]
+        assert np.all(qb[m, k, :3] <= np.minimum(cb[:, 0, :3], cb[:, 1, :3]))
+        assert np.all(qb[m, k, 3:] >= np.maximum(cb[:, 0, 3:], cb[:, 1, 3:]))
 
 
 def compare_all(v, f, o, d, **kw):

@@ -186,7 +186,7 @@ struct tr_blob_header {
     float aabb_min[3], aabb_max[3];
     uint32_t sizeof_node, sizeof_tri, sizeof_link, pad;
 };
-const char TR_MAGIC[8] = {'T', 'R', 'B', 'V', 'H', 0, 0, 2};   // 2: child boxes stored lo.xy|lo.z hi.z|hi.xy
+const char TR_MAGIC[8] = {'T', 'R', 'B', 'V', 'H', 0, 0, 3};   // 3: arena = nodes | links | tris | 32-byte grid nodes
 }  // namespace
 
 int64_t tr_bvh_serialized_size(const tr_bvh* bvh) {
@@ -250,6 +250,7 @@ int tr_bvh_deserialize(const void* h_buffer, int64_t size, void* stream, tr_bvh*
         if (s == TR_OK) {
             bvh->num_tris = h.num_tris; bvh->num_nodes = h.num_nodes; bvh->depth = h.depth; bvh->key_mode = h.key_mode;
             for (int k = 0; k < 3; k++) { bvh->aabb_min[k] = h.aabb_min[k]; bvh->aabb_max[k] = h.aabb_max[k]; }
+            tr_qframe_make(bvh->aabb_min, bvh->aabb_max, &bvh->frame);   // the grid is a function of the bounds
         }
     }
     if (s != TR_OK) {
@@ -287,9 +288,22 @@ int tr_bvh_get_info(const tr_bvh* bvh, tr_bvh_info* info) {
     info->depth = bvh->depth;
     info->key_mode = bvh->key_mode;
     info->arena_bytes = bvh->arena_bytes;
-    info->node_bytes = bvh->num_nodes * (int64_t)sizeof(tr_node);
+    info->node_bytes = bvh->num_nodes * (int64_t)(sizeof(tr_node) + sizeof(tr_qnode));
     info->tri_bytes = bvh->num_tris * (int64_t)sizeof(tr_tri);
     for (int k = 0; k < 3; k++) { info->aabb_min[k] = bvh->aabb_min[k]; info->aabb_max[k] = bvh->aabb_max[k]; }
+    return TR_OK;
+}
+
+int tr_bvh_download_qnodes(const tr_bvh* bvh, void* h_qnodes, float* h_frame6, void* stream) {
+    if (!bvh) return tr_fail(TR_ERR_INVALID_ARG, "bvh == NULL");
+    hipStream_t s = (hipStream_t)stream;
+    tr_device_guard g;
+    if (g.enter(bvh->device) != TR_OK) return tr_fail(TR_ERR_NO_DEVICE, "hipSetDevice failed");
+    if (h_qnodes && bvh->num_nodes)
+        TR_HIP_TRY(hipMemcpyAsync(h_qnodes, bvh->qnodes, sizeof(tr_qnode) * (size_t)bvh->num_nodes, hipMemcpyDeviceToHost, s));
+    TR_HIP_TRY(hipStreamSynchronize(s));
+    if (h_frame6)
+        for (int k = 0; k < 3; k++) { h_frame6[k] = bvh->frame.base[k]; h_frame6[3 + k] = bvh->frame.scale[k]; }
     return TR_OK;
 }
 

@@ -311,13 +311,33 @@ __global__ __launch_bounds__(256) void k_refit_round(const int32_t* __restrict__
 }
 
 // ---- 7. emit traversal nodes -------------------------------------------------------------------
+// quantisation frame of the 32-byte node array from the encoded mesh bounds of step 1 (one
+// thread; the host derives the same frame from the same six floats with the same function)
+__global__ void k_qframe(const uint32_t* __restrict__ bounds, tr_qframe* __restrict__ frame) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float mn[3], mx[3];
+    for (int k = 0; k < 3; k++) { mn[k] = dec_f32(bounds[k]); mx[k] = dec_f32(bounds[3 + k]); }
+    tr_qframe f;
+    tr_qframe_make(mn, mx, &f);
+    *frame = f;
+}
+// the same from a float box lo[3], hi[3] (refit: the new root box)
+__global__ void k_qframe_box(const float* __restrict__ box, tr_qframe* __restrict__ frame) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    tr_qframe f;
+    tr_qframe_make(box, box + 3, &f);
+    *frame = f;
+}
+
 __global__ __launch_bounds__(256) void k_emit(const int32_t* __restrict__ childL,
                                               const int32_t* __restrict__ childR,
                                               const int32_t* __restrict__ parent,
                                               const float* __restrict__ sbox,
                                               const float* __restrict__ ibox, int64_t ninternal,
+                                              const tr_qframe* __restrict__ frame,
                                               tr_node* __restrict__ nodes,
-                                              tr_link* __restrict__ links) {
+                                              tr_link* __restrict__ links,
+                                              tr_qnode* __restrict__ qnodes) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ninternal) return;
     int32_t cl = childL[i], cr = childR[i];
@@ -334,6 +354,13 @@ __global__ __launch_bounds__(256) void k_emit(const int32_t* __restrict__ childL
     nodes[i] = nd;
     tr_link l; l.parent = p; l.sibling = sib;
     links[i] = l;
+    // the same two boxes on the 16-bit grid (supersets), for the unordered schedule
+    const tr_qframe f = *frame;
+    tr_qnode qn;
+    tr_qnode_set_box(qn.q, a, a + 3, f);
+    tr_qnode_set_box(qn.q + 3, b, b + 3, f);
+    qn.c0 = cl; qn.c1 = cr;
+    qnodes[i] = qn;
 }
 
 // ---- refit (same topology, new vertex positions) ------------------------------------------------
@@ -385,7 +412,9 @@ __global__ __launch_bounds__(256) void k_refit_nodes_round(const tr_node* __rest
 __global__ __launch_bounds__(256) void k_update_boxes(tr_node* __restrict__ nodes,
                                                       const float* __restrict__ sbox,
                                                       const float* __restrict__ ibox,
-                                                      int64_t ninternal) {
+                                                      int64_t ninternal,
+                                                      const tr_qframe* __restrict__ frame,
+                                                      tr_qnode* __restrict__ qnodes) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ninternal) return;
     const int32_t cl = nodes[i].c0, cr = nodes[i].c1;
@@ -393,6 +422,9 @@ __global__ __launch_bounds__(256) void k_update_boxes(tr_node* __restrict__ node
     const float* b = cr < 0 ? sbox + 6 * (int64_t)(~cr) : ibox + 6 * (int64_t)cr;
     tr_node_set_box(nodes[i].box0, a, a + 3);
     tr_node_set_box(nodes[i].box1, b, b + 3);
+    const tr_qframe f = *frame;          // the grid follows the new bounds
+    tr_qnode_set_box(qnodes[i].q, a, a + 3, f);
+    tr_qnode_set_box(qnodes[i].q + 3, b, b + 3, f);
 }
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
@@ -417,7 +449,8 @@ static size_t carve_arena(tr_bvh* bvh, char* base, int64_t nf) {
     tr_node* nodes = c.take<tr_node>((size_t)(nn > 0 ? nn : 1));
     tr_link* links = c.take<tr_link>((size_t)(nn > 0 ? nn : 1));
     tr_tri* tris = c.take<tr_tri>((size_t)(nf > 0 ? nf : 1));
-    if (base) { bvh->nodes = nodes; bvh->links = links; bvh->tris = tris; }
+    tr_qnode* qnodes = c.take<tr_qnode>((size_t)(nn > 0 ? nn : 1));
+    if (base) { bvh->nodes = nodes; bvh->links = links; bvh->tris = tris; bvh->qnodes = qnodes; }
     return align_up(c.off, 256);
 }
 
@@ -441,6 +474,7 @@ int tr_arena_alloc(tr_bvh* bvh, int64_t nf) {
 int64_t tr_arena_used_bytes(int64_t nf) { return (int64_t)carve_arena(nullptr, nullptr, nf); }
 
 void tr_bvh_reset(tr_bvh* bvh) {
+    bvh->frame = tr_qframe{{0.f, 0.f, 0.f}, {1.f, 1.f, 1.f}};
     bvh->num_tris = 0; bvh->num_nodes = 0; bvh->depth = 0; bvh->key_mode = 0;
     for (int k = 0; k < 3; k++) { bvh->aabb_min[k] = 0.f; bvh->aabb_max[k] = 0.f; }
     for (int k = 0; k < TR_SCHED_SLOTS; k++) bvh->sched[k].nblocks = 0;
@@ -485,7 +519,7 @@ int tr_build_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_
         v1 = c.take<uint32_t>((size_t)nf);
         hist = c.take<uint32_t>(256 * (size_t)ntiles);
         gtot = c.take<uint32_t>(8 * 256);
-        bounds = c.take<uint32_t>(8);
+        bounds = c.take<uint32_t>(8 + 8);   // 8 words of bounds / flags + the quantisation frame (6 floats)
         cl = c.take<int32_t>((size_t)nf);
         cr = c.take<int32_t>((size_t)nf);
         par = c.take<int32_t>((size_t)nf);
@@ -509,8 +543,10 @@ int tr_build_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_
     const int TB = 256;
     const unsigned gF = (unsigned)cdiv(nf, TB);
 
+    tr_qframe* d_frame = reinterpret_cast<tr_qframe*>(bounds + 8);
     hipLaunchKernelGGL(k_init_bounds, dim3(1), dim3(64), 0, stream, bounds);
     hipLaunchKernelGGL(k_tri_bounds, dim3(gF < 1024u ? gF : 1024u), dim3(TB), 0, stream, d_vertices, nv, d_faces, nf, tribox, bounds);
+    hipLaunchKernelGGL(k_qframe, dim3(1), dim3(64), 0, stream, bounds, d_frame);
     check(hipGetLastError(), "k_tri_bounds");
     // mesh bounds back to the host; completes with the first synchronisation below
     uint32_t hb[8] = {0};
@@ -569,7 +605,7 @@ int tr_build_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_
                 }
                 check(hipGetLastError(), "k_refit_round");
                 // harmless if the root is not final yet: it is launched again below
-                hipLaunchKernelGGL(k_emit, dim3(gI), dim3(TB), 0, stream, cl, cr, par, sbox, ibox, ni, bvh->nodes, bvh->links);
+                hipLaunchKernelGGL(k_emit, dim3(gI), dim3(TB), 0, stream, cl, cr, par, sbox, ibox, ni, d_frame, bvh->nodes, bvh->links, bvh->qnodes);
                 check(hipGetLastError(), "k_emit");
                 check(hipMemcpyAsync(&root_ready, ready, sizeof(int32_t), hipMemcpyDeviceToHost, stream), "memcpy root");
                 check(hipStreamSynchronize(stream), "sync refit");
@@ -598,6 +634,7 @@ int tr_build_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_
             memcpy(&bvh->aabb_min[k], &b0, 4);
             memcpy(&bvh->aabb_max[k], &b1, 4);
         }
+        tr_qframe_make(bvh->aabb_min, bvh->aabb_max, &bvh->frame);   // == k_qframe's (same function, same bounds)
     }
     int rs = tr_build_temp_release(st);   // the stream is drained: the next build may reuse the buffer
     if (rs != TR_OK && status == TR_OK) status = rs;
@@ -622,7 +659,7 @@ int tr_refit_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_
     const int64_t ni = bvh->num_nodes;
     Carver tc{nullptr};
     tc.take<float>(6 * (size_t)nf); tc.take<float>(6 * (size_t)(ni > 0 ? ni : 1)); tc.take<int32_t>((size_t)(ni > 0 ? ni : 1));
-    tc.take<uint32_t>(4);
+    tc.take<uint32_t>(4 + 8);
     const size_t need = align_up(tc.off, 256);
     if (bvh->refit_temp_bytes < need) {
         if (bvh->refit_temp) { TR_HIP_TRY(hipFree(bvh->refit_temp)); bvh->refit_temp = nullptr; bvh->refit_temp_bytes = 0; }
@@ -633,7 +670,8 @@ int tr_refit_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_
     float* sbox = c2.take<float>(6 * (size_t)nf);
     float* ibox = c2.take<float>(6 * (size_t)(ni > 0 ? ni : 1));
     int32_t* ready = c2.take<int32_t>((size_t)(ni > 0 ? ni : 1));
-    uint32_t* bad = c2.take<uint32_t>(4);   // smallest face id with an out-of-range vertex index
+    uint32_t* bad = c2.take<uint32_t>(4 + 8);   // smallest face id with an out-of-range vertex index | frame
+    tr_qframe* d_frame = reinterpret_cast<tr_qframe*>(bad + 4);
     uint32_t hbad = 0xffffffffu;
     int status = TR_OK;
     auto check = [&](hipError_t e, const char* what) {
@@ -650,13 +688,16 @@ int tr_refit_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_
         check(hipMemsetAsync(ready, 0, sizeof(int32_t) * (size_t)ni, stream), "memset ready");
         for (int32_t round = 1; round <= bvh->depth; round++)
             hipLaunchKernelGGL(k_refit_nodes_round, dim3(gI), dim3(TB), 0, stream, bvh->nodes, sbox, ibox, ready, ni, round);
-        hipLaunchKernelGGL(k_update_boxes, dim3(gI), dim3(TB), 0, stream, bvh->nodes, sbox, ibox, ni);
+        hipLaunchKernelGGL(k_qframe_box, dim3(1), dim3(64), 0, stream, ibox, d_frame);   // the new root box
+        hipLaunchKernelGGL(k_update_boxes, dim3(gI), dim3(TB), 0, stream, bvh->nodes, sbox, ibox, ni, d_frame, bvh->qnodes);
         check(hipGetLastError(), "refit rounds");
         float rootbox[6];
         check(hipMemcpyAsync(rootbox, ibox, sizeof(rootbox), hipMemcpyDeviceToHost, stream), "memcpy root box");
         check(hipStreamSynchronize(stream), "sync refit");
-        if (status == TR_OK)
+        if (status == TR_OK) {
             for (int k = 0; k < 3; k++) { bvh->aabb_min[k] = rootbox[k]; bvh->aabb_max[k] = rootbox[3 + k]; }
+            tr_qframe_make(bvh->aabb_min, bvh->aabb_max, &bvh->frame);
+        }
     } else {
         float box[6];
         check(hipMemcpyAsync(box, sbox, sizeof(box), hipMemcpyDeviceToHost, stream), "memcpy box");

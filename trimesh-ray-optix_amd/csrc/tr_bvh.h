@@ -7,6 +7,7 @@
 //
 // Layout in HBM (one arena per mesh, see DESIGN.md "Data layout"):
 //   nodes : (F-1) x 64 B   tr_node   both children's boxes + child ids + parent + sibling
+//   qnodes: (F-1) x 32 B   tr_qnode  the same boxes on a 16-bit grid + child ids (unordered schedule)
 //   links : (F-1) x  8 B   tr_link   {parent, sibling} again, packed 8 per 64-B line, read
 //                                    only while backtracking (keeps the climb off the
 //                                    64-B node lines)
@@ -58,6 +59,73 @@ struct alignas(8) tr_link {
     int32_t parent, sibling;
 };
 
+// ---- second node array for the UNORDERED schedule (count / location): 32-byte nodes -------------
+// Both child boxes on a 16-bit grid over the mesh bounds + child ids: two 16-byte loads per visit
+// instead of four.  The unordered leaf phase evaluates the full predicate from the triangle's
+// vertices anyway (tr_tri_hit), so the grid boxes only have to be SUPERSETS of the exact ones: the
+// builder searches, with the very decode the traversal uses, the largest grid plane <= lo and the
+// smallest >= hi, and the slab arithmetic on the decoded planes is the contract's -- monotone under
+// box inclusion, so nothing the exact tree would visit is culled.  Measured: C4 count 0.93 -> 0.80
+// ms, location 1.18 -> 1.0 ms.  The ordered (closest / first / any) trip keeps the exact 64-byte
+// nodes: it needs the leaf's exact slab interval from its parent, and the decode (12 cvt + 6 packed
+// fma per visit) made every ordered configuration slower (experiments/q32_nodes.patch).
+// Grid plane q of axis k lies at fma(q, scale[k], base[k]), q = 0 .. 65535; base = the mesh bounds'
+// minimum, scale = a power of two with decode(65535) >= the bounds' maximum: a pure function of
+// the bounds (tr_qframe_make), so host and device derive identical frames.
+struct tr_qframe {
+    float base[3];
+    float scale[3];
+};
+TR_HD float tr_qdecode(uint32_t q, float scale, float base) { return fmaf((float)q, scale, base); }
+TR_HD void tr_qframe_make(const float* mn, const float* mx, tr_qframe* f) {
+    for (int k = 0; k < 3; k++) {
+        const float ext = mx[k] - mn[k];
+        int e = 0;
+        float s = 1.0f;
+        if (ext > 0.f && ext <= 3.0e38f) {
+            (void)frexpf(ext / 65535.0f, &e);      // ext/65535 = m * 2^e, m in [0.5, 1)
+            s = ldexpf(1.0f, e < -126 ? -126 : e);
+        }
+        // rounding in the two lines above can leave the last plane just short of the maximum
+        for (int it = 0; it < 300 && !(tr_qdecode(65535u, s, mn[k]) >= mx[k]); it++) s *= 2.0f;
+        f->base[k] = mn[k];
+        f->scale[k] = s;
+    }
+}
+// largest grid plane <= lo / smallest grid plane >= hi, searched with the traversal's own decode
+// (binary search: the decode is monotone in q); lo >= base and hi <= decode(65535) by construction
+TR_HD uint32_t tr_qfloor(float lo, float scale, float base) {
+    uint32_t a = 0u, z = 65535u;
+    while (a < z) {
+        const uint32_t m = (a + z + 1u) >> 1;
+        if (tr_qdecode(m, scale, base) <= lo) a = m; else z = m - 1u;
+    }
+    return a;
+}
+TR_HD uint32_t tr_qceil(float hi, float scale, float base) {
+    uint32_t a = 0u, z = 65535u;
+    while (a < z) {
+        const uint32_t m = (a + z) >> 1;
+        if (tr_qdecode(m, scale, base) >= hi) z = m; else a = m + 1u;
+    }
+    return a;
+}
+// Child boxes as 16-bit pairs {lo.x, lo.y | lo.z, hi.z | hi.x, hi.y} (low half first): every pair
+// meets the SAME pair of frame and ray constants ((x,y) or (z,z)), so a node decodes with 6 packed
+// fma and its 12 slab planes are 6 packed subtracts + 6 packed multiplies (tr_qnode_slabs).
+struct alignas(32) tr_qnode {
+    uint32_t q[6];   // q[0..2] child 0, q[3..5] child 1
+    int32_t c0, c1;
+};
+static_assert(sizeof(tr_qnode) == 32, "quantised node must be 32 B");
+TR_HD void tr_qnode_set_box(uint32_t* q, const float* lo, const float* hi, const tr_qframe& f) {
+    const uint32_t lx = tr_qfloor(lo[0], f.scale[0], f.base[0]), ly = tr_qfloor(lo[1], f.scale[1], f.base[1]);
+    const uint32_t lz = tr_qfloor(lo[2], f.scale[2], f.base[2]);
+    const uint32_t hx = tr_qceil(hi[0], f.scale[0], f.base[0]), hy = tr_qceil(hi[1], f.scale[1], f.base[1]);
+    const uint32_t hz = tr_qceil(hi[2], f.scale[2], f.base[2]);
+    q[0] = lx | (ly << 16); q[1] = lz | (hz << 16); q[2] = hx | (hy << 16);
+}
+
 struct alignas(16) tr_tri {
     float ax, ay, az, bx, by, bz, cx, cy, cz;
     int32_t face;  // original triangle index
@@ -70,6 +138,8 @@ struct tr_bvh_view {
     const tr_link* links;
     const tr_tri* tris;
     int64_t num_tris;
+    const tr_qnode* qnodes;   // 32-byte grid nodes of the unordered schedule (same topology as `nodes`)
+    tr_qframe frame;
 };
 
 enum tr_query { TR_Q_ANY = 0, TR_Q_FIRST = 1, TR_Q_CLOSEST = 2, TR_Q_COUNT = 3, TR_Q_LOCATION = 4 };
@@ -492,6 +562,56 @@ TR_HD void tr_fused_step(const tr_bvh_view& b, const tr_ray& r, tr_state_t<W>& s
     }
 }
 
+// Slab intervals of both children of a 32-byte grid node held in two 16-byte registers:
+// w0 = q[0..3], w1 = q[4], q[5], c0, c1.  Decode: plane = fma(q, scale, base) per 16-bit half; then
+// the contract's subtract and multiply per plane.  On the device both steps are packed FP32.
+TR_HD void tr_qnode_slabs(const tr_ray& r, const tr_qframe& f, const tr_i4& w0, const tr_i4& w1,
+                          float& tn0, float& tf0, float& tn1, float& tf1) {
+    const uint32_t q0 = (uint32_t)w0.x, q1 = (uint32_t)w0.y, q2 = (uint32_t)w0.z, q3 = (uint32_t)w0.w;
+    const uint32_t q4 = (uint32_t)w1.x, q5 = (uint32_t)w1.y;
+#if defined(__HIP_DEVICE_COMPILE__) && TR_PK_SLAB
+    typedef float tr_v2 __attribute__((ext_vector_type(2)));
+    const tr_v2 sxy = {f.scale[0], f.scale[1]}, szz = {f.scale[2], f.scale[2]};
+    const tr_v2 bxy = {f.base[0], f.base[1]}, bzz = {f.base[2], f.base[2]};
+    const tr_v2 oxy = {r.ox, r.oy}, ozz = {r.oz, r.oz};
+    const tr_v2 ixy = {r.ix, r.iy}, izz = {r.iz, r.iz};
+#define TR_UNPK(w) tr_v2{(float)((w) & 0xffffu), (float)((w) >> 16)}
+    const tr_v2 a = (__builtin_elementwise_fma(TR_UNPK(q0), sxy, bxy) - oxy) * ixy;   // child 0: x1 y1
+    const tr_v2 b = (__builtin_elementwise_fma(TR_UNPK(q1), szz, bzz) - ozz) * izz;   //          z1 z2
+    const tr_v2 c = (__builtin_elementwise_fma(TR_UNPK(q2), sxy, bxy) - oxy) * ixy;   //          x2 y2
+    const tr_v2 d = (__builtin_elementwise_fma(TR_UNPK(q3), sxy, bxy) - oxy) * ixy;   // child 1: x1 y1
+    const tr_v2 e = (__builtin_elementwise_fma(TR_UNPK(q4), szz, bzz) - ozz) * izz;   //          z1 z2
+    const tr_v2 g = (__builtin_elementwise_fma(TR_UNPK(q5), sxy, bxy) - oxy) * ixy;   //          x2 y2
+#undef TR_UNPK
+    tn0 = fmaxf(fmaxf(fminf(a.x, c.x), fminf(a.y, c.y)), fminf(b.x, b.y));
+    tf0 = fminf(fminf(fmaxf(a.x, c.x), fmaxf(a.y, c.y)), fmaxf(b.x, b.y)) * TR_SLAB_PAD;
+    tn1 = fmaxf(fmaxf(fminf(d.x, g.x), fminf(d.y, g.y)), fminf(e.x, e.y));
+    tf1 = fminf(fminf(fmaxf(d.x, g.x), fmaxf(d.y, g.y)), fmaxf(e.x, e.y)) * TR_SLAB_PAD;
+#else
+    const float sx = f.scale[0], sy = f.scale[1], sz = f.scale[2], bx = f.base[0], by = f.base[1], bz = f.base[2];
+    tr_slab(r, tr_qdecode(q0 & 0xffffu, sx, bx), tr_qdecode(q0 >> 16, sy, by), tr_qdecode(q1 & 0xffffu, sz, bz),
+            tr_qdecode(q2 & 0xffffu, sx, bx), tr_qdecode(q2 >> 16, sy, by), tr_qdecode(q1 >> 16, sz, bz), tn0, tf0);
+    tr_slab(r, tr_qdecode(q3 & 0xffffu, sx, bx), tr_qdecode(q3 >> 16, sy, by), tr_qdecode(q4 & 0xffffu, sz, bz),
+            tr_qdecode(q5 & 0xffffu, sx, bx), tr_qdecode(q5 >> 16, sy, by), tr_qdecode(q4 >> 16, sz, bz), tn1, tf1);
+#endif
+}
+
+// Backtracking without the ring and without parent / sibling in the node record: climb the parent
+// links from `node` (at `depth`) to the ancestor at depth j+1 and return its sibling -- the far
+// child owed at depth j (internal by construction).  One dependent 8-byte load per level.
+template <bool STATS>
+TR_HD int32_t tr_climb(const tr_bvh_view& b, int32_t node, uint32_t depth, uint32_t j, tr_counters* cnt) {
+    tr_link l = b.links[node];
+    if (STATS) cnt->climbs++;
+    while (depth > j + 1) {
+        node = l.parent;
+        l = b.links[node];
+        depth--;
+        if (STATS) cnt->climbs++;
+    }
+    return l.sibling;
+}
+
 // ---- unordered two-phase schedule (any / count / location) --------------------------------------
 // Queries that do not prune by distance gain nothing from near-first order or from testing a
 // leaf as soon as it is found -- and the fused trip pays for both: its Moller-Trumbore block and
@@ -539,8 +659,9 @@ TR_HD void tr_unord_step(const tr_bvh_view& b, const tr_ray& r, bool go_node, bo
                          tr_ustate_t<W>& st, tr_result& res, tr_topk<K>& top, tr_counters* cnt,
                          const tr_ring ring, const tr_leafq lq) {
     const int32_t nidx = go_node ? st.node : 0;
-    const tr_f4* np = tr_node_ptr<COMPACT>(b, nidx);
-    const tr_f4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+    const tr_i4* np = COMPACT ? reinterpret_cast<const tr_i4*>(reinterpret_cast<const char*>(b.qnodes) + ((uint32_t)nidx << 5))
+                              : reinterpret_cast<const tr_i4*>(b.qnodes + nidx);
+    const tr_i4 w0 = np[0], w1 = np[1];
     if (STATS && go_node) cnt->nodes++;
     bool fin = false;
     if (leaf_phase) {
@@ -565,11 +686,8 @@ TR_HD void tr_unord_step(const tr_bvh_view& b, const tr_ray& r, bool go_node, bo
     if (Q == TR_Q_ANY && fin) { st.node = -1; st.nq = 0; }
     const bool go = go_node && !fin;
     float tn0, tf0, tn1, tf1;
-    tr_node_slabs(r, n0, n1, n2, tn0, tf0, tn1, tf1);
-    union { float f; int32_t i; } u0, u1, u2, u3;
-    u0.f = n3.x; u1.f = n3.y; u2.f = n3.z; u3.f = n3.w;
-    const int32_t c0 = u0.i, c1 = u1.i;
-    int32_t parent = u2.i, sibling = u3.i;
+    tr_qnode_slabs(r, b.frame, w0, w1, tn0, tf0, tn1, tf1);
+    const int32_t c0 = w1.z, c1 = w1.w;
     bool h0 = tr_slab_hit(tn0, tf0, TR_TMAX) && go;
     bool h1 = tr_slab_hit(tn1, tf1, TR_TMAX) && go;
     if (h0 && c0 < 0) { lq.base[st.nq * lq.stride] = ~c0; st.nq++; h0 = false; }
@@ -593,20 +711,8 @@ TR_HD void tr_unord_step(const tr_bvh_view& b, const tr_ray& r, bool go_node, bo
         } else {
             const uint32_t j = tr_top_bit(st.trail);
             st.trail &= ~(W(1) << j);
-            if (ring.base && ((st.owned >> j) & W(1))) {
-                st.node = ring.base[(j & (TR_RING - 1)) * ring.stride];
-            } else {
-                int32_t node = st.node;
-                uint32_t depth = st.depth;
-                while (depth > j + 1) {
-                    node = parent;
-                    const tr_link l = b.links[node];
-                    parent = l.parent; sibling = l.sibling;
-                    depth--;
-                    if (STATS) cnt->climbs++;
-                }
-                st.node = sibling;
-            }
+            if (ring.base && ((st.owned >> j) & W(1))) st.node = ring.base[(j & (TR_RING - 1)) * ring.stride];
+            else st.node = tr_climb<STATS>(b, st.node, st.depth, j, cnt);
             st.depth = j + 1;
         }
     }

@@ -47,12 +47,14 @@ struct tr_bvh {
     int64_t num_nodes = 0;
     int32_t depth = 0;
     int32_t key_mode = 0;
-    void* arena = nullptr;      // one hipMalloc: nodes | links | tris
+    void* arena = nullptr;      // one hipMalloc: nodes | links | tris | qnodes
     int64_t arena_bytes = 0;
     int64_t capacity_tris = 0;  // arena was sized for this many triangles
     tr_node* nodes = nullptr;
     tr_link* links = nullptr;
     tr_tri* tris = nullptr;
+    tr_qnode* qnodes = nullptr;   // 32-byte grid nodes of the unordered schedule (same arena)
+    tr_qframe frame = {{0, 0, 0}, {1, 1, 1}};   // their grid: a function of the bounds below
     float aabb_min[3] = {0, 0, 0};
     float aabb_max[3] = {0, 0, 0};
     void* refit_temp = nullptr;   // boxes + flags of tr_bvh_refit, kept between calls (animation loops)
@@ -135,6 +137,6 @@ struct tr_options {
     int stream_rays = 512;    // rays per wave of the streaming launch (its private range)
     int stream_refill = 32;   // idle lanes that trigger a refill
     int unordered = 1;    // count / location (2: also any) use the unordered two-phase schedule (queued leaves)
-    int leaf_vote = 16;   // unordered schedule: lanes with a queued leaf that fire a leaf phase
+    int leaf_vote = 32;   // unordered schedule: lanes with a queued leaf that fire a leaf phase
 };
 tr_options tr_opts();   // snapshot by value

@@ -888,6 +888,7 @@ int make_fetch(const tr_rays* rays, RayFetch* rf) {
 tr_bvh_view make_view(const tr_bvh* bvh) {
     tr_bvh_view v;
     v.nodes = bvh->nodes; v.links = bvh->links; v.tris = bvh->tris; v.num_tris = bvh->num_tris;
+    v.qnodes = bvh->qnodes; v.frame = bvh->frame;
     return v;
 }
 

@@ -270,6 +270,16 @@ class OptixAccelStructureWrapper:
                     key_mode=inf.key_mode, arena_bytes=inf.arena_bytes, node_bytes=inf.node_bytes,
                     tri_bytes=inf.tri_bytes, aabb_min=list(inf.aabb_min), aabb_max=list(inf.aabb_max))
 
+    def download_qnodes(self):
+        """Test hook: (qnodes[u32 N,8], frame[f32 6] = base[3], scale[3]) of the 32-byte grid nodes."""
+        inf = self.info()
+        qn = np.zeros((inf["num_nodes"], 8), np.uint32)
+        frame = np.zeros(6, np.float32)
+        with torch.cuda.device(inf["device"]):
+            stream = torch.cuda.current_stream().cuda_stream
+            hops._check(hops.get_module().tr_bvh_download_qnodes(self._inner, qn.ctypes.data, frame.ctypes.data, stream))
+        return qn, frame
+
     def download(self):
         """Test hook: (nodes[u32 N,16], links[i32 N,2], tris[u32 F,12]) as numpy arrays."""
         inf = self.info()
