@@ -62,8 +62,8 @@ typedef struct tr_bvh_info {
     int64_t num_nodes;     /* internal nodes (F-1 for F >= 2, else 0)               */
     int32_t depth;         /* height of the hierarchy in internal-node levels       */
     int32_t key_mode;      /* 0: 63-bit Morton keys, 1: depth-bounded fallback keys */
-    int64_t arena_bytes;   /* bytes of device memory owned by the handle            */
-    int64_t node_bytes;    /* bytes of traversal nodes (64 B + 32 B grid copy each) */
+    int64_t arena_bytes;   /* device memory owned by the handle (nodes, links, tris, grid nodes) */
+    int64_t node_bytes;    /* bytes of the exact traversal nodes (64 B each)        */
     int64_t tri_bytes;     /* bytes of leaf triangle records (48 B each)            */
     float aabb_min[3];     /* mesh bounds                                            */
     float aabb_max[3];

@@ -288,7 +288,7 @@ int tr_bvh_get_info(const tr_bvh* bvh, tr_bvh_info* info) {
     info->depth = bvh->depth;
     info->key_mode = bvh->key_mode;
     info->arena_bytes = bvh->arena_bytes;
-    info->node_bytes = bvh->num_nodes * (int64_t)(sizeof(tr_node) + sizeof(tr_qnode));
+    info->node_bytes = bvh->num_nodes * (int64_t)sizeof(tr_node);   // the exact nodes; the 32-byte grid copy is in arena_bytes only
     info->tri_bytes = bvh->num_tris * (int64_t)sizeof(tr_tri);
     for (int k = 0; k < 3; k++) { info->aabb_min[k] = bvh->aabb_min[k]; info->aabb_max[k] = bvh->aabb_max[k]; }
     return TR_OK;
