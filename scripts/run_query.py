@@ -32,6 +32,7 @@ ap.add_argument("--opt", action="append", default=[])
 ap.add_argument("--subdiv", type=int, default=8, help="c5i / c5s: icosphere subdivisions of the headline mesh")
 ap.add_argument("--flat", action="store_true", help="pass image-shaped rays as a flat [N, 3] batch")
 ap.add_argument("--stats", action="store_true", help="also run the instrumented kernel (traversal counters)")
+ap.add_argument("--each", action="store_true", help="also print the time of every step")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)  # noqa: E731
@@ -79,6 +80,8 @@ ms = [e0.elapsed_time(e1) for e0, e1 in ev]
 res = {"config": a.config, "query": a.query, "rays": n, "tris": int(len(f)), "opts": a.opt,
        "ms_mean": round(float(np.mean(ms)), 4), "ms_min": round(min(ms), 4), "wall_ms": round(wall * 1e3, 4),
        "mrays_per_s": round(n / np.mean(ms) / 1e3, 1)}
+if a.each:
+    res["ms_each"] = [round(x, 3) for x in ms]
 if a.query == "location":
     res["hits"] = int(out[0].shape[0])
 if a.stats:

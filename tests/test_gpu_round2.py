@@ -91,6 +91,44 @@ def test_steal_merge_with_rays_starting_on_the_mesh(device, threshold, mesh):
         hops.set_option("steal", 1)
 
 
+@pytest.mark.parametrize("split,split_steal", [(1, 8), (2, 0), (3, 2), (4, 64)])
+def test_split_blocks_of_the_learned_order_match_the_oracle(device, split, split_steal):
+    """Block splitting (k_sched_sort): from the second launch of a batch on the most expensive blocks
+    run as two / four launch slots of half / quarter density whose idle lanes steal from the first
+    trips on.  Image-shaped (8x8 tiles) and flat batches, the stealing queries (closest, first, any;
+    count with stealing forced), several launches each (learn -> split -> re-measure), interleaved
+    with count / location launches of the same batch, which keep their own order."""
+    import triro.backend.ops as hops
+    v, f = W.icosphere(5)
+    v = W.displaced(v, seed=3, amplitude=0.05)
+    r = make(v, f, device)
+    R = OracleIntersector(v, f, 1)
+    o_img, d_img = W.pinhole_grid(384, 256, distance=2.5)            # 98 304 rays = 768 blocks
+    o_on, d_on = on_surface_rays(v, f, r, device, n_each=1500, seed=5)   # +-0.0 keys through split waves
+    cases = [("image", o_img, d_img), ("flat", o_img.reshape(-1, 3), d_img.reshape(-1, 3)), ("on-surface", o_on, d_on)]
+    try:
+        hops.set_option("split", split)
+        hops.set_option("split_steal", split_steal)
+        for name, o, d in cases:
+            exp = R.closest_raw(o.reshape(-1, 3), d.reshape(-1, 3))
+            cnt = R.intersects_count(o.reshape(-1, 3), d.reshape(-1, 3))
+            ot, dt = T(o, device), T(d, device)
+            for rep in range(6):
+                got = [g.reshape((-1,) + tuple(g.shape[o.ndim - 1:])) for g in r.intersects_closest(ot, dt)]
+                assert_closest_bitexact(got, exp, f"{name} split={split} launch {rep}")
+                assert np.array_equal(r.intersects_first(ot, dt).cpu().numpy().reshape(-1), exp[2])
+                assert np.array_equal(r.intersects_any(ot, dt).cpu().numpy().reshape(-1), cnt > 0)
+                assert np.array_equal(r.intersects_count(ot, dt).cpu().numpy().reshape(-1), cnt)
+            hops.set_option("steal", 16)        # count through the stealing shape, split as well
+            for rep in range(3):
+                assert np.array_equal(r.intersects_count(ot, dt).cpu().numpy().reshape(-1), cnt)
+                assert np.array_equal(r.intersects_first(ot, dt).cpu().numpy().reshape(-1), exp[2])
+            hops.set_option("steal", 1)
+    finally:
+        for k, val in (("split", 1), ("split_steal", 8), ("steal", 1)):
+            hops.set_option(k, val)
+
+
 def test_bad_face_indices_are_reported_not_dereferenced(device):
     """VERDICT r01 weak #8 / ADVICE: out-of-range vertex indices -> ValueError naming the first
     bad face (the reference hands the index buffer to optixAccelBuild unchecked, ray.cpp:44-58)."""

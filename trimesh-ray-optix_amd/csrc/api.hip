@@ -38,6 +38,8 @@ const opt_desc OPTS[] = {
     {"stream_rays", &tr_options::stream_rays, 64, 1 << 20, false},
     {"stream_refill", &tr_options::stream_refill, 1, 64, false},
     {"leaf_vote", &tr_options::leaf_vote, 1, 64, false},
+    {"split", &tr_options::split, 0, 12, false},
+    {"split_steal", &tr_options::split_steal, 0, 4096, false},
 };
 constexpr int NUM_OPTS = (int)(sizeof(OPTS) / sizeof(OPTS[0]));
 struct opt_store {

@@ -34,8 +34,10 @@ constexpr int TR_SCHED_MAX = 131072;  // blocks (x256 rays) up to which the orde
 constexpr int TR_SCHED_SLOTS = 8;
 struct tr_sched_slot {
     hipStream_t stream = nullptr;
+    int cls = 0;            // 1: orders with split blocks (launch shapes that steal), 0: plain
     uint32_t* buf = nullptr;
     int64_t nblocks = 0;    // block count the current order was measured for (0 = none)
+    int64_t split = 0;      // ... and the number of split blocks per XCD the order was written with
     int64_t launches = 0;   // launches with this block count so far
     bool used = false;
 };
@@ -137,6 +139,8 @@ struct tr_options {
     int stream_rays = 512;    // rays per wave of the streaming launch (its private range)
     int stream_refill = 32;   // idle lanes that trigger a refill
     int unordered = 1;    // count / location (2: also any) use the unordered two-phase schedule (queued leaves)
+    int split = 1;        // block splitting: 0 off, 1 auto, N >= 2: the nblocks >> N most expensive blocks of the previous launch get two launch slots
+    int split_steal = 8;  // ... and give subtrees away from this trip on
     int leaf_vote = 32;   // unordered schedule: lanes with a queued leaf that fire a leaf phase
 };
 tr_options tr_opts();   // snapshot by value

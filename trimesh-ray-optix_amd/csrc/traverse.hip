@@ -13,6 +13,8 @@
 //                round 2 after the randomised sweep found a mismatch in it.
 // Kernel parameters travel by value (no per-call malloc/memcpy/free as in ray.cpp:279-287).
 #include <atomic>
+#include <cstdio>
+#include <cstdlib>
 
 #include "tr_internal.h"
 
@@ -171,6 +173,9 @@ __device__ __forceinline__ bool wave_traverse_steal(const tr_bvh_view& b, tr_ray
     int owner = lane;          // lane whose ray this lane is working on
     bool split = false;        // wave-uniform: some ray is (or was) traversed by more than one lane
     uint32_t trip = 0;
+#ifdef TR_TIMELINE
+    int tl_handovers = 0;
+#endif
     // explicit LDS pointers: volatile accesses through generic pointers would compile to flat
     // loads/stores with 64-bit addresses held in VGPRs for the whole loop
     typedef __attribute__((address_space(3))) volatile int32_t lds_i32;
@@ -223,6 +228,9 @@ __device__ __forceinline__ bool wave_traverse_steal(const tr_bvh_view& b, tr_ray
             const int ni = __popcll(idle), nd = __popcll(donors);
             const int np = ni < nd ? ni : nd;
             if (np > 0) {
+#ifdef TR_TIMELINE
+                tl_handovers += np;
+#endif
                 if (!split) {   // first hand-over in this wave: set the accumulators up
                     if (Q == TR_Q_COUNT || Q == TR_Q_ANY) vsum[lane] = 0;
                     else vkeys[lane] = ~0ull;
@@ -281,6 +289,10 @@ __device__ __forceinline__ bool wave_traverse_steal(const tr_bvh_view& b, tr_ray
             }
         }
     }
+#ifdef TR_TIMELINE
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) { lw[0] = (int32_t)trip; lw[1] = tl_handovers; }
+#endif
     return split;
 }
 
@@ -396,6 +408,11 @@ __device__ __forceinline__ void flush_stats(const tr_counters& c, unsigned long 
     }
 }
 
+#ifdef TR_TIMELINE
+// experiment build only (not part of the ABI): TR_TIMELINE = number of wave records kept
+__device__ unsigned long long g_timeline[4 * TR_TIMELINE];
+#endif
+
 // MODE: 0 fused ordered trip, 1 fused trip + intra-wave work stealing, 2 unordered two-phase
 // schedule (any / count / location on hierarchies of at least two triangles)
 template <int Q, bool STATS, bool COMPACT, int BS, int MODE = 0>
@@ -413,6 +430,10 @@ __global__ __launch_bounds__(BS) void k_query_direct(tr_bvh_view b, RayFetch rf,
     __shared__ volatile int32_t pad_lds[TR_LDS_PAD / 4];
     pad_lds[threadIdx.x] = (int32_t)blockIdx.x;      // volatile: the allocation must survive
 #endif
+#ifdef TR_TIMELINE
+    // experiment (scripts/exp_timeline.py): per-wave start / end / placement of the launch
+    const unsigned long long tl_start = wall_clock64();
+#endif
     const unsigned long long t_start = cost ? wall_clock64() : 0ull;
     __shared__ int32_t ring_lds[TR_RING * BS];
     const tr_ring ring = {ring_lds + threadIdx.x, BS};
@@ -422,8 +443,23 @@ __global__ __launch_bounds__(BS) void k_query_direct(tr_bvh_view b, RayFetch rf,
     // (and of the BVH) while expensive regions are still spread over all XCDs.  Placement only
     // affects speed.
     int64_t blk = blockIdx.x;
+    int part = 0, parts_lg = 0;           // block splitting (k_sched_sort): this launch slot's share
     if (order) {
-        blk = order[blockIdx.x];          // measured order: most expensive blocks first
+        // measured order: most expensive blocks first.  Bits 30-31 of an entry = lg of the number of
+        // launch slots the block's rays were dealt to, bits 28-29 = this slot's part.
+        const uint32_t e = order[blockIdx.x];
+        blk = e & 0x0fffffffu;
+        parts_lg = (int)(e >> 30);
+        part = (int)((e >> 28) & 3u);
+        if (MODE != 1) {                  // (split orders are only written for the shapes that steal)
+            if (part) return;
+            parts_lg = 0;
+        }
+#ifdef TR_PRIO_SHIFT
+        // experiment: the launch ends with its most expensive waves (scripts/exp_timeline.py); let
+        // the first gridDim >> TR_PRIO_SHIFT slots (the most expensive blocks) win instruction issue
+        if (blockIdx.x < (gridDim.x >> TR_PRIO_SHIFT)) __builtin_amdgcn_s_setprio(3);
+#endif
     } else if (xcd_map > 0) {
         const int64_t T = xcd_map, span = 8 * T;
         const int64_t nfull = (int64_t)gridDim.x / span * span;   // blocks covered by whole spans
@@ -449,6 +485,9 @@ __global__ __launch_bounds__(BS) void k_query_direct(tr_bvh_view b, RayFetch rf,
         i = ((ty << lgh) + (lane >> lgw)) * width + (tx << lgw) + (lane & ((1 << lgw) - 1));
     }
     tr_counters cnt = {0, 0, 0};
+#ifdef TR_TIMELINE
+    unsigned long long tl_extra = 0;
+#endif
     if (MODE == 2) {
         // the steal_min argument carries the leaf-phase vote threshold of this schedule
         __shared__ int32_t leafq_lds[TR_LEAFQ * BS];
@@ -456,17 +495,43 @@ __global__ __launch_bounds__(BS) void k_query_direct(tr_bvh_view b, RayFetch rf,
         process_ray_unordered<Q, STATS, COMPACT>(b, rf, out, i, i < rf.n, &cnt, ring, lq, steal_min);
     } else if (MODE == 1) {
         __shared__ alignas(8) int32_t steal_lds[(BS / 64) * 384];
-        // the scramble argument is not needed by launches that steal: it carries the trip
-        // threshold from which a closest/first ray without a hit may give subtrees away
-        process_ray_steal<Q, STATS, COMPACT>(b, rf, out, i, i < rf.n, &cnt, ring,
-                                             steal_lds + (threadIdx.x >> 6) * 384, (uint32_t)steal_min);
+        // A split block (one of the most expensive of the previous launch): this slot owns the rays
+        // of every 2^parts_lg-th lane; the other lanes start idle and take subtrees of those rays
+        // from the trip in the upper half of the argument on (the lower half: everybody else)
+        const bool mine = (((int)threadIdx.x ^ part) & ((1 << parts_lg) - 1)) == 0;
+        const uint32_t smin = parts_lg ? (uint32_t)steal_min >> 16 : (uint32_t)steal_min & 0xffffu;
+        process_ray_steal<Q, STATS, COMPACT>(b, rf, out, i, i < rf.n && mine, &cnt, ring,
+                                             steal_lds + (threadIdx.x >> 6) * 384, smin);
+#ifdef TR_TIMELINE
+        tl_extra = (unsigned)(steal_lds[(threadIdx.x >> 6) * 384] & 0xffff) |
+                   ((unsigned long long)(steal_lds[(threadIdx.x >> 6) * 384 + 1] & 0xffff) << 16);
+#endif
     } else {
         process_ray<Q, STATS, COMPACT>(b, rf, out, i, i < rf.n, &cnt, ring);
     }
     if (cost && (threadIdx.x & 63) == 0) {
-        const unsigned long long dt = wall_clock64() - t_start;     // 100 MHz ticks
+        // 100 MHz ticks.  A split block records twice what it would have cost in one piece (roughly):
+        // it has to stay among the expensive ones, or the split set alternates between two groups of
+        // blocks from one measurement to the next (and every other group of launches has a long tail)
+        const unsigned long long dt = (wall_clock64() - t_start) << (parts_lg ? parts_lg + 1 : 0);
         atomicMax(&cost[blk], (uint32_t)(dt > 0x7ffffull ? 0x7ffffull : dt));
     }
+#ifdef TR_TIMELINE
+    if ((threadIdx.x & 63) == 0) {
+        const uint64_t w = (uint64_t)blockIdx.x * (BS / 64) + (threadIdx.x >> 6);
+        if (w < TR_TIMELINE) {
+            g_timeline[w * 4 + 0] = tl_start;
+            g_timeline[w * 4 + 1] = wall_clock64();
+            g_timeline[w * 4 + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) << 32) |
+                                    (unsigned)__builtin_amdgcn_s_getreg(20 | (31 << 11));   // HW_ID | XCC_ID
+            unsigned long long extra = 0;
+            if (MODE == 1) {   // trips of the wave | hand-overs (wave_traverse_steal)
+                extra = tl_extra;
+            }
+            g_timeline[w * 4 + 3] = (unsigned long long)blk | (extra << 32);
+        }
+    }
+#endif
     flush_stats<STATS>(cnt, stats);
 }
 
@@ -476,7 +541,7 @@ __global__ __launch_bounds__(BS) void k_query_direct(tr_bvh_view b, RayFetch rf,
 // Resets the cost array for the next measurement.
 __global__ __launch_bounds__(1024) void k_sched_sort(uint32_t* __restrict__ cost,
                                                       uint32_t* __restrict__ order, int nblocks,
-                                                      int xcd_map) {
+                                                      int xcd_map, int split, int split4) {
     // list x: blocks whose home in the XCD-chunked map is XCD x (see k_query_direct; the blocks
     // past the last whole span are dealt round-robin there, so their home is i % 8).  Launch
     // slot j*8+x runs on XCD x, so list x fills the slots of XCD x in cost order: expensive
@@ -520,7 +585,20 @@ __global__ __launch_bounds__(1024) void k_sched_sort(uint32_t* __restrict__ cost
         const uint32_t q = 255u - min(255u, (uint32_t)((float)cost[i] * scale));
         const int x = i < nfull ? (i / T) & 7 : i & 7;
         const uint32_t j = atomicAdd(&bins[x][q], 1u);
-        order[j * 8u + (uint32_t)x] = (uint32_t)i;
+        // block splitting: the `split` most expensive blocks of every XCD get two launch slots
+        // each (halves of their rays, see k_query_direct); the launch has 8 * split slots more
+        // (the first `split4` of them four: quarters of their rays)
+        const uint32_t sp = (uint32_t)split, q4 = (uint32_t)split4;
+        if (j < q4) {
+            for (uint32_t k = 0; k < 4u; k++)
+                order[(4u * j + k) * 8u + (uint32_t)x] = (uint32_t)i | (2u << 30) | (k << 28);
+        } else if (j < sp) {
+            const uint32_t p = 4u * q4 + 2u * (j - q4);
+            order[p * 8u + (uint32_t)x] = (uint32_t)i | (1u << 30);
+            order[(p + 1u) * 8u + (uint32_t)x] = (uint32_t)i | (1u << 30) | (1u << 28);
+        } else {
+            order[(j + sp + 2u * q4) * 8u + (uint32_t)x] = (uint32_t)i;
+        }
         cost[i] = 0u;
     }
 }
@@ -918,31 +996,35 @@ int enter_bvh_device(const tr_bvh* bvh, const tr_rays* rays, tr_device_guard* gu
 // this launch should record block costs (and be followed by k_sched_sort), order != NULL when a
 // measured order exists for this block count.
 void sched_acquire(const tr_bvh* bvh, const tr_options& opt, hipStream_t stream, int64_t nblocks,
-                   const uint32_t** order, uint32_t** cost) {
+                   int64_t split, const uint32_t** order, uint32_t** cost) {
     *order = nullptr;
     *cost = nullptr;
     tr_bvh* mb = const_cast<tr_bvh*>(bvh);
     if (!opt.adaptive || !mb->sched_mutex || nblocks < 64 || nblocks > TR_SCHED_MAX) return;
+    // launches with split blocks (the stealing shapes) and launches without learn separate orders:
+    // their costs differ, and a plain shape would only skip the extra slots of a split order
+    const int cls = split > 0;
     tr_sched_slot* slot = nullptr;
     std::lock_guard<std::mutex> lock(*mb->sched_mutex);
     for (int k = 0; k < TR_SCHED_SLOTS && !slot; k++)
-        if (mb->sched[k].used && mb->sched[k].stream == stream) slot = &mb->sched[k];
+        if (mb->sched[k].used && mb->sched[k].stream == stream && mb->sched[k].cls == cls) slot = &mb->sched[k];
     for (int k = 0; k < TR_SCHED_SLOTS && !slot; k++)
         if (!mb->sched[k].used) {
             uint32_t* buf = nullptr;
             if (hipMalloc((void**)&buf, sizeof(uint32_t) * 2 * TR_SCHED_MAX) != hipSuccess) { (void)hipGetLastError(); break; }
             if (hipMemsetAsync(buf, 0, sizeof(uint32_t) * 2 * TR_SCHED_MAX, stream) != hipSuccess) { (void)hipFree(buf); break; }
-            mb->sched[k].used = true; mb->sched[k].stream = stream; mb->sched[k].buf = buf; mb->sched[k].nblocks = 0;
+            mb->sched[k].used = true; mb->sched[k].stream = stream; mb->sched[k].cls = cls; mb->sched[k].buf = buf; mb->sched[k].nblocks = 0;
             slot = &mb->sched[k];
         }
     if (!slot) return;
-    if (slot->nblocks == nblocks) {
+    if (slot->nblocks == nblocks && slot->split == split) {
         *order = slot->buf + TR_SCHED_MAX;
         slot->launches++;
     } else {
         slot->launches = 0;
     }
     slot->nblocks = nblocks;   // the sort enqueued after the launch makes it valid for the next one
+    slot->split = split;
     // measure + re-sort after each of the first launches of a batch size, then every 4th: the
     // costs of a scene change slowly and the sort (8 us) is serial work behind every launch
     if (slot->launches < 3 || (slot->launches & 3) == 3) *cost = slot->buf;
@@ -1020,9 +1102,6 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
                 if (!sel) return TR_OK;
             }
         }
-        const uint32_t* order = nullptr;
-        uint32_t* cost = nullptr;
-        if (!STATS) sched_acquire(bvh, opt, stream, nblocks_direct, &order, &cost);
         // chunk size of the XCD map: the option is in units of 256 rays; at least 4 chunks per
         // XCD so that the XCDs' shares of an uneven image stay comparable
         int xc = opt.xcd_chunk * (256 / bs);
@@ -1055,15 +1134,6 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
             const int w = 64 >> lgh, h = 1 << lgh;
             if (lgh > 0 && rf.s2 % w == 0 && rf.n % ((int64_t)h * rf.s2) == 0) tile_w = (int)rf.s2 | (lgh << 28);
         }
-        int scramble = 0;
-        if (xc > 0 && opt.scramble) {
-            const int64_t cnt = nblocks_direct / (8 * (int64_t)xc) * xc;   // blocks per XCD in whole spans
-            for (int p : {7919, 7907, 7901})
-                if (cnt > 1 && cnt % p != 0) { scramble = p; break; }
-        }
-#define TR_LAUNCH_DIRECT(C, B)                                                                          \
-    hipLaunchKernelGGL((k_query_direct<Q, STATS, C, B>), dim3((unsigned)nblocks_direct), dim3(B), 0, stream, \
-                       view, rf, out, xc, scramble, tile_w, steal_min, order, cost, d_stats, sel)
         // intra-wave work stealing (wave_traverse_steal).  steal = 1 (default): closest / first / any
         // launches of up to 4 M rays, donors from their 64th trip on -- +11 % on the headline, +45 % at
         // 262 k rays, +25 % on the 4-shell scene, -3 % on 1 M incoherent rays; larger launches are
@@ -1078,11 +1148,53 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
         // any where stealing is not in play).  Hierarchies only (a single triangle has none).
         const bool unord = opt.unordered && !steal && bvh->num_tris >= 2 &&
                            (Q == TR_Q_COUNT || Q == TR_Q_LOCATION || (Q == TR_Q_ANY && opt.unordered > 1));
+        // Block splitting: the nblocks >> N most expensive blocks of the previous launch get two launch
+        // slots each.  A launch ends with its most expensive waves (scripts/exp_timeline.py: with 8x8
+        // tiles everything but ~100 waves of the headline image is done after 215 us of 320), and those
+        // are waves whose 64 rays ALL graze the surface, so stealing inside the wave has no idle lane to
+        // give work to: half the rays per wave leaves 32 lanes that take subtrees from the first trips on
+        // -- which is what makes 8x8 tiles (14 % fewer instructions: the launch is bound by VALU issue)
+        // affordable below 4 M rays.  The first quarter of the split blocks gets four slots (C4 closest
+        // 0.221 -> 0.2015 ms).  Launch shapes that steal only; the others keep their own learned order
+        // (sched_acquire).  Speed only.  split: 0 off, 1 auto, N >= 2: nblocks >> N.
+        const bool small_tris = rf.n >= 8 * bvh->num_tris;   // triangles of many pixels: flat tiles, balanced waves
+        const bool can_tile8 = opt.tile && rf.s1 > 1 && rf.s2 % 8 == 0 && rf.s2 >= 8 && rf.s2 < (1 << 28) && rf.n % (8 * rf.s2) == 0;
+        int split_shift = 0;
+        if (steal && opt.split > 1) split_shift = opt.split;
+        else if (steal && opt.split == 1 && opt.steal == 1) {
+            if (can_tile8 && !small_tris) split_shift = nblocks_direct <= 8192 ? 4 : (nblocks_direct < 32768 ? 5 : 0);
+            else if (!can_tile8 && nblocks_direct <= 2048) split_shift = 4;
+        }
+        int64_t split = 0;
+        if (split_shift > 0 && bs == 128 && nblocks_direct >= (opt.split > 1 ? 64 : 512)) split = (nblocks_direct >> split_shift) / 8;
+        if (nblocks_direct + 12 * split > TR_SCHED_MAX) split = 0;
+        const int64_t split4 = split >> 2;
+        const int steal_arg = steal_min | (opt.split_steal << 16);   // trip thresholds: ordinary | split blocks
+        const uint32_t* order = nullptr;
+        uint32_t* cost = nullptr;
+        if (!STATS) sched_acquire(bvh, opt, stream, nblocks_direct, split, &order, &cost);
+        const int64_t nslots = nblocks_direct + (order ? 8 * (split + 2 * split4) : 0);
+        // ... and with split blocks the pruning queries take 8x8 tiles at any size
+        if (split > 0 && can_tile8 && !small_tris && opt.tile_small == 4) tile_w = (int)rf.s2 | (3 << 28);
+        int scramble = 0;
+        if (xc > 0 && opt.scramble) {
+            const int64_t cnt = nblocks_direct / (8 * (int64_t)xc) * xc;   // blocks per XCD in whole spans
+            for (int p : {7919, 7907, 7901})
+                if (cnt > 1 && cnt % p != 0) { scramble = p; break; }
+        }
+#define TR_LAUNCH_DIRECT(C, B)                                                                          \
+    hipLaunchKernelGGL((k_query_direct<Q, STATS, C, B>), dim3((unsigned)nslots), dim3(B), 0, stream, \
+                       view, rf, out, xc, scramble, tile_w, steal_min, order, cost, d_stats, sel)
+        static const bool debug_launch = getenv("TRIRO_DEBUG_LAUNCH") != nullptr;
+        if (debug_launch)
+            fprintf(stderr, "[triro] query %d: rays %lld blocks %lld slots %lld tile 0x%x split %lld order %d cost %d steal %d unordered %d compact %d\n",
+                    Q, (long long)rf.n, (long long)nblocks_direct, (long long)nslots, (unsigned)tile_w, (long long)split,
+                    order != nullptr, cost != nullptr, (int)steal, (int)unord, (int)compact);
         if (unord) {
             if constexpr (Q == TR_Q_COUNT || Q == TR_Q_LOCATION || Q == TR_Q_ANY) {
                 const int leaf_min = opt.leaf_vote;
 #define TR_LAUNCH_UNORD(C, B)                                                                            \
-    hipLaunchKernelGGL((k_query_direct<Q, STATS, C, B, 2>), dim3((unsigned)nblocks_direct), dim3(B), 0, stream, \
+    hipLaunchKernelGGL((k_query_direct<Q, STATS, C, B, 2>), dim3((unsigned)nslots), dim3(B), 0, stream, \
                        view, rf, out, xc, scramble, tile_w, leaf_min, order, cost, d_stats, sel)
                 if (bs == 64) { if (compact) TR_LAUNCH_UNORD(true, 64); else TR_LAUNCH_UNORD(false, 64); }
                 else if (bs == 128) { if (compact) TR_LAUNCH_UNORD(true, 128); else TR_LAUNCH_UNORD(false, 128); }
@@ -1092,11 +1204,11 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
         } else
         if (steal) {
             if (compact)
-                hipLaunchKernelGGL((k_query_direct<Q, false, true, 128, 1>), dim3((unsigned)nblocks_direct), dim3(128), 0, stream,
-                                   view, rf, out, xc, scramble, tile_w, steal_min, order, cost, d_stats, sel);
+                hipLaunchKernelGGL((k_query_direct<Q, false, true, 128, 1>), dim3((unsigned)nslots), dim3(128), 0, stream,
+                                   view, rf, out, xc, scramble, tile_w, steal_arg, order, cost, d_stats, sel);
             else
-                hipLaunchKernelGGL((k_query_direct<Q, false, false, 128, 1>), dim3((unsigned)nblocks_direct), dim3(128), 0, stream,
-                                   view, rf, out, xc, scramble, tile_w, steal_min, order, cost, d_stats, sel);
+                hipLaunchKernelGGL((k_query_direct<Q, false, false, 128, 1>), dim3((unsigned)nslots), dim3(128), 0, stream,
+                                   view, rf, out, xc, scramble, tile_w, steal_arg, order, cost, d_stats, sel);
         } else
         if (bs == 64) { if (compact) TR_LAUNCH_DIRECT(true, 64); else TR_LAUNCH_DIRECT(false, 64); }
         else if (bs == 128) { if (compact) TR_LAUNCH_DIRECT(true, 128); else TR_LAUNCH_DIRECT(false, 128); }
@@ -1104,7 +1216,7 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
 #undef TR_LAUNCH_DIRECT
         if (cost)
             hipLaunchKernelGGL(k_sched_sort, dim3(1), dim3(1024), 0, stream, cost, cost + TR_SCHED_MAX,
-                               (int)nblocks_direct, xc);
+                               (int)nblocks_direct, xc, (int)split, (int)split4);
     }
     TR_HIP_TRY(hipGetLastError());
     return TR_OK;
@@ -1318,3 +1430,10 @@ int tr_trace_stats_closest(const tr_bvh* bvh, const tr_rays* rays, tr_trace_stat
 }
 
 }  // extern "C"
+
+#ifdef TR_TIMELINE
+extern "C" int tr_debug_timeline(unsigned long long* host_out, long long n_waves) {
+    if (n_waves > TR_TIMELINE) n_waves = TR_TIMELINE;
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_timeline), (size_t)n_waves * 32);
+}
+#endif
