@@ -30,19 +30,20 @@ ap.add_argument("--query", default="closest")
 ap.add_argument("--warmup", type=int, default=8)
 ap.add_argument("--opt", action="append", default=[])
 ap.add_argument("--waves-per-simd", type=int, default=7)
+ap.add_argument("--mesh", default="c5i", help="c5i (headline mesh), c4 (4 nested shells), c2 (bunny stand-in)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)  # noqa: E731
 for kv in a.opt:
     k, v_ = kv.split("=", 1)
     hops.set_option(k, int(v_))
-v, f = W.headline_mesh(8)
+v, f = {"c5i": lambda: W.headline_mesh(8), "c4": lambda: W.nested_shells(7), "c2": W.bunny_standin}[a.mesh]()
 r = RayMeshIntersector(vertices=T(v), faces=T(f))
 rad = float(np.linalg.norm(v, axis=1).max())
-on, dn = W.pinhole_grid(a.res, a.res, distance=2.5 * rad)
+on, dn = W.pinhole_grid(a.res, a.res, distance=2.5 if a.mesh == "c4" else 2.5 * rad)
 o, d = T(on), T(dn)
 fn = {"closest": lambda: r.intersects_closest(o, d), "any": lambda: r.intersects_any(o, d),
-      "count": lambda: r.intersects_count(o, d)}[a.query]
+      "count": lambda: r.intersects_count(o, d), "location": lambda: r.intersects_location(o, d)}[a.query]
 for _ in range(a.warmup):
     fn()
 torch.cuda.synchronize()
@@ -81,7 +82,7 @@ ucu = np.unique(cu_id)
 per_cu_time = np.array([dur[cu_id == c].sum() for c in ucu])
 last_end_cu = np.array([en[cu_id == c].max() for c in ucu])
 q = lambda x, p: float(np.percentile(x, p))  # noqa: E731
-out = {"res": a.res, "query": a.query, "opts": a.opt, "event_ms": round(e0.elapsed_time(e1), 4),
+out = {"mesh": a.mesh, "res": a.res, "query": a.query, "opts": a.opt, "event_ms": round(e0.elapsed_time(e1), 4),
        "waves": int(ok.sum()), "span_us": round(span, 1),
        "wave_us": {"mean": round(float(dur.mean()), 1), "p50": round(q(dur, 50), 1), "p90": round(q(dur, 90), 1),
                    "p99": round(q(dur, 99), 1), "max": round(float(dur.max()), 1)},

@@ -152,6 +152,9 @@ __device__ __forceinline__ void wave_traverse(const tr_bvh_view& b, const tr_ray
 #ifndef TR_STEAL_EVERY
 #define TR_STEAL_EVERY 3u     // hand-overs are attempted on every (TR_STEAL_EVERY+1)-th trip ...
 #endif
+#ifndef TR_STEAL_SHARE
+#define TR_STEAL_SHARE 1      // lanes working on the same ray exchange their best hit at every look
+#endif
 #ifndef TR_STEAL_IDLE
 #define TR_STEAL_IDLE 1       // ... when at least this many lanes are idle
 #endif
@@ -218,6 +221,37 @@ __device__ __forceinline__ bool wave_traverse_steal(const tr_bvh_view& b, tr_ray
             TR_CONVERGE();
         }
         trip += TR_STEAL_EVERY + 1u;
+        if (TR_STEAL_SHARE && split) {
+            // Rays that are traversed by several lanes share what they have found: a lane's bound is
+            // the best hit of ANY lane working on its ray (closest / first), and an any-hit ray ends
+            // for all of them with the first hit.  A bound that is a real hit of the same ray culls
+            // exactly what the lane's own hit at that distance would cull, and the result is the
+            // minimum (t_key, face) over all lanes either way -- but the subtrees given away early no
+            // longer lose the culling the donor's later hits would have brought.
+            if (Q == TR_Q_ANY) {
+                if (res.best_face >= 0) vsum[owner] = 1;
+                __builtin_amdgcn_wave_barrier();
+                if (vsum[owner] != 0 && !tr_done(fs)) {
+                    fs.node = -1; fs.p0 = -1; fs.p1 = -1;
+#if TR_LEAF_QUEUE
+                    fs.p2 = -1;
+#endif
+                }
+            } else if (Q == TR_Q_CLOSEST || Q == TR_Q_FIRST) {
+                const bool have = res.best_slot >= 0;
+                const unsigned long long mine = ((unsigned long long)(__float_as_uint(res.best_t) & 0x7fffffffu) << 32) |
+                                                (unsigned)(res.best_face < 0 ? 0x7fffffff : res.best_face);
+                if (have) atomicMin(&keys[owner], mine);
+                __builtin_amdgcn_wave_barrier();
+                const unsigned long long k = vkeys[owner];
+                if (have && k == mine) vslots[owner] = res.best_slot;
+                if (k < mine) {     // another lane's hit: a bound, not a result of this lane
+                    res.best_t = __uint_as_float((unsigned)(k >> 32));
+                    res.best_face = (int32_t)(unsigned)k;
+                    res.best_slot = -1;
+                }
+            }
+        }
         const bool done = tr_done(fs);
         const unsigned long long idle = __ballot(done);
         if (idle == ~0ull) break;
@@ -1161,7 +1195,7 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
         const bool can_tile8 = opt.tile && rf.s1 > 1 && rf.s2 % 8 == 0 && rf.s2 >= 8 && rf.s2 < (1 << 28) && rf.n % (8 * rf.s2) == 0;
         int split_shift = 0;
         if (steal && opt.split > 1) split_shift = opt.split;
-        else if (steal && opt.split == 1 && opt.steal == 1) {
+        else if (steal && opt.split == 1 && rf.n <= ((int64_t)1 << 22) && Q != TR_Q_COUNT) {
             if (can_tile8 && !small_tris) split_shift = nblocks_direct <= 8192 ? 4 : (nblocks_direct < 32768 ? 5 : 0);
             else if (!can_tile8 && nblocks_direct <= 2048) split_shift = 4;
         }
