@@ -500,7 +500,10 @@ int tr_build_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_
     bvh->num_nodes = nf >= 2 ? nf - 1 : 0;
     bvh->depth = 0;
     bvh->key_mode = 0;
-    for (int k = 0; k < TR_SCHED_SLOTS; k++) bvh->sched[k].nblocks = 0;   // measured orders are stale
+    // A learned launch order describes the rays, not the mesh: after a rebuild (an animation step,
+    // `update_raw`) it is one frame stale, which is a far better hint than none -- keep it and
+    // measure again on the next launches
+    for (int k = 0; k < TR_SCHED_SLOTS; k++) bvh->sched[k].launches = 0;
     for (int k = 0; k < 3; k++) { bvh->aabb_min[k] = 0.f; bvh->aabb_max[k] = 0.f; }
     if (nf == 0) return TR_OK;
 

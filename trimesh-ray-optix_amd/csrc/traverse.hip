@@ -1201,7 +1201,7 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
         }
         int64_t split = 0;
         if (split_shift > 0 && bs == 128 && nblocks_direct >= (opt.split > 1 ? 64 : 512)) split = (nblocks_direct >> split_shift) / 8;
-        if (nblocks_direct + 12 * split > TR_SCHED_MAX) split = 0;
+        if (nblocks_direct + 12 * split > TR_SCHED_MAX || !opt.adaptive) split = 0;   // no learned order, no split
         const int64_t split4 = split >> 2;
         const int steal_arg = steal_min | (opt.split_steal << 16);   // trip thresholds: ordinary | split blocks
         const uint32_t* order = nullptr;
