@@ -489,11 +489,6 @@ __global__ __launch_bounds__(BS) void k_query_direct(tr_bvh_view b, RayFetch rf,
             if (part) return;
             parts_lg = 0;
         }
-#ifdef TR_PRIO_SHIFT
-        // experiment: the launch ends with its most expensive waves (scripts/exp_timeline.py); let
-        // the first gridDim >> TR_PRIO_SHIFT slots (the most expensive blocks) win instruction issue
-        if (blockIdx.x < (gridDim.x >> TR_PRIO_SHIFT)) __builtin_amdgcn_s_setprio(3);
-#endif
     } else if (xcd_map > 0) {
         const int64_t T = xcd_map, span = 8 * T;
         const int64_t nfull = (int64_t)gridDim.x / span * span;   // blocks covered by whole spans
