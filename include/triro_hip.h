@@ -192,8 +192,14 @@ int tr_trace_stats_query(const tr_bvh *bvh, const tr_rays *rays, int query, tr_t
  *    device, between builds so a rebuild costs no allocation; default 1),
  *    "unordered" (0/1/2: count and location -- with 2 also any -- queue box-hit leaves and test
  *    them in separate wave-level leaf phases instead of on every trip; default 1), "leaf_vote"
- *    (1..64 lanes with a queued leaf that trigger such a phase).
- *    Returns TR_ERR_INVALID_ARG for unknown names.                                         */
+ *    (1..64 lanes with a queued leaf that trigger such a phase), "tile_small" (0..4: pixel
+ *    footprint of a wave for image-shaped batches below the "tile" threshold), "stream" (0/1/2),
+ *    "stream_rays", "stream_refill" (streaming launch with wave-level ray refill for large
+ *    incoherent batches), "split" (0 off / 1 auto / N >= 2: the nblocks >> N most expensive blocks of
+ *    the learned launch order are traced by two -- the first quarter by four -- launch slots of
+ *    half / quarter lane density whose idle lanes steal from trip "split_steal" on).
+ *    None of them changes results.  Returns TR_ERR_INVALID_ARG for unknown names or values out
+ *    of range.                                                                             */
 int tr_set_option(const char *name, int64_t value);
 
 #ifdef __cplusplus

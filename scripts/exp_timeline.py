@@ -31,6 +31,7 @@ ap.add_argument("--warmup", type=int, default=8)
 ap.add_argument("--opt", action="append", default=[])
 ap.add_argument("--waves-per-simd", type=int, default=7)
 ap.add_argument("--mesh", default="c5i", help="c5i (headline mesh), c4 (4 nested shells), c2 (bunny stand-in)")
+ap.add_argument("--hash-rays", type=int, default=0, help="N incoherent hash rays instead of the pinhole image (streaming launch)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)  # noqa: E731
@@ -42,6 +43,8 @@ r = RayMeshIntersector(vertices=T(v), faces=T(f))
 rad = float(np.linalg.norm(v, axis=1).max())
 on, dn = W.pinhole_grid(a.res, a.res, distance=2.5 if a.mesh == "c4" else 2.5 * rad)
 o, d = T(on), T(dn)
+if a.hash_rays:
+    o, d = W.hash_rays_torch(a.hash_rays, 1234, v.min(0) * 1.5, v.max(0) * 1.5, device=dev)
 fn = {"closest": lambda: r.intersects_closest(o, d), "any": lambda: r.intersects_any(o, d),
       "count": lambda: r.intersects_count(o, d), "location": lambda: r.intersects_location(o, d)}[a.query]
 for _ in range(a.warmup):
@@ -54,6 +57,8 @@ e1.record()
 torch.cuda.synchronize()
 lib = ctypes.CDLL(hops.library_path())
 nw = min(a.res * a.res // 64 + 4096, 131072)          # + the extra launch slots of split blocks
+if a.hash_rays:
+    nw = min((a.hash_rays + 63) // 64, 131072)
 buf = np.zeros((nw, 4), np.uint64)
 rc = lib.tr_debug_timeline(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_longlong(nw))
 assert rc == 0, rc

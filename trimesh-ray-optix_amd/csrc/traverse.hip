@@ -698,6 +698,10 @@ __global__ __launch_bounds__(BS) void k_query_stream(tr_bvh_view b, RayFetch rf,
                                                      unsigned long long* stats,
                                                      const int* __restrict__ sel) {
     if (sel && *sel != 1) return;      // dual launch: this is the shape for incoherent batches (id 1)
+#ifdef TR_TIMELINE
+    const unsigned long long tl_start = wall_clock64();
+    unsigned tl_trips = 0, tl_refills = 0;
+#endif
     typedef typename tr_word<COMPACT>::T W;
     __shared__ int32_t ring_lds[TR_RING * BS];
     const tr_ring ring = {ring_lds + threadIdx.x, BS};
@@ -748,6 +752,9 @@ __global__ __launch_bounds__(BS) void k_query_stream(tr_bvh_view b, RayFetch rf,
                 }
             }
             next += nidle;     // lanes past `end` took nothing; the cursor only has to reach `end`
+#ifdef TR_TIMELINE
+            tl_refills++;
+#endif
         }
         // trips until the next refill is due (or, once the range is used up, until all lanes are
         // done): a plain single-exit loop like the direct launch's, with a wave-uniform exit test
@@ -760,9 +767,22 @@ __global__ __launch_bounds__(BS) void k_query_stream(tr_bvh_view b, RayFetch rf,
             }
             TR_CONVERGE();
             idle_now = __popcll(__ballot(!busy));
+#ifdef TR_TIMELINE
+            tl_trips++;
+#endif
         } while (idle_now < stop);
     }
     if (rid >= 0) write_result<Q>(b, out, rid, r, res);
+#ifdef TR_TIMELINE
+    if ((threadIdx.x & 63) == 0 && wave < TR_TIMELINE) {
+        g_timeline[wave * 4 + 0] = tl_start;
+        g_timeline[wave * 4 + 1] = wall_clock64();
+        g_timeline[wave * 4 + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) << 32) |
+                                   (unsigned)__builtin_amdgcn_s_getreg(20 | (31 << 11));
+        g_timeline[wave * 4 + 3] = (unsigned long long)(wave & 0x0fffffff) | ((unsigned long long)(tl_trips & 0xffff) << 32) |
+                                   ((unsigned long long)(tl_refills & 0xffff) << 48);
+    }
+#endif
     flush_stats<STATS>(cnt, stats);
 }
 
