@@ -18,7 +18,7 @@ dev = torch.device("cuda:0")
 T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
 DEFAULTS = {"steal": 1, "tile": 1, "block_size": 128, "adaptive": 1, "xcd_chunk": 128, "compact": 1, "scramble": 1,
             "persistent": 0, "blocks_per_cu": 8,
-            "tile_small": 4, "unordered": 1, "leaf_vote": 32, "stream": 1, "stream_rays": 512, "stream_refill": 16,
+            "tile_small": 4, "unordered": 1, "leaf_vote": 32, "stream": 1, "stream_rays": 256, "stream_refill": 32, "stream_dynamic": 1,
             "split": 1, "split_steal": 8}
 bad = 0
 for it in range(a.iters):
@@ -61,7 +61,7 @@ for it in range(a.iters):
             # streaming launch with wave-level ray refill (2 = forced at any size and shape)
             "tile_small": int(rng.choice([0, 1, 2, 3, 4])),
             "stream": int(rng.choice([0, 1, 2, 2])), "stream_rays": int(rng.choice([64, 100, 512, 4096])),
-            "stream_refill": int(rng.choice([1, 8, 16, 40, 64])),
+            "stream_refill": int(rng.choice([1, 8, 16, 40, 64])), "stream_dynamic": int(rng.choice([0, 1, 1])),
             # block splitting of the stealing launch shapes (from the second launch of a batch on)
             "split": int(rng.choice([0, 1, 1, 2, 3, 4])), "split_steal": int(rng.choice([0, 2, 8, 64]))}
     for k, val in opts.items(): hops.set_option(k, val)

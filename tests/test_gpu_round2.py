@@ -324,9 +324,11 @@ def test_unordered_schedule_matches_the_oracle(device, unordered, leaf_vote):
         hops.set_option("leaf_vote", 32)
 
 
-@pytest.mark.parametrize("rays_per_wave,refill", [(64, 1), (100, 16), (512, 16), (512, 64), (4096, 32)])
-def test_streaming_launch_with_ray_refill_matches_the_oracle(device, rays_per_wave, refill):
-    """The streaming launch (every wave owns a range of rays and refills its idle lanes from it)
+@pytest.mark.parametrize("rays_per_wave,refill,dynamic", [(64, 1, 1), (100, 16, 1), (256, 32, 1), (512, 16, 0), (512, 64, 1),
+                                                          (4096, 32, 0), (64, 40, 0), (4096, 8, 1)])
+def test_streaming_launch_with_ray_refill_matches_the_oracle(device, rays_per_wave, refill, dynamic):
+    """The streaming launch (a wave takes ranges of rays -- from a work counter, or one static range --
+    and refills its idle lanes from them)
     forced on at sizes and shapes where the automatic policy would not use it: closest / first /
     any / count against the oracle on incoherent and coherent rays, ragged tails (n not a
     multiple of the range), strided and broadcast inputs, a single-triangle mesh, invalid rays."""
@@ -341,6 +343,7 @@ def test_streaming_launch_with_ray_refill_matches_the_oracle(device, rays_per_wa
         hops.set_option("stream", 2)
         hops.set_option("stream_rays", rays_per_wave)
         hops.set_option("stream_refill", refill)
+        hops.set_option("stream_dynamic", dynamic)
         for (v, f), (o, d) in cases:
             r = make(v, f, device)
             R = OracleIntersector(v, f, 1)
@@ -370,8 +373,9 @@ def test_streaming_launch_with_ray_refill_matches_the_oracle(device, rays_per_wa
         assert_closest_bitexact(r1.intersects_closest(T(o1, device), T(d1, device)), R1.closest_raw(o1, d1), "one triangle")
     finally:
         hops.set_option("stream", 1)
-        hops.set_option("stream_rays", 512)
-        hops.set_option("stream_refill", 16)
+        hops.set_option("stream_rays", 256)
+        hops.set_option("stream_refill", 32)
+        hops.set_option("stream_dynamic", 1)
 
 
 def test_large_flat_batches_probe_and_both_launch_shapes(device):

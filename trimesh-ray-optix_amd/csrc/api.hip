@@ -37,6 +37,7 @@ const opt_desc OPTS[] = {
     {"stream", &tr_options::stream, 0, 2, false},
     {"stream_rays", &tr_options::stream_rays, 64, 1 << 20, false},
     {"stream_refill", &tr_options::stream_refill, 1, 64, false},
+    {"stream_dynamic", &tr_options::stream_dynamic, 0, 1, false},
     {"leaf_vote", &tr_options::leaf_vote, 1, 64, false},
     {"split", &tr_options::split, 0, 12, false},
     {"split_steal", &tr_options::split_steal, 0, 4096, false},

@@ -136,8 +136,9 @@ struct tr_options {
     int scramble = 1;     // launches without a measured order visit each XCD's blocks in a scrambled order
     int build_cache = 1;  // keep the builder's temporaries (about 130 B/triangle) per device between builds
     int stream = 1;       // streaming launch with wave-level ray refill: 0 never, 1 large non-image batches, 2 always
-    int stream_rays = 512;    // rays per wave of the streaming launch (its private range)
+    int stream_rays = 256;    // rays per range of the streaming launch (512 was the optimum of the static map)
     int stream_refill = 32;   // idle lanes that trigger a refill
+    int stream_dynamic = 1;   // ranges handed out by a work counter to a resident-sized grid (0: one static range per wave)
     int unordered = 1;    // count / location (2: also any) use the unordered two-phase schedule (queued leaves)
     int split = 1;        // block splitting: 0 off, 1 auto, N >= 2: the nblocks >> N most expensive blocks of the previous launch get two launch slots
     int split_steal = 8;  // ... and give subtrees away from this trip on

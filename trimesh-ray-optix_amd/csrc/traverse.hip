@@ -689,14 +689,18 @@ __global__ __launch_bounds__(256) void k_probe_coherence(RayFetch rf, float scen
         if (par && near) atomicAdd(&votes, 1);
     }
     __syncthreads();
-    if (threadIdx.x == 0) *sel = votes >= 192 ? 0 : 1;
+    if (threadIdx.x == 0) {
+        *sel = votes >= 192 ? 0 : 1;
+        sel[2] = 0; sel[3] = 0;        // the streaming launch's work counter (2nd 64-bit word of the slot)
+    }
 }
 
 template <int Q, bool STATS, bool COMPACT, int BS>
 __global__ __launch_bounds__(BS) void k_query_stream(tr_bvh_view b, RayFetch rf, QueryOut out,
                                                      int rays_per_wave, int refill_min, int xcd_map,
                                                      unsigned long long* stats,
-                                                     const int* __restrict__ sel) {
+                                                     const int* __restrict__ sel,
+                                                     unsigned long long* work) {
     if (sel && *sel != 1) return;      // dual launch: this is the shape for incoherent batches (id 1)
 #ifdef TR_TIMELINE
     const unsigned long long tl_start = wall_clock64();
@@ -720,6 +724,13 @@ __global__ __launch_bounds__(BS) void k_query_stream(tr_bvh_view b, RayFetch rf,
     int64_t next = wave * rays_per_wave;                 // wave-uniform cursor into the wave's range
     int64_t end = next + rays_per_wave;
     if (end > rf.n) end = rf.n;
+    // work != NULL: ranges are handed out by a work counter instead (one atomic per range): a wave
+    // that has used its range up takes the next one and keeps refilling, so only the very last
+    // range of every wave is drained and the launch ends within one range's time for all waves
+    // (the first range of a wave is still the static one: no burst of atomics at the start)
+    bool exhausted = work == nullptr;
+    const unsigned long long first_dynamic = (unsigned long long)gridDim.x * (BS / 64) * (unsigned long long)rays_per_wave;
+    if (next >= rf.n) { next = 0; end = 0; }
     tr_counters cnt = {0, 0, 0};
     int64_t rid = -1;          // ray this lane holds (-1 none); its result is stored when the lane is refilled
     bool busy = false;         // still traversing
@@ -731,6 +742,18 @@ __global__ __launch_bounds__(BS) void k_query_stream(tr_bvh_view b, RayFetch rf,
     tr_result_init(res);
     tr_ray_setup(r, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f);
     for (;;) {
+        if (!exhausted && next >= end) {
+            unsigned long long base = 0;
+            if ((threadIdx.x & 63) == 0) base = atomicAdd(work, (unsigned long long)rays_per_wave) + first_dynamic;
+            base = __shfl(base, 0);
+            if (base >= (unsigned long long)rf.n) {
+                exhausted = true;
+            } else {
+                next = (int64_t)base;
+                end = next + rays_per_wave;
+                if (end > rf.n) end = rf.n;
+            }
+        }
         const unsigned long long idle = __ballot(!busy);
         const int nidle = __popcll(idle);
         const bool more = next < end;
@@ -758,7 +781,7 @@ __global__ __launch_bounds__(BS) void k_query_stream(tr_bvh_view b, RayFetch rf,
         }
         // trips until the next refill is due (or, once the range is used up, until all lanes are
         // done): a plain single-exit loop like the direct launch's, with a wave-uniform exit test
-        const int stop = next < end ? refill_min : 64;
+        const int stop = (next < end || !exhausted) ? refill_min : 64;
         int idle_now;
         do {
             if (busy) {
@@ -1128,9 +1151,11 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
         if constexpr (Q != TR_Q_LOCATION) {
             const bool auto_stream = opt.stream == 1 && rf.n >= ((int64_t)1 << 21) && bvh->num_tris >= 2;
             if (opt.stream == 2 || auto_stream) {
+                unsigned long long* d_work = nullptr;
                 if (auto_stream) {
                     unsigned slot = __atomic_fetch_add(&st->next_counter, 1u, __ATOMIC_RELAXED) % (TR_NUM_COUNTERS / 8);
                     int* d_sel = reinterpret_cast<int*>(reinterpret_cast<unsigned long long*>(st->counters) + 8 * slot);
+                    d_work = reinterpret_cast<unsigned long long*>(st->counters) + 8 * slot + 1;   // zeroed by the probe
                     float diag2 = 0.f;
                     for (int k = 0; k < 3; k++) { const float e = bvh->aabb_max[k] - bvh->aabb_min[k]; diag2 += e * e; }
                     hipLaunchKernelGGL(k_probe_coherence, dim3(1), dim3(256), 0, stream, rf, sqrtf(diag2), d_sel);
@@ -1138,15 +1163,30 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
                 }
                 const int rpw = opt.stream_rays;
                 const int64_t nwaves = (rf.n + rpw - 1) / rpw;
-                const unsigned grid = (unsigned)((nwaves + 1) / 2);
+                unsigned grid = (unsigned)((nwaves + 1) / 2);
                 int sxc = opt.xcd_chunk > 0 ? 16 : 0;       // blocks (2 ranges each) per XCD-local chunk
                 while (sxc > 0 && (int64_t)sxc * 32 > grid) sxc >>= 1;
+                // stream_dynamic (default): the ranges come from a work counter (the 2nd word of the
+                // probe's slot, zeroed by the probe; memset when the launch is forced) and the grid is
+                // what can be resident -- the static map gives every wave exactly one range
+                unsigned long long* work = nullptr;
+                if (opt.stream_dynamic) {
+                    if (d_work == nullptr) {
+                        unsigned slot = __atomic_fetch_add(&st->next_counter, 1u, __ATOMIC_RELAXED) % (TR_NUM_COUNTERS / 8);
+                        d_work = reinterpret_cast<unsigned long long*>(st->counters) + 8 * slot + 1;
+                        TR_HIP_TRY(hipMemsetAsync(d_work, 0, sizeof(unsigned long long), stream));
+                    }
+                    work = d_work;
+                    const unsigned resident = (unsigned)st->num_cus * 16u;
+                    if (grid > resident) grid = resident;
+                    sxc = 0;
+                }
                 if (compact)
                     hipLaunchKernelGGL((k_query_stream<Q, STATS, true, 128>), dim3(grid), dim3(128), 0, stream,
-                                       view, rf, out, rpw, opt.stream_refill, sxc, d_stats, sel);
+                                       view, rf, out, rpw, opt.stream_refill, sxc, d_stats, sel, work);
                 else
                     hipLaunchKernelGGL((k_query_stream<Q, STATS, false, 128>), dim3(grid), dim3(128), 0, stream,
-                                       view, rf, out, rpw, opt.stream_refill, sxc, d_stats, sel);
+                                       view, rf, out, rpw, opt.stream_refill, sxc, d_stats, sel, work);
                 TR_HIP_TRY(hipGetLastError());
                 if (!sel) return TR_OK;
             }
