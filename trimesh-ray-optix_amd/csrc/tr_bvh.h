@@ -440,19 +440,16 @@ TR_HD void tr_leaf_step(const tr_bvh_view& b, const tr_ray& r, tr_state& st, tr_
 // node + the test of a leaf queued by an EARLIER trip.  The node loads are issued first, so
 // the triangle loads and the node loads are in flight together: one memory round trip per
 // trip.  Lanes never sit out.
-template <int Q, int K, bool STATS, bool COMPACT = false, typename W = uint64_t>
-TR_HD void tr_fused_step(const tr_bvh_view& b, const tr_ray& r, tr_state_t<W>& st, tr_result& res,
-                         tr_topk<K>& top, tr_counters* cnt, const tr_ring ring) {
+#if !TR_LEAF_QUEUE
+#error "the fused trip needs the 3-slot leaf FIFO (TR_LEAF_QUEUE)"
+#endif
+// everything of a trip after the node record has arrived (n0..n3: in vector registers, or -- on
+// trips where the whole wave visits the same node -- in scalar registers)
+template <int Q, int K, bool STATS, bool COMPACT, typename W>
+TR_HD void tr_fused_body(const tr_bvh_view& b, const tr_ray& r, tr_state_t<W>& st, tr_result& res,
+                         tr_topk<K>& top, tr_counters* cnt, const tr_ring ring, const bool has_node,
+                         const tr_f4& n0, const tr_f4& n1, const tr_f4& n2, const tr_f4& n3) {
     const bool ordered = (Q == TR_Q_FIRST || Q == TR_Q_CLOSEST);
-#if TR_LEAF_QUEUE
-    // one leaf test per trip: the head of the lane's FIFO (p0, p1, p2).  The node is visited
-    // unless the FIFO is full (it then waits one trip: no fetch, no new leaves).
-    const bool has_node = st.node >= 0 && st.p2 < 0;
-    // node index or 0, from the sign bits (a select here loses the SGPR-base + 32-bit-offset
-    // addressing of the four node loads)
-    const int32_t nidx = st.node & ~(st.node >> 31) & (st.p2 >> 31);
-    const tr_f4* np = tr_node_ptr<COMPACT>(b, nidx);
-    const tr_f4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
     if (STATS && has_node) cnt->nodes++;
     bool fin = false;
     const int32_t q0 = st.p0;
@@ -465,30 +462,6 @@ TR_HD void tr_fused_step(const tr_bvh_view& b, const tr_ray& r, tr_state_t<W>& s
         fin = tr_fold_leaf<Q, K>(live, r, t0, q0, st.p0n, st.p0f, res, top);
     }
     if (Q == TR_Q_ANY && fin) { st.node = -1; st.p1 = -1; st.p2 = -1; }
-#else
-    const bool has_node = st.node >= 0;
-    const tr_f4* np = tr_node_ptr<COMPACT>(b, has_node ? st.node : 0);
-    const tr_f4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
-    if (STATS && has_node) cnt->nodes++;
-    bool fin = false;
-    const int32_t q0 = st.p0, q1 = st.p1;
-    if (TR_WAVE_ANY(q0 >= 0 || q1 >= 0)) {
-        tr_counters* nc = nullptr;
-        const bool any1 = TR_WAVE_ANY(q1 >= 0);
-        const tr_tri t0 = tr_load_tri<false, COMPACT>(b, q0 >= 0 ? q0 : 0, nc);
-        tr_tri t1 = t0;
-        if (any1) t1 = tr_load_tri<false, COMPACT>(b, q1 >= 0 ? q1 : 0, nc);
-        if (STATS && q0 >= 0) cnt->tris++;
-        fin = tr_fold_leaf<Q, K>(q0 >= 0, r, t0, q0, st.p0n, st.p0f, res, top);
-        if (any1) {
-            const bool live = q1 >= 0 && !fin && (!ordered || st.p1n <= res.best_t);
-            if (STATS && live) cnt->tris++;
-            fin = tr_fold_leaf<Q, K>(live, r, t1, q1, st.p1n, st.p1f, res, top) || fin;
-        }
-    }
-    st.p0 = -1; st.p1 = -1;
-    if (Q == TR_Q_ANY && fin) st.node = -1;
-#endif
     // n3 = c0 c1 parent sibling
     float tn0, tf0, tn1, tf1;
     tr_node_slabs(r, n0, n1, n2, tn0, tf0, tn1, tf1);
@@ -560,6 +533,46 @@ TR_HD void tr_fused_step(const tr_bvh_view& b, const tr_ray& r, tr_state_t<W>& s
             st.depth = j + 1;
         }
     }
+}
+
+
+// UNI: look for wave-uniform trips (below).  Worth it for large coherent batches (4 M rays: -4 %,
+// 16.7 M: -5 %), a loss where the texture path is not the busiest unit or uniform trips are rare
+// (1 M rays +-0, 262 k rays +5 %, coarse meshes +3 %, incoherent batches +2 %): the test costs two
+// ballots and a readlane on every trip.
+template <int Q, int K, bool STATS, bool COMPACT = false, typename W = uint64_t, bool UNI = false>
+TR_HD void tr_fused_step(const tr_bvh_view& b, const tr_ray& r, tr_state_t<W>& st, tr_result& res,
+                         tr_topk<K>& top, tr_counters* cnt, const tr_ring ring) {
+    // one leaf test per trip: the head of the lane's FIFO (p0, p1, p2).  The node is visited
+    // unless the FIFO is full (it then waits one trip: no fetch, no new leaves).
+    const bool has_node = st.node >= 0 && st.p2 < 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // Wave-uniform trips: 36-44 % of the node visits of an image-shaped batch happen on trips where
+    // every visiting lane is at the SAME node (the top of the tree under an 8x8 pixel tile).  The
+    // record is then fetched once, by the scalar unit, instead of by a 64-lane gather of four
+    // dwordx4 that all hit the same line: no texture-path work at all for that trip.
+    if (UNI) {
+        const unsigned long long m = __ballot(has_node);
+        if (m != 0ull) {
+            const int32_t nu = __builtin_amdgcn_readlane(st.node, (int)__builtin_ctzll(m));
+            if (__ballot(has_node && st.node != nu) == 0ull) {
+                // constant address space: the node array is read-only while queries run, and a
+                // uniform address in that space is what selects the scalar memory path
+                typedef const __attribute__((address_space(4))) tr_f4* tr_cf4p;
+                const tr_cf4p sp = (tr_cf4p)(unsigned long long)tr_node_ptr<COMPACT>(b, nu);
+                const tr_f4 n0 = sp[0], n1 = sp[1], n2 = sp[2], n3 = sp[3];
+                tr_fused_body<Q, K, STATS, COMPACT, W>(b, r, st, res, top, cnt, ring, has_node, n0, n1, n2, n3);
+                return;
+            }
+        }
+    }
+#endif
+    // node index or 0, from the sign bits (a select here loses the SGPR-base + 32-bit-offset
+    // addressing of the four node loads)
+    const int32_t nidx = st.node & ~(st.node >> 31) & (st.p2 >> 31);
+    const tr_f4* np = tr_node_ptr<COMPACT>(b, nidx);
+    const tr_f4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+    tr_fused_body<Q, K, STATS, COMPACT, W>(b, r, st, res, top, cnt, ring, has_node, n0, n1, n2, n3);
 }
 
 // Slab intervals of both children of a 32-byte grid node held in two 16-byte registers:

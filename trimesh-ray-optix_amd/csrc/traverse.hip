@@ -120,7 +120,7 @@ template <> struct tr_word<true> { typedef uint32_t T; };
 
 // COMPACT = the hierarchy is at most 32 levels high and both arrays are below 4 GiB: 32-bit
 // trail/owned words and SGPR-base + 32-bit-offset loads (chosen on the host per BVH).
-template <int Q, int K, bool STATS, bool COMPACT = false>
+template <int Q, int K, bool STATS, bool COMPACT = false, bool UNI = false>
 __device__ __forceinline__ void wave_traverse(const tr_bvh_view& b, const tr_ray& r, bool go,
                                               tr_result& res, tr_topk<K>& top, tr_counters* cnt,
                                               const tr_ring ring) {
@@ -132,7 +132,7 @@ __device__ __forceinline__ void wave_traverse(const tr_bvh_view& b, const tr_ray
     tr_state_init(fs);
     if (!go) fs.node = -1;
     while (!tr_done(fs)) {
-        tr_fused_step<Q, K, STATS, COMPACT, W>(b, r, fs, res, top, cnt, ring);
+        tr_fused_step<Q, K, STATS, COMPACT, W, UNI>(b, r, fs, res, top, cnt, ring);
         TR_CONVERGE();
     }
 }
@@ -331,7 +331,7 @@ __device__ __forceinline__ bool wave_traverse_steal(const tr_bvh_view& b, tr_ray
 }
 
 // All 64 lanes of a wave call this together (`in_range` = the lane owns ray i).
-template <int Q, bool STATS, bool COMPACT = false>
+template <int Q, bool STATS, bool COMPACT = false, bool UNI = false>
 __device__ __forceinline__ void process_ray(const tr_bvh_view& b, const RayFetch& rf,
                                             const QueryOut& out, int64_t i, bool in_range,
                                             tr_counters* cnt, const tr_ring ring) {
@@ -347,7 +347,7 @@ __device__ __forceinline__ void process_ray(const tr_bvh_view& b, const RayFetch
         top.tris = b.tris;
         top.cap = out.cap;
         if (b.num_tris >= 2) {
-            wave_traverse<Q, 0, STATS, COMPACT>(b, r, valid, res, top, cnt, ring);
+            wave_traverse<Q, 0, STATS, COMPACT, UNI>(b, r, valid, res, top, cnt, ring);
         } else {
             top.init();
             brute_one<Q>(b, r, valid, res);
@@ -355,7 +355,7 @@ __device__ __forceinline__ void process_ray(const tr_bvh_view& b, const RayFetch
         }
     } else {
         tr_topk<1> top;
-        if (b.num_tris >= 2) wave_traverse<Q, 1, STATS, COMPACT>(b, r, valid, res, top, cnt, ring);
+        if (b.num_tris >= 2) wave_traverse<Q, 1, STATS, COMPACT, UNI>(b, r, valid, res, top, cnt, ring);
         else brute_one<Q>(b, r, valid, res);
     }
     if (in_range) write_result<Q>(b, out, i, r, res);
@@ -536,7 +536,9 @@ __global__ __launch_bounds__(BS) void k_query_direct(tr_bvh_view b, RayFetch rf,
                    ((unsigned long long)(steal_lds[(threadIdx.x >> 6) * 384 + 1] & 0xffff) << 16);
 #endif
     } else {
-        process_ray<Q, STATS, COMPACT>(b, rf, out, i, i < rf.n, &cnt, ring);
+        // the plain shape is what large coherent batches get (small ones steal, incoherent ones
+        // stream): look for wave-uniform trips (tr_fused_step)
+        process_ray<Q, STATS, COMPACT, !STATS && BS == 128 && Q != TR_Q_LOCATION>(b, rf, out, i, i < rf.n, &cnt, ring);
     }
     if (cost && (threadIdx.x & 63) == 0) {
         // 100 MHz ticks.  A split block records twice what it would have cost in one piece (roughly):
