@@ -437,3 +437,25 @@ def test_queries_can_be_captured_in_a_hip_graph(device):
         exp = R.closest_raw((o + np.float32(0.01 * k)).astype(np.float32), d)
         assert_closest_bitexact(out, exp, f"graph replay {k}")
         assert np.array_equal(cnt.cpu().numpy(), R.intersects_count((o + np.float32(0.01 * k)).astype(np.float32), d))
+    # The learned launch order is per (handle, stream) and rewritten by every measuring launch: launches
+    # of ANOTHER batch size on the capture stream, between replays, leave an order written for another
+    # grid behind (and a replay leaves its own for them).  The kernels check the stamp of the order and
+    # fall back to the static launch order -- results never depend on it.
+    o2, d2 = W.pinhole_grid(384, 320, distance=2.5 * 1.12)
+    o2t, d2t = T(o2, device), T(d2, device)
+    exp2 = R.closest_raw(o2, d2)
+    cnt2 = R.intersects_count(o2, d2)
+    ot.copy_(T(o, device))
+    exp = R.closest_raw(o, d)
+    for k in range(4):
+        with torch.cuda.stream(side):
+            for _ in range(1 + k % 2):
+                got2 = r.intersects_closest(o2t, d2t)
+                c2 = r.intersects_count(o2t, d2t)
+        side.synchronize()
+        assert_closest_bitexact(got2, exp2, f"eager launch of another size after replay {k}")
+        assert np.array_equal(c2.cpu().numpy(), cnt2)
+        g.replay()
+        torch.cuda.synchronize()
+        assert_closest_bitexact(out, exp, f"graph replay after another batch size {k}")
+        assert np.array_equal(cnt.cpu().numpy(), R.intersects_count(o, d))

@@ -452,7 +452,7 @@ __device__ unsigned long long g_timeline[4 * TR_TIMELINE];
 template <int Q, bool STATS, bool COMPACT, int BS, int MODE = 0>
 __global__ __launch_bounds__(BS) void k_query_direct(tr_bvh_view b, RayFetch rf, QueryOut out,
                                                       int xcd_map, int scramble, int tile_w, int steal_min,
-                                                      const uint32_t* __restrict__ order,
+                                                      const uint32_t* __restrict__ order, int order_split,
                                                       uint32_t* __restrict__ cost,
                                                       unsigned long long* stats,
                                                       const int* __restrict__ sel) {
@@ -478,6 +478,20 @@ __global__ __launch_bounds__(BS) void k_query_direct(tr_bvh_view b, RayFetch rf,
     // affects speed.
     int64_t blk = blockIdx.x;
     int part = 0, parts_lg = 0;           // block splitting (k_sched_sort): this launch slot's share
+    int64_t nblk = gridDim.x;             // ray blocks of the launch (the grid may have extra slots)
+    if (order) {
+        // The order buffer belongs to the (handle, stream) and is rewritten by the sort behind every
+        // measuring launch: a launch replayed from a HIP graph -- or any launch, after such a replay
+        // -- may find an order that was written for ANOTHER grid.  The sort stamps what it wrote
+        // (block count, split blocks per XCD) behind the array; anything else is ignored and this
+        // launch runs in the static order (its extra slots have nothing to do).
+        nblk -= 8 * ((int64_t)order_split + 2 * (order_split >> 2));
+        const uint32_t* hdr = order + TR_SCHED_MAX;
+        if (hdr[0] != (uint32_t)nblk || hdr[1] != (uint32_t)order_split) {
+            order = nullptr;
+            if ((int64_t)blockIdx.x >= nblk) return;
+        }
+    }
     if (order) {
         // measured order: most expensive blocks first.  Bits 30-31 of an entry = lg of the number of
         // launch slots the block's rays were dealt to, bits 28-29 = this slot's part.
@@ -491,7 +505,7 @@ __global__ __launch_bounds__(BS) void k_query_direct(tr_bvh_view b, RayFetch rf,
         }
     } else if (xcd_map > 0) {
         const int64_t T = xcd_map, span = 8 * T;
-        const int64_t nfull = (int64_t)gridDim.x / span * span;   // blocks covered by whole spans
+        const int64_t nfull = nblk / span * span;                 // blocks covered by whole spans
         if (blk < nfull) {
             const int64_t x = blk & 7;                            // XCD label
             int64_t k = blk >> 3;                                 // index within the XCD
@@ -632,6 +646,7 @@ __global__ __launch_bounds__(1024) void k_sched_sort(uint32_t* __restrict__ cost
         }
         cost[i] = 0u;
     }
+    if (tid == 0) { order[TR_SCHED_MAX] = (uint32_t)nblocks; order[TR_SCHED_MAX + 1] = (uint32_t)split; }
 }
 
 template <int Q, bool STATS>
@@ -1085,8 +1100,9 @@ void sched_acquire(const tr_bvh* bvh, const tr_options& opt, hipStream_t stream,
     for (int k = 0; k < TR_SCHED_SLOTS && !slot; k++)
         if (!mb->sched[k].used) {
             uint32_t* buf = nullptr;
-            if (hipMalloc((void**)&buf, sizeof(uint32_t) * 2 * TR_SCHED_MAX) != hipSuccess) { (void)hipGetLastError(); break; }
-            if (hipMemsetAsync(buf, 0, sizeof(uint32_t) * 2 * TR_SCHED_MAX, stream) != hipSuccess) { (void)hipFree(buf); break; }
+            // cost[TR_SCHED_MAX] | order[TR_SCHED_MAX] | stamp of the order (block count, split blocks)
+            if (hipMalloc((void**)&buf, sizeof(uint32_t) * (2 * TR_SCHED_MAX + 4)) != hipSuccess) { (void)hipGetLastError(); break; }
+            if (hipMemsetAsync(buf, 0, sizeof(uint32_t) * (2 * TR_SCHED_MAX + 4), stream) != hipSuccess) { (void)hipFree(buf); break; }
             mb->sched[k].used = true; mb->sched[k].stream = stream; mb->sched[k].cls = cls; mb->sched[k].buf = buf; mb->sched[k].nblocks = 0;
             slot = &mb->sched[k];
         }
@@ -1275,7 +1291,7 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
         }
 #define TR_LAUNCH_DIRECT(C, B)                                                                          \
     hipLaunchKernelGGL((k_query_direct<Q, STATS, C, B>), dim3((unsigned)nslots), dim3(B), 0, stream, \
-                       view, rf, out, xc, scramble, tile_w, steal_min, order, cost, d_stats, sel)
+                       view, rf, out, xc, scramble, tile_w, steal_min, order, (int)split, cost, d_stats, sel)
         static const bool debug_launch = getenv("TRIRO_DEBUG_LAUNCH") != nullptr;
         if (debug_launch)
             fprintf(stderr, "[triro] query %d: rays %lld blocks %lld slots %lld tile 0x%x split %lld order %d cost %d steal %d unordered %d compact %d\n",
@@ -1286,7 +1302,7 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
                 const int leaf_min = opt.leaf_vote;
 #define TR_LAUNCH_UNORD(C, B)                                                                            \
     hipLaunchKernelGGL((k_query_direct<Q, STATS, C, B, 2>), dim3((unsigned)nslots), dim3(B), 0, stream, \
-                       view, rf, out, xc, scramble, tile_w, leaf_min, order, cost, d_stats, sel)
+                       view, rf, out, xc, scramble, tile_w, leaf_min, order, (int)split, cost, d_stats, sel)
                 if (bs == 64) { if (compact) TR_LAUNCH_UNORD(true, 64); else TR_LAUNCH_UNORD(false, 64); }
                 else if (bs == 128) { if (compact) TR_LAUNCH_UNORD(true, 128); else TR_LAUNCH_UNORD(false, 128); }
                 else { if (compact) TR_LAUNCH_UNORD(true, 256); else TR_LAUNCH_UNORD(false, 256); }
@@ -1296,10 +1312,10 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
         if (steal) {
             if (compact)
                 hipLaunchKernelGGL((k_query_direct<Q, false, true, 128, 1>), dim3((unsigned)nslots), dim3(128), 0, stream,
-                                   view, rf, out, xc, scramble, tile_w, steal_arg, order, cost, d_stats, sel);
+                                   view, rf, out, xc, scramble, tile_w, steal_arg, order, (int)split, cost, d_stats, sel);
             else
                 hipLaunchKernelGGL((k_query_direct<Q, false, false, 128, 1>), dim3((unsigned)nslots), dim3(128), 0, stream,
-                                   view, rf, out, xc, scramble, tile_w, steal_arg, order, cost, d_stats, sel);
+                                   view, rf, out, xc, scramble, tile_w, steal_arg, order, (int)split, cost, d_stats, sel);
         } else
         if (bs == 64) { if (compact) TR_LAUNCH_DIRECT(true, 64); else TR_LAUNCH_DIRECT(false, 64); }
         else if (bs == 128) { if (compact) TR_LAUNCH_DIRECT(true, 128); else TR_LAUNCH_DIRECT(false, 128); }
