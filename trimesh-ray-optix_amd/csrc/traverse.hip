@@ -1084,6 +1084,36 @@ int enter_bvh_device(const tr_bvh* bvh, const tr_rays* rays, tr_device_guard* gu
 // buffers, so overlapping launches cannot see a half-written order.  Returns cost != NULL when
 // this launch should record block costs (and be followed by k_sched_sort), order != NULL when a
 // measured order exists for this block count.
+// the slot of (stream, class) of this handle, created on first use; sched_mutex must be held.
+// buf = cost[TR_SCHED_MAX] | order[TR_SCHED_MAX] | stamp of the order (block count, split blocks,
+// 2 spare words) | 8 words of per-stream launch scratch (coherence-probe result, work counter)
+constexpr size_t TR_SCHED_WORDS = 2 * (size_t)TR_SCHED_MAX + 4 + 8;
+tr_sched_slot* sched_slot(tr_bvh* mb, hipStream_t stream, int cls) {
+    for (int k = 0; k < TR_SCHED_SLOTS; k++)
+        if (mb->sched[k].used && mb->sched[k].stream == stream && mb->sched[k].cls == cls) return &mb->sched[k];
+    for (int k = 0; k < TR_SCHED_SLOTS; k++)
+        if (!mb->sched[k].used) {
+            uint32_t* buf = nullptr;
+            if (hipMalloc((void**)&buf, sizeof(uint32_t) * TR_SCHED_WORDS) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+            if (hipMemsetAsync(buf, 0, sizeof(uint32_t) * TR_SCHED_WORDS, stream) != hipSuccess) { (void)hipFree(buf); return nullptr; }
+            mb->sched[k].used = true; mb->sched[k].stream = stream; mb->sched[k].cls = cls; mb->sched[k].buf = buf; mb->sched[k].nblocks = 0;
+            return &mb->sched[k];
+        }
+    return nullptr;
+}
+
+// Eight words that belong to (handle, stream): the coherence probe's result and the streaming
+// launch's work counter.  Launches of one stream are ordered, so the words are never shared by two
+// launches in flight -- also not when one of them is a graph replay (a slot of the per-device ring,
+// the fallback when the handle has no free slot, is reused after 512 launches on ANY stream).
+uint32_t* stream_scratch(const tr_bvh* bvh, hipStream_t stream) {
+    tr_bvh* mb = const_cast<tr_bvh*>(bvh);
+    if (!mb->sched_mutex) return nullptr;
+    std::lock_guard<std::mutex> lock(*mb->sched_mutex);
+    tr_sched_slot* slot = sched_slot(mb, stream, 0);
+    return slot ? slot->buf + 2 * (size_t)TR_SCHED_MAX + 4 : nullptr;
+}
+
 void sched_acquire(const tr_bvh* bvh, const tr_options& opt, hipStream_t stream, int64_t nblocks,
                    int64_t split, const uint32_t** order, uint32_t** cost) {
     *order = nullptr;
@@ -1093,19 +1123,8 @@ void sched_acquire(const tr_bvh* bvh, const tr_options& opt, hipStream_t stream,
     // launches with split blocks (the stealing shapes) and launches without learn separate orders:
     // their costs differ, and a plain shape would only skip the extra slots of a split order
     const int cls = split > 0;
-    tr_sched_slot* slot = nullptr;
     std::lock_guard<std::mutex> lock(*mb->sched_mutex);
-    for (int k = 0; k < TR_SCHED_SLOTS && !slot; k++)
-        if (mb->sched[k].used && mb->sched[k].stream == stream && mb->sched[k].cls == cls) slot = &mb->sched[k];
-    for (int k = 0; k < TR_SCHED_SLOTS && !slot; k++)
-        if (!mb->sched[k].used) {
-            uint32_t* buf = nullptr;
-            // cost[TR_SCHED_MAX] | order[TR_SCHED_MAX] | stamp of the order (block count, split blocks)
-            if (hipMalloc((void**)&buf, sizeof(uint32_t) * (2 * TR_SCHED_MAX + 4)) != hipSuccess) { (void)hipGetLastError(); break; }
-            if (hipMemsetAsync(buf, 0, sizeof(uint32_t) * (2 * TR_SCHED_MAX + 4), stream) != hipSuccess) { (void)hipFree(buf); break; }
-            mb->sched[k].used = true; mb->sched[k].stream = stream; mb->sched[k].cls = cls; mb->sched[k].buf = buf; mb->sched[k].nblocks = 0;
-            slot = &mb->sched[k];
-        }
+    tr_sched_slot* slot = sched_slot(mb, stream, cls);
     if (!slot) return;
     if (slot->nblocks == nblocks && slot->split == split) {
         *order = slot->buf + TR_SCHED_MAX;
@@ -1170,10 +1189,14 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
             const bool auto_stream = opt.stream == 1 && rf.n >= ((int64_t)1 << 21) && bvh->num_tris >= 2;
             if (opt.stream == 2 || auto_stream) {
                 unsigned long long* d_work = nullptr;
-                if (auto_stream) {
+                unsigned long long* scratch = reinterpret_cast<unsigned long long*>(stream_scratch(bvh, stream));
+                if (!scratch) {
                     unsigned slot = __atomic_fetch_add(&st->next_counter, 1u, __ATOMIC_RELAXED) % (TR_NUM_COUNTERS / 8);
-                    int* d_sel = reinterpret_cast<int*>(reinterpret_cast<unsigned long long*>(st->counters) + 8 * slot);
-                    d_work = reinterpret_cast<unsigned long long*>(st->counters) + 8 * slot + 1;   // zeroed by the probe
+                    scratch = reinterpret_cast<unsigned long long*>(st->counters) + 8 * slot;
+                }
+                if (auto_stream) {
+                    int* d_sel = reinterpret_cast<int*>(scratch);
+                    d_work = scratch + 1;                                    // zeroed by the probe
                     float diag2 = 0.f;
                     for (int k = 0; k < 3; k++) { const float e = bvh->aabb_max[k] - bvh->aabb_min[k]; diag2 += e * e; }
                     hipLaunchKernelGGL(k_probe_coherence, dim3(1), dim3(256), 0, stream, rf, sqrtf(diag2), d_sel);
@@ -1190,8 +1213,7 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
                 unsigned long long* work = nullptr;
                 if (opt.stream_dynamic) {
                     if (d_work == nullptr) {
-                        unsigned slot = __atomic_fetch_add(&st->next_counter, 1u, __ATOMIC_RELAXED) % (TR_NUM_COUNTERS / 8);
-                        d_work = reinterpret_cast<unsigned long long*>(st->counters) + 8 * slot + 1;
+                        d_work = scratch + 1;
                         TR_HIP_TRY(hipMemsetAsync(d_work, 0, sizeof(unsigned long long), stream));
                     }
                     work = d_work;
