@@ -884,11 +884,17 @@ __global__ __launch_bounds__(256) void k_fill_list(tr_bvh_view b, RayFetch rf, i
     const int64_t i = g / cap;
     const int32_t k = (int32_t)(g - i * cap);
     if (i >= rf.n) return;
+    // everything that only depends on (i, k) is requested before the first use, so that the kernel
+    // is two dependent memory round trips deep (entry -> triangle) instead of four
+    // (count -> entry -> triangle -> offset); slots of unused entries are not dereferenced
+    const tr_hit_entry* e = entries + i * cap;
     const int32_t c = count[i];
+    const tr_hit_entry me = e[k];
+    const int64_t off = offsets[i];
+    float o[3], d[3];
+    fetch_ray(rf, i, o, d);
     const int32_t ns = c < cap ? c : cap;
     if (k >= ns) return;
-    const tr_hit_entry* e = entries + i * cap;
-    const tr_hit_entry me = e[k];
     tr_counters* nc = nullptr;
     const tr_tri t = tr_load_tri<false>(b, me.slot, nc);
     int32_t rank = 0;
@@ -897,15 +903,13 @@ __global__ __launch_bounds__(256) void k_fill_list(tr_bvh_view b, RayFetch rf, i
         const tr_hit_entry ej = e[j];
         if (ej.t_key < me.t_key || (ej.t_key == me.t_key && b.tris[ej.slot].face < t.face)) rank++;
     }
-    float o[3], d[3];
-    fetch_ray(rf, i, o, d);
     tr_ray r;
     tr_ray_setup(r, o[0], o[1], o[2], d[0], d[1], d[2]);
     tr_hit h;
     tr_tri_hit(r, t.ax, t.ay, t.az, t.bx, t.by, t.bz, t.cx, t.cy, t.cz, h);
     float l3[3], uv[2];
     tr_hit_outputs(h, t.ax, t.ay, t.az, t.bx, t.by, t.bz, t.cx, t.cy, t.cz, l3, uv);
-    const int64_t w = offsets[i] + rank;
+    const int64_t w = off + rank;
     loc[3 * w] = l3[0]; loc[3 * w + 1] = l3[1]; loc[3 * w + 2] = l3[2];
     ray_idx[w] = (int32_t)(i + ray_base);
     tri_idx[w] = t.face;
