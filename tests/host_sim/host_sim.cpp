@@ -253,10 +253,17 @@ static void run_query(const tr_bvh_view& v, const float* o, const float* d, int6
             if (valid) {
                 if ((g_fused & 3) == 1) {
                     tr_state_t<uint64_t> fs; tr_state_init(fs);
-                    while (!tr_done(fs)) tr_fused_step<Q, 1, true, false, uint64_t>(v, r, fs, res, top, &cnt, ring);
+                    // as the kernels run it: trips with and without the leaf block alternate
+                    while (!tr_done(fs)) {
+                        tr_fused_step<Q, 1, true, false, uint64_t, false, true>(v, r, fs, res, top, &cnt, ring);
+                        if (!tr_done(fs)) tr_fused_step<Q, 1, true, false, uint64_t, false, false>(v, r, fs, res, top, &cnt, ring);
+                    }
                 } else {
                     tr_state_t<uint32_t> fs; tr_state_init(fs);
-                    while (!tr_done(fs)) tr_fused_step<Q, 1, true, true, uint32_t>(v, r, fs, res, top, &cnt, ring);
+                    while (!tr_done(fs)) {
+                        tr_fused_step<Q, 1, true, true, uint32_t, false, true>(v, r, fs, res, top, &cnt, ring);
+                        if (!tr_done(fs)) tr_fused_step<Q, 1, true, true, uint32_t, false, false>(v, r, fs, res, top, &cnt, ring);
+                    }
                 }
             }
         } else if (v.num_tris >= 2) tr_traverse<Q, 1, true>(v, r, valid, res, top, &cnt, ring);

@@ -445,7 +445,8 @@ TR_HD void tr_leaf_step(const tr_bvh_view& b, const tr_ray& r, tr_state& st, tr_
 #endif
 // everything of a trip after the node record has arrived (n0..n3: in vector registers, or -- on
 // trips where the whole wave visits the same node -- in scalar registers)
-template <int Q, int K, bool STATS, bool COMPACT, typename W>
+// TEST = false: a trip WITHOUT the leaf block (tr_fused_step)
+template <int Q, int K, bool STATS, bool COMPACT, typename W, bool TEST = true>
 TR_HD void tr_fused_body(const tr_bvh_view& b, const tr_ray& r, tr_state_t<W>& st, tr_result& res,
                          tr_topk<K>& top, tr_counters* cnt, const tr_ring ring, const bool has_node,
                          const tr_f4& n0, const tr_f4& n1, const tr_f4& n2, const tr_f4& n3) {
@@ -453,7 +454,7 @@ TR_HD void tr_fused_body(const tr_bvh_view& b, const tr_ray& r, tr_state_t<W>& s
     if (STATS && has_node) cnt->nodes++;
     bool fin = false;
     const int32_t q0 = st.p0;
-    if (TR_WAVE_ANY(q0 >= 0)) {
+    if (TEST && TR_WAVE_ANY(q0 >= 0)) {
         tr_counters* nc = nullptr;
         const tr_tri t0 = tr_load_tri<false, COMPACT>(b, q0 >= 0 ? q0 : 0, nc);
         // a queued leaf whose box entry lies beyond the best hit found meanwhile cannot win
@@ -478,7 +479,22 @@ TR_HD void tr_fused_body(const tr_bvh_view& b, const tr_ray& r, tr_state_t<W>& s
     // (no shift-then-push: every move is a v_cndmask).  The head (p0) was consumed above; b =
     // old p1 and c = old p2 are carried.  When c is valid the node waited (go is false, no new
     // leaves) and c takes the place of "leaf of child 1" in the formulas below.
-    {
+    if (!TEST) {
+        // the head was NOT consumed; a lane that visits its node on such a trip holds at most one
+        // queued leaf (p0), so FIFO = (p0, new leaf of child 0, new leaf of child 1) still fits.
+        // Lanes that do not visit keep their FIFO as it is.
+        const bool l0 = h0 && c0 < 0, l1 = h1 && c1 < 0;
+        h0 = h0 && c0 >= 0;
+        h1 = h1 && c1 >= 0;
+        if (go) {
+            const bool hb = st.p0 >= 0, two = l0 && l1;
+            const int32_t xi = l0 ? ~c0 : (l1 ? ~c1 : -1);
+            const float xe = l0 ? tn0 : tn1, xx = l0 ? tf0 : tf1;
+            st.p2 = (hb && two) ? ~c1 : -1;   st.p2n = tn1;   st.p2f = tf1;
+            st.p1 = hb ? xi : (two ? ~c1 : -1);   st.p1n = hb ? xe : tn1;   st.p1f = hb ? xx : tf1;
+            st.p0 = hb ? st.p0 : xi;   st.p0n = hb ? st.p0n : xe;   st.p0f = hb ? st.p0f : xx;
+        }
+    } else {
         const bool l0 = h0 && c0 < 0;
         const bool wait = st.p2 >= 0;
         const bool l1 = (h1 && c1 < 0) || wait;
@@ -540,12 +556,20 @@ TR_HD void tr_fused_body(const tr_bvh_view& b, const tr_ray& r, tr_state_t<W>& s
 // 16.7 M: -5 %), a loss where the texture path is not the busiest unit or uniform trips are rare
 // (1 M rays +-0, 262 k rays +5 %, coarse meshes +3 %, incoherent batches +2 %): the test costs two
 // ballots and a readlane on every trip.
-template <int Q, int K, bool STATS, bool COMPACT = false, typename W = uint64_t, bool UNI = false>
+//
+// TEST: this trip has a leaf block.  The leaf block -- three triangle loads, Moller-Trumbore, a
+// division: 3 of the trip's 7 vector-memory instructions and about half of its VALU instructions --
+// is executed by the whole wave whenever ANY lane has a queued leaf, i.e. on nearly every trip, while
+// only ~8 % of the lane-trips have one.  The callers therefore alternate trips with and without it:
+// on a trip without, a lane visits its node if it holds at most one queued leaf (so that two new
+// ones still fit).  A leaf is tested at most one trip later than before; same tests, same results.
+template <int Q, int K, bool STATS, bool COMPACT = false, typename W = uint64_t, bool UNI = false, bool TEST = true>
 TR_HD void tr_fused_step(const tr_bvh_view& b, const tr_ray& r, tr_state_t<W>& st, tr_result& res,
                          tr_topk<K>& top, tr_counters* cnt, const tr_ring ring) {
     // one leaf test per trip: the head of the lane's FIFO (p0, p1, p2).  The node is visited
     // unless the FIFO is full (it then waits one trip: no fetch, no new leaves).
-    const bool has_node = st.node >= 0 && st.p2 < 0;
+    const int32_t room = TEST ? st.p2 : st.p1;     // must be empty (-1) for the node to be visited
+    const bool has_node = st.node >= 0 && room < 0;
 #if defined(__HIP_DEVICE_COMPILE__)
     // Wave-uniform trips: 36-44 % of the node visits of an image-shaped batch happen on trips where
     // every visiting lane is at the SAME node (the top of the tree under an 8x8 pixel tile).  The
@@ -561,7 +585,7 @@ TR_HD void tr_fused_step(const tr_bvh_view& b, const tr_ray& r, tr_state_t<W>& s
                 typedef const __attribute__((address_space(4))) tr_f4* tr_cf4p;
                 const tr_cf4p sp = (tr_cf4p)(unsigned long long)tr_node_ptr<COMPACT>(b, nu);
                 const tr_f4 n0 = sp[0], n1 = sp[1], n2 = sp[2], n3 = sp[3];
-                tr_fused_body<Q, K, STATS, COMPACT, W>(b, r, st, res, top, cnt, ring, has_node, n0, n1, n2, n3);
+                tr_fused_body<Q, K, STATS, COMPACT, W, TEST>(b, r, st, res, top, cnt, ring, has_node, n0, n1, n2, n3);
                 return;
             }
         }
@@ -569,10 +593,10 @@ TR_HD void tr_fused_step(const tr_bvh_view& b, const tr_ray& r, tr_state_t<W>& s
 #endif
     // node index or 0, from the sign bits (a select here loses the SGPR-base + 32-bit-offset
     // addressing of the four node loads)
-    const int32_t nidx = st.node & ~(st.node >> 31) & (st.p2 >> 31);
+    const int32_t nidx = st.node & ~(st.node >> 31) & (room >> 31);
     const tr_f4* np = tr_node_ptr<COMPACT>(b, nidx);
     const tr_f4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
-    tr_fused_body<Q, K, STATS, COMPACT, W>(b, r, st, res, top, cnt, ring, has_node, n0, n1, n2, n3);
+    tr_fused_body<Q, K, STATS, COMPACT, W, TEST>(b, r, st, res, top, cnt, ring, has_node, n0, n1, n2, n3);
 }
 
 // Slab intervals of both children of a 32-byte grid node held in two 16-byte registers:

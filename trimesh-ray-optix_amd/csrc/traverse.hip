@@ -120,6 +120,9 @@ template <> struct tr_word<true> { typedef uint32_t T; };
 
 // COMPACT = the hierarchy is at most 32 levels high and both arrays are below 4 GiB: 32-bit
 // trail/owned words and SGPR-base + 32-bit-offset loads (chosen on the host per BVH).
+#ifndef TR_ALTERNATE
+#define TR_ALTERNATE 1        // every second trip runs without the leaf block (tr_fused_step<..., TEST>)
+#endif
 template <int Q, int K, bool STATS, bool COMPACT = false, bool UNI = false>
 __device__ __forceinline__ void wave_traverse(const tr_bvh_view& b, const tr_ray& r, bool go,
                                               tr_result& res, tr_topk<K>& top, tr_counters* cnt,
@@ -132,8 +135,13 @@ __device__ __forceinline__ void wave_traverse(const tr_bvh_view& b, const tr_ray
     tr_state_init(fs);
     if (!go) fs.node = -1;
     while (!tr_done(fs)) {
-        tr_fused_step<Q, K, STATS, COMPACT, W, UNI>(b, r, fs, res, top, cnt, ring);
+        tr_fused_step<Q, K, STATS, COMPACT, W, UNI, true>(b, r, fs, res, top, cnt, ring);
         TR_CONVERGE();
+#pragma unroll
+        for (int a = 0; a < TR_ALTERNATE; a++) {
+            tr_fused_step<Q, K, STATS, COMPACT, W, UNI, false>(b, r, fs, res, top, cnt, ring);   // no-op for a finished lane
+            TR_CONVERGE();
+        }
     }
 }
 
@@ -216,11 +224,23 @@ __device__ __forceinline__ bool wave_traverse_steal(const tr_bvh_view& b, tr_ray
         // TR_STEAL_EVERY+1 plain trips (idle lanes sit them out under the exec mask: a trip takes
         // longer the more lanes take part in its loads), then one look at the wave
 #pragma unroll 1
+#if TR_ALTERNATE
+        for (uint32_t k = 0; k <= TR_STEAL_EVERY; k += 1 + TR_ALTERNATE) {
+            if (!tr_done(fs)) tr_fused_step<Q, 1, STATS, COMPACT, W, false, true>(b, r, fs, res, top, cnt, ring);
+            TR_CONVERGE();
+#pragma unroll
+            for (int a = 0; a < TR_ALTERNATE; a++) {
+                if (!tr_done(fs)) tr_fused_step<Q, 1, STATS, COMPACT, W, false, false>(b, r, fs, res, top, cnt, ring);
+                TR_CONVERGE();
+            }
+        }
+#else
         for (uint32_t k = 0; k <= TR_STEAL_EVERY; k++) {
             if (!tr_done(fs)) tr_fused_step<Q, 1, STATS, COMPACT, W>(b, r, fs, res, top, cnt, ring);
             TR_CONVERGE();
         }
-        trip += TR_STEAL_EVERY + 1u;
+#endif
+        trip += TR_ALTERNATE ? (TR_STEAL_EVERY / (1u + TR_ALTERNATE) + 1u) * (1u + TR_ALTERNATE) : TR_STEAL_EVERY + 1u;
         if (TR_STEAL_SHARE && split) {
             // Rays that are traversed by several lanes share what they have found: a lane's bound is
             // the best hit of ANY lane working on its ray (closest / first), and an any-hit ray ends
@@ -802,10 +822,18 @@ __global__ __launch_bounds__(BS) void k_query_stream(tr_bvh_view b, RayFetch rf,
         int idle_now;
         do {
             if (busy) {
-                tr_fused_step<Q, 1, STATS, COMPACT, W>(b, r, fs, res, top, &cnt, ring);
+                tr_fused_step<Q, 1, STATS, COMPACT, W, false, true>(b, r, fs, res, top, &cnt, ring);
                 busy = !tr_done(fs);
             }
             TR_CONVERGE();
+#pragma unroll
+            for (int a = 0; a < TR_ALTERNATE; a++) {
+                if (busy) {
+                    tr_fused_step<Q, 1, STATS, COMPACT, W, false, false>(b, r, fs, res, top, &cnt, ring);
+                    busy = !tr_done(fs);
+                }
+                TR_CONVERGE();
+            }
             idle_now = __popcll(__ballot(!busy));
 #ifdef TR_TIMELINE
             tl_trips++;
