@@ -1274,7 +1274,8 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
         // 16.7 M rays) but they also pack the expensive silhouette rays into waves whose 64
         // lanes all stay active through hundreds of trips, each trip then gathering 64
         // distinct nodes: the critical path of a small launch gets longer (-25 % at 1 M rays).
-        // Hence tiles only from 4 M rays on (option tile: 0 never, 1 auto, 2 always).
+        // Hence, on their own, tiles only from 4 M rays on; below that together with block splitting
+        // (further down), which takes those waves apart (option tile: 0 never, 1 auto, 2 always).
         // Queries without distance pruning (count, location) have no such critical path -- every ray
         // of a tile costs about the same -- and take tiles at any size: C4 count 1.12 -> 0.93 ms,
         // location 1.38 -> 1.18 ms at 1 M rays (profiles/r02_sweep_c4.jsonl).
@@ -1314,8 +1315,8 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
         // tiles everything but ~100 waves of the headline image is done after 215 us of 320), and those
         // are waves whose 64 rays ALL graze the surface, so stealing inside the wave has no idle lane to
         // give work to: half the rays per wave leaves 32 lanes that take subtrees from the first trips on
-        // -- which is what makes 8x8 tiles (14 % fewer instructions: the launch is bound by VALU issue)
-        // affordable below 4 M rays.  The first quarter of the split blocks gets four slots (C4 closest
+        // -- which is what makes 8x8 tiles (14 % fewer wave-trips: the launch is bound by VALU issue and
+        // by gather instructions, both per trip) affordable below 4 M rays.  The first quarter of the split blocks gets four slots (C4 closest
         // 0.221 -> 0.2015 ms).  Launch shapes that steal only; the others keep their own learned order
         // (sched_acquire).  Speed only.  split: 0 off, 1 auto, N >= 2: nblocks >> N.
         const bool small_tris = rf.n >= 8 * bvh->num_tris;   // triangles of many pixels: flat tiles, balanced waves
