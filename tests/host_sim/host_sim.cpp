@@ -330,6 +330,26 @@ void sim_steps(const void* nodes, const void* links, const void* tris, int64_t n
     }
 }
 
+#ifdef TR_COUNT_BOTTOM
+// experiment build (scripts/exp_pair_leaves.py): additionally the visits of nodes whose two children
+// are leaves and the number of their children that passed the box test, per ray
+void sim_steps_bottom(const void* nodes, const void* links, const void* tris, int64_t nf, const float* o,
+                      const float* d, int64_t n, int32_t* node_visits, int32_t* tri_tests,
+                      int32_t* bottom, int32_t* bottom_hits) {
+    tr_bvh_view v = view_of((const tr_node*)nodes, (const tr_link*)links, (const tr_tri*)tris, nf);
+    for (int64_t i = 0; i < n; i++) {
+        tr_ray r;
+        bool valid = tr_ray_setup(r, o[3 * i], o[3 * i + 1], o[3 * i + 2], d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+        tr_result res; tr_topk<1> top; tr_counters cnt = {};
+        int32_t ring_mem[TR_RING];
+        tr_ring ring = {ring_mem, 1};
+        tr_traverse<TR_Q_CLOSEST, 1, true>(v, r, valid, res, top, &cnt, ring);
+        node_visits[i] = (int32_t)cnt.nodes; tri_tests[i] = (int32_t)cnt.tris;
+        bottom[i] = (int32_t)cnt.bottom; bottom_hits[i] = (int32_t)cnt.bottom_hits;
+    }
+}
+#endif
+
 // multi-hit: counts[i] hits (uncapped), first min(count,cap) nearest written at i*cap
 void sim_location(const void* nodes, const void* links, const void* tris, int64_t nf, const float* o,
                   const float* d, int64_t n, int32_t cap, int32_t* count, int32_t* tri_out, float* t_out) {

@@ -146,6 +146,10 @@ enum tr_query { TR_Q_ANY = 0, TR_Q_FIRST = 1, TR_Q_CLOSEST = 2, TR_Q_COUNT = 3, 
 
 struct tr_counters {
     uint32_t nodes, tris, climbs;
+#ifdef TR_COUNT_BOTTOM
+    uint32_t bottom, bottom_hits;   // host experiment (scripts/exp_pair_leaves.py): visits of nodes whose
+                                    // children are both leaves, and how many of those passed the box test
+#endif
 };
 
 // sorted list of the K nearest hits (by (t, face)); static indexing only
@@ -372,6 +376,9 @@ TR_HD void tr_node_step(const tr_bvh_view& b, const tr_ray& r, tr_state& st, con
     const float lim = ordered ? res.best_t : TR_TMAX;
     bool h0 = tr_slab_hit(tn0, tf0, lim);
     bool h1 = tr_slab_hit(tn1, tf1, lim);
+#ifdef TR_COUNT_BOTTOM
+    if (STATS && c0 < 0 && c1 < 0) { cnt->bottom++; cnt->bottom_hits += (h0 ? 1u : 0u) + (h1 ? 1u : 0u); }
+#endif
     // leaf children are queued for the leaf phase
     if (h0 && c0 < 0) { st.p0 = ~c0; st.p0n = tn0; st.p0f = tf0; h0 = false; }
     if (h1 && c1 < 0) { st.p1 = ~c1; st.p1n = tn1; st.p1f = tf1; h1 = false; }
