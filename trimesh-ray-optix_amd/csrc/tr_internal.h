@@ -31,7 +31,7 @@ int tr_fail(int code, const std::string& msg);
 // adaptive launch order: per (handle, stream) measured block costs and the order derived from
 // them.  buf = cost[TR_SCHED_MAX] | order[TR_SCHED_MAX]
 constexpr int TR_SCHED_MAX = 131072;  // blocks (x256 rays) up to which the order is learned
-constexpr int TR_SCHED_SLOTS = 8;
+constexpr int TR_SCHED_SLOTS = 16;   // (stream, class) pairs per handle: 8 streams x {plain, split} orders
 struct tr_sched_slot {
     hipStream_t stream = nullptr;
     int cls = 0;            // 1: orders with split blocks (launch shapes that steal), 0: plain
