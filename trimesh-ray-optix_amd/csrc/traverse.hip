@@ -115,22 +115,24 @@ __device__ __forceinline__ void brute_one(const tr_bvh_view& b, const tr_ray& r,
 // Wave-level traversal of one ray per lane with the fused, software-pipelined trip
 // (tr_fused_step): every lane advances on every trip; results do not depend on the schedule
 // (the hit predicate is order-independent, tr_math.h).
-template <bool C> struct tr_word { typedef uint64_t T; };
-template <> struct tr_word<true> { typedef uint32_t T; };
+template <bool C, bool DEEP = false> struct tr_word { typedef uint64_t T; };
+template <> struct tr_word<true, false> { typedef uint32_t T; };
 
-// COMPACT = the hierarchy is at most 32 levels high and both arrays are below 4 GiB: 32-bit
-// trail/owned words and SGPR-base + 32-bit-offset loads (chosen on the host per BVH).
+// COMPACT = both arrays are below 4 GiB: SGPR-base + 32-bit-offset loads; and, unless DEEP (the
+// hierarchy is more than 32 levels high), 32-bit trail / owned words.  Chosen on the host per BVH.
+// COMPACT + DEEP is what meshes of a few million triangles and more get (5.2 M-triangle sphere: 34
+// levels): 80 instead of 82 VGPRs in the stealing closest kernel, i.e. 6 instead of 5 waves/SIMD.
 #ifndef TR_ALTERNATE
 #define TR_ALTERNATE 1        // every second trip runs without the leaf block (tr_fused_step<..., TEST>)
 #endif
-template <int Q, int K, bool STATS, bool COMPACT = false, bool UNI = false>
+template <int Q, int K, bool STATS, bool COMPACT = false, bool UNI = false, bool DEEP = false>
 __device__ __forceinline__ void wave_traverse(const tr_bvh_view& b, const tr_ray& r, bool go,
                                               tr_result& res, tr_topk<K>& top, tr_counters* cnt,
                                               const tr_ring ring) {
     tr_result_init(res);
     if (Q == TR_Q_LOCATION) top.init();
     // fused, software-pipelined schedule: every lane advances on every trip
-    typedef typename tr_word<COMPACT>::T W;
+    typedef typename tr_word<COMPACT, DEEP>::T W;
     tr_state_t<W> fs;
     tr_state_init(fs);
     if (!go) fs.node = -1;
@@ -170,12 +172,12 @@ __device__ __forceinline__ int lane_rank(unsigned long long mask) {   // set bit
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
 
-template <int Q, bool STATS, bool COMPACT>
+template <int Q, bool STATS, bool COMPACT, bool DEEP = false>
 __device__ __forceinline__ bool wave_traverse_steal(const tr_bvh_view& b, tr_ray& r, bool go,
                                                     tr_result& res, tr_counters* cnt,
                                                     const tr_ring ring, int32_t* wl, int lane,
                                                     uint32_t steal_min) {
-    typedef typename tr_word<COMPACT>::T W;
+    typedef typename tr_word<COMPACT, DEEP>::T W;
     tr_result_init(res);
     tr_topk<1> top;
     tr_state_t<W> fs;
@@ -351,7 +353,7 @@ __device__ __forceinline__ bool wave_traverse_steal(const tr_bvh_view& b, tr_ray
 }
 
 // All 64 lanes of a wave call this together (`in_range` = the lane owns ray i).
-template <int Q, bool STATS, bool COMPACT = false, bool UNI = false>
+template <int Q, bool STATS, bool COMPACT = false, bool UNI = false, bool DEEP = false>
 __device__ __forceinline__ void process_ray(const tr_bvh_view& b, const RayFetch& rf,
                                             const QueryOut& out, int64_t i, bool in_range,
                                             tr_counters* cnt, const tr_ring ring) {
@@ -367,7 +369,7 @@ __device__ __forceinline__ void process_ray(const tr_bvh_view& b, const RayFetch
         top.tris = b.tris;
         top.cap = out.cap;
         if (b.num_tris >= 2) {
-            wave_traverse<Q, 0, STATS, COMPACT, UNI>(b, r, valid, res, top, cnt, ring);
+            wave_traverse<Q, 0, STATS, COMPACT, UNI, DEEP>(b, r, valid, res, top, cnt, ring);
         } else {
             top.init();
             brute_one<Q>(b, r, valid, res);
@@ -375,13 +377,13 @@ __device__ __forceinline__ void process_ray(const tr_bvh_view& b, const RayFetch
         }
     } else {
         tr_topk<1> top;
-        if (b.num_tris >= 2) wave_traverse<Q, 1, STATS, COMPACT, UNI>(b, r, valid, res, top, cnt, ring);
+        if (b.num_tris >= 2) wave_traverse<Q, 1, STATS, COMPACT, UNI, DEEP>(b, r, valid, res, top, cnt, ring);
         else brute_one<Q>(b, r, valid, res);
     }
     if (in_range) write_result<Q>(b, out, i, r, res);
 }
 
-template <int Q, bool STATS, bool COMPACT>
+template <int Q, bool STATS, bool COMPACT, bool DEEP = false>
 __device__ __forceinline__ void process_ray_steal(const tr_bvh_view& b, const RayFetch& rf,
                                                   const QueryOut& out, int64_t i, bool in_range,
                                                   tr_counters* cnt, const tr_ring ring, int32_t* wl,
@@ -392,7 +394,7 @@ __device__ __forceinline__ void process_ray_steal(const tr_bvh_view& b, const Ra
     const bool valid = tr_ray_setup(r, o[0], o[1], o[2], d[0], d[1], d[2]) && in_range;
     tr_result res;
     bool split = false;
-    if (b.num_tris >= 2) split = wave_traverse_steal<Q, STATS, COMPACT>(b, r, valid, res, cnt, ring, wl, (int)(threadIdx.x & 63), steal_min);
+    if (b.num_tris >= 2) split = wave_traverse_steal<Q, STATS, COMPACT, DEEP>(b, r, valid, res, cnt, ring, wl, (int)(threadIdx.x & 63), steal_min);
     else brute_one<Q>(b, r, valid, res);   // no hierarchy below two triangles
     if (split && in_range) {   // this lane may hold another lane's ray now: take its own again
         fetch_ray(rf, i, o, d);
@@ -405,11 +407,11 @@ __device__ __forceinline__ void process_ray_steal(const tr_bvh_view& b, const Ra
 // Wave-level vote per trip: the leaf phase (three triangle loads + the full predicate) runs only
 // when a lane's queue is nearly full ("parked": it could not take both children of its node),
 // when at least `leaf_min` lanes have something queued, or when no lane has a node left.
-template <int Q, int K, bool STATS, bool COMPACT>
+template <int Q, int K, bool STATS, bool COMPACT, bool DEEP = false>
 __device__ __forceinline__ void wave_traverse_unordered(const tr_bvh_view& b, const tr_ray& r, bool go,
                                                         tr_result& res, tr_topk<K>& top, tr_counters* cnt,
                                                         const tr_ring ring, const tr_leafq lq, int leaf_min) {
-    typedef typename tr_word<COMPACT>::T W;
+    typedef typename tr_word<COMPACT, DEEP>::T W;
     tr_result_init(res);
     if (Q == TR_Q_LOCATION) top.init();
     tr_ustate_t<W> st;
@@ -426,7 +428,7 @@ __device__ __forceinline__ void wave_traverse_unordered(const tr_bvh_view& b, co
     }
 }
 
-template <int Q, bool STATS, bool COMPACT>
+template <int Q, bool STATS, bool COMPACT, bool DEEP = false>
 __device__ __forceinline__ void process_ray_unordered(const tr_bvh_view& b, const RayFetch& rf,
                                                       const QueryOut& out, int64_t i, bool in_range,
                                                       tr_counters* cnt, const tr_ring ring,
@@ -441,10 +443,10 @@ __device__ __forceinline__ void process_ray_unordered(const tr_bvh_view& b, cons
         top.ent = out.hits + (in_range ? i : 0) * out.cap;
         top.tris = b.tris;
         top.cap = out.cap;
-        wave_traverse_unordered<Q, 0, STATS, COMPACT>(b, r, valid, res, top, cnt, ring, lq, leaf_min);
+        wave_traverse_unordered<Q, 0, STATS, COMPACT, DEEP>(b, r, valid, res, top, cnt, ring, lq, leaf_min);
     } else {
         tr_topk<1> top;
-        wave_traverse_unordered<Q, 1, STATS, COMPACT>(b, r, valid, res, top, cnt, ring, lq, leaf_min);
+        wave_traverse_unordered<Q, 1, STATS, COMPACT, DEEP>(b, r, valid, res, top, cnt, ring, lq, leaf_min);
     }
     if (in_range) write_result<Q>(b, out, i, r, res);
 }
@@ -469,7 +471,7 @@ __device__ unsigned long long g_timeline[4 * TR_TIMELINE];
 
 // MODE: 0 fused ordered trip, 1 fused trip + intra-wave work stealing, 2 unordered two-phase
 // schedule (any / count / location on hierarchies of at least two triangles)
-template <int Q, bool STATS, bool COMPACT, int BS, int MODE = 0>
+template <int Q, bool STATS, bool COMPACT, int BS, int MODE = 0, bool DEEP = false>
 __global__ __launch_bounds__(BS) void k_query_direct(tr_bvh_view b, RayFetch rf, QueryOut out,
                                                       int xcd_map, int scramble, int tile_w, int steal_min,
                                                       const uint32_t* __restrict__ order, int order_split,
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(BS) void k_query_direct(tr_bvh_view b, RayFetch rf,
         // the steal_min argument carries the leaf-phase vote threshold of this schedule
         __shared__ int32_t leafq_lds[TR_LEAFQ * BS];
         const tr_leafq lq = {leafq_lds + threadIdx.x, BS};
-        process_ray_unordered<Q, STATS, COMPACT>(b, rf, out, i, i < rf.n, &cnt, ring, lq, steal_min);
+        process_ray_unordered<Q, STATS, COMPACT, DEEP>(b, rf, out, i, i < rf.n, &cnt, ring, lq, steal_min);
     } else if (MODE == 1) {
         __shared__ alignas(8) int32_t steal_lds[(BS / 64) * 384];
         // A split block (one of the most expensive of the previous launch): this slot owns the rays
@@ -563,7 +565,7 @@ __global__ __launch_bounds__(BS) void k_query_direct(tr_bvh_view b, RayFetch rf,
         // from the trip in the upper half of the argument on (the lower half: everybody else)
         const bool mine = (((int)threadIdx.x ^ part) & ((1 << parts_lg) - 1)) == 0;
         const uint32_t smin = parts_lg ? (uint32_t)steal_min >> 16 : (uint32_t)steal_min & 0xffffu;
-        process_ray_steal<Q, STATS, COMPACT>(b, rf, out, i, i < rf.n && mine, &cnt, ring,
+        process_ray_steal<Q, STATS, COMPACT, DEEP>(b, rf, out, i, i < rf.n && mine, &cnt, ring,
                                              steal_lds + (threadIdx.x >> 6) * 384, smin);
 #ifdef TR_TIMELINE
         tl_extra = (unsigned)(steal_lds[(threadIdx.x >> 6) * 384] & 0xffff) |
@@ -572,7 +574,7 @@ __global__ __launch_bounds__(BS) void k_query_direct(tr_bvh_view b, RayFetch rf,
     } else {
         // the plain shape is what large coherent batches get (small ones steal, incoherent ones
         // stream): look for wave-uniform trips (tr_fused_step)
-        process_ray<Q, STATS, COMPACT, !STATS && BS == 128 && Q != TR_Q_LOCATION>(b, rf, out, i, i < rf.n, &cnt, ring);
+        process_ray<Q, STATS, COMPACT, !STATS && BS == 128 && Q != TR_Q_LOCATION, DEEP>(b, rf, out, i, i < rf.n, &cnt, ring);
     }
     if (cost && (threadIdx.x & 63) == 0) {
         // 100 MHz ticks.  A split block records twice what it would have cost in one piece (roughly):
@@ -732,7 +734,7 @@ __global__ __launch_bounds__(256) void k_probe_coherence(RayFetch rf, float scen
     }
 }
 
-template <int Q, bool STATS, bool COMPACT, int BS>
+template <int Q, bool STATS, bool COMPACT, int BS, bool DEEP = false>
 __global__ __launch_bounds__(BS) void k_query_stream(tr_bvh_view b, RayFetch rf, QueryOut out,
                                                      int rays_per_wave, int refill_min, int xcd_map,
                                                      unsigned long long* stats,
@@ -743,7 +745,7 @@ __global__ __launch_bounds__(BS) void k_query_stream(tr_bvh_view b, RayFetch rf,
     const unsigned long long tl_start = wall_clock64();
     unsigned tl_trips = 0, tl_refills = 0;
 #endif
-    typedef typename tr_word<COMPACT>::T W;
+    typedef typename tr_word<COMPACT, DEEP>::T W;
     __shared__ int32_t ring_lds[TR_RING * BS];
     const tr_ring ring = {ring_lds + threadIdx.x, BS};
     // the XCD-chunked block -> range map of the direct launch: consecutive ranges stay on one
@@ -1207,9 +1209,12 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
         hipLaunchKernelGGL((k_query_persistent<Q, STATS>), dim3((unsigned)pgrid), dim3(256), 0, stream,
                            view, rf, out, counter, d_stats);
     } else {
-        const bool compact = opt.compact && bvh->depth <= 32 &&
-                             bvh->num_nodes * (int64_t)sizeof(tr_node) < ((int64_t)1 << 32) &&
-                             bvh->num_tris * (int64_t)sizeof(tr_tri) < ((int64_t)1 << 32);
+        // 32-bit offsets when both arrays are below 4 GiB; 32-bit trail words when the hierarchy is at
+        // most 32 levels high (`compact` = both, `deep` = offsets only; 128-thread blocks)
+        const bool addr32 = opt.compact && bvh->num_nodes * (int64_t)sizeof(tr_node) < ((int64_t)1 << 32) &&
+                            bvh->num_tris * (int64_t)sizeof(tr_tri) < ((int64_t)1 << 32);
+        const bool compact = addr32 && bvh->depth <= 32;
+        const bool deep = addr32 && !compact && bs == 128;
         // Streaming launch with ray refill for large incoherent batches (stream: 0 never, 1 auto,
         // 2 always).  Auto: every batch of at least 2 M rays gets BOTH launch shapes enqueued behind a
         // coherence probe that selects one on the device (k_probe_coherence): a camera image -- flat
@@ -1255,6 +1260,9 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
                 }
                 if (compact)
                     hipLaunchKernelGGL((k_query_stream<Q, STATS, true, 128>), dim3(grid), dim3(128), 0, stream,
+                                       view, rf, out, rpw, opt.stream_refill, sxc, d_stats, sel, work);
+                else if (addr32)
+                    hipLaunchKernelGGL((k_query_stream<Q, STATS, true, 128, true>), dim3(grid), dim3(128), 0, stream,
                                        view, rf, out, rpw, opt.stream_refill, sxc, d_stats, sel, work);
                 else
                     hipLaunchKernelGGL((k_query_stream<Q, STATS, false, 128>), dim3(grid), dim3(128), 0, stream,
@@ -1344,23 +1352,23 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
             for (int p : {7919, 7907, 7901})
                 if (cnt > 1 && cnt % p != 0) { scramble = p; break; }
         }
-#define TR_LAUNCH_DIRECT(C, B)                                                                          \
-    hipLaunchKernelGGL((k_query_direct<Q, STATS, C, B>), dim3((unsigned)nslots), dim3(B), 0, stream, \
+#define TR_LAUNCH_DIRECT(C, B, D)                                                                          \
+    hipLaunchKernelGGL((k_query_direct<Q, STATS, C, B, 0, D>), dim3((unsigned)nslots), dim3(B), 0, stream, \
                        view, rf, out, xc, scramble, tile_w, steal_min, order, (int)split, cost, d_stats, sel)
         static const bool debug_launch = getenv("TRIRO_DEBUG_LAUNCH") != nullptr;
         if (debug_launch)
             fprintf(stderr, "[triro] query %d: rays %lld blocks %lld slots %lld tile 0x%x split %lld order %d cost %d steal %d unordered %d compact %d\n",
                     Q, (long long)rf.n, (long long)nblocks_direct, (long long)nslots, (unsigned)tile_w, (long long)split,
-                    order != nullptr, cost != nullptr, (int)steal, (int)unord, (int)compact);
+                    order != nullptr, cost != nullptr, (int)steal, (int)unord, compact ? 1 : (deep ? 2 : 0));
         if (unord) {
             if constexpr (Q == TR_Q_COUNT || Q == TR_Q_LOCATION || Q == TR_Q_ANY) {
                 const int leaf_min = opt.leaf_vote;
-#define TR_LAUNCH_UNORD(C, B)                                                                            \
-    hipLaunchKernelGGL((k_query_direct<Q, STATS, C, B, 2>), dim3((unsigned)nslots), dim3(B), 0, stream, \
+#define TR_LAUNCH_UNORD(C, B, D)                                                                            \
+    hipLaunchKernelGGL((k_query_direct<Q, STATS, C, B, 2, D>), dim3((unsigned)nslots), dim3(B), 0, stream, \
                        view, rf, out, xc, scramble, tile_w, leaf_min, order, (int)split, cost, d_stats, sel)
-                if (bs == 64) { if (compact) TR_LAUNCH_UNORD(true, 64); else TR_LAUNCH_UNORD(false, 64); }
-                else if (bs == 128) { if (compact) TR_LAUNCH_UNORD(true, 128); else TR_LAUNCH_UNORD(false, 128); }
-                else { if (compact) TR_LAUNCH_UNORD(true, 256); else TR_LAUNCH_UNORD(false, 256); }
+                if (bs == 64) { if (compact) TR_LAUNCH_UNORD(true, 64, false); else TR_LAUNCH_UNORD(false, 64, false); }
+                else if (bs == 128) { if (compact) TR_LAUNCH_UNORD(true, 128, false); else if (deep) TR_LAUNCH_UNORD(true, 128, true); else TR_LAUNCH_UNORD(false, 128, false); }
+                else { if (compact) TR_LAUNCH_UNORD(true, 256, false); else TR_LAUNCH_UNORD(false, 256, false); }
 #undef TR_LAUNCH_UNORD
             }
         } else
@@ -1368,13 +1376,16 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
             if (compact)
                 hipLaunchKernelGGL((k_query_direct<Q, false, true, 128, 1>), dim3((unsigned)nslots), dim3(128), 0, stream,
                                    view, rf, out, xc, scramble, tile_w, steal_arg, order, (int)split, cost, d_stats, sel);
+            else if (deep)
+                hipLaunchKernelGGL((k_query_direct<Q, false, true, 128, 1, true>), dim3((unsigned)nslots), dim3(128), 0, stream,
+                                   view, rf, out, xc, scramble, tile_w, steal_arg, order, (int)split, cost, d_stats, sel);
             else
                 hipLaunchKernelGGL((k_query_direct<Q, false, false, 128, 1>), dim3((unsigned)nslots), dim3(128), 0, stream,
                                    view, rf, out, xc, scramble, tile_w, steal_arg, order, (int)split, cost, d_stats, sel);
         } else
-        if (bs == 64) { if (compact) TR_LAUNCH_DIRECT(true, 64); else TR_LAUNCH_DIRECT(false, 64); }
-        else if (bs == 128) { if (compact) TR_LAUNCH_DIRECT(true, 128); else TR_LAUNCH_DIRECT(false, 128); }
-        else { if (compact) TR_LAUNCH_DIRECT(true, 256); else TR_LAUNCH_DIRECT(false, 256); }
+        if (bs == 64) { if (compact) TR_LAUNCH_DIRECT(true, 64, false); else TR_LAUNCH_DIRECT(false, 64, false); }
+        else if (bs == 128) { if (compact) TR_LAUNCH_DIRECT(true, 128, false); else if (deep) TR_LAUNCH_DIRECT(true, 128, true); else TR_LAUNCH_DIRECT(false, 128, false); }
+        else { if (compact) TR_LAUNCH_DIRECT(true, 256, false); else TR_LAUNCH_DIRECT(false, 256, false); }
 #undef TR_LAUNCH_DIRECT
         if (cost)
             hipLaunchKernelGGL(k_sched_sort, dim3(1), dim3(1024), 0, stream, cost, cost + TR_SCHED_MAX,
