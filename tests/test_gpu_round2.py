@@ -459,3 +459,38 @@ def test_queries_can_be_captured_in_a_hip_graph(device):
         torch.cuda.synchronize()
         assert_closest_bitexact(out, exp, f"graph replay after another batch size {k}")
         assert np.array_equal(cnt.cpu().numpy(), R.intersects_count(o, d))
+
+
+@pytest.mark.parametrize("subdiv", [10, 11])
+def test_large_meshes_deep_trees_and_arrays_above_4gib(device, subdiv):
+    """Size-independent properties at sizes the oracle cannot reach: 21 M triangles (a hierarchy of
+    more than 32 levels with 32-bit addressing: the DEEP kernel variants) and, opt-in with
+    TRIRO_TEST_HUGE=1, 84 M triangles (node and triangle arrays above 4 GiB: 64-bit addressing).
+    first == closest's triangle, any == hit == (count > 0), loc is the barycentric point of the
+    reported triangle, the multi-hit rows add up, a second build gives the same bits."""
+    import os
+    if subdiv == 11 and os.environ.get("TRIRO_TEST_HUGE") != "1":
+        pytest.skip("84 M triangles: set TRIRO_TEST_HUGE=1 (about 20 s and 15 GB of device memory)")
+    v, f = W.headline_mesh(subdiv)
+    vt, ft = T(v, device), T(f, device)
+    r = make(v, f, device)
+    rad = float(np.linalg.norm(v[::997], axis=1).max())
+    o, d = W.pinhole_grid(512, 512, distance=2.5 * rad)
+    ot, dt = T(o, device), T(d, device)
+    for _ in range(3):                                         # learned order, split blocks
+        hit, front, tri, loc, uv = r.intersects_closest(ot, dt)
+    assert 0.5 < float(hit.float().mean()) < 0.99 and int(tri.max()) < len(f)
+    first, anyh, cnt = r.intersects_first(ot, dt), r.intersects_any(ot, dt), r.intersects_count(ot, dt)
+    assert torch.equal(first, tri) and torch.equal(anyh, hit) and torch.equal(cnt > 0, hit)
+    tv = vt[ft[tri[hit].long()].long()]
+    w0, w1 = uv[hit][:, 0:1], uv[hit][:, 1:2]
+    rec = w0 * tv[:, 0] + w1 * tv[:, 1] + (1 - w0 - w1) * tv[:, 2]
+    assert float((rec - loc[hit]).abs().max()) <= 1e-5 * rad
+    l3, ridx, tidx = r.intersects_location(ot, dt)
+    assert len(ridx) == int(cnt.clamp(max=8).sum()) and torch.equal(torch.bincount(ridx.long(), minlength=cnt.numel()), cnt.clamp(max=8).reshape(-1).long())
+    o2, d2 = W.hash_rays_torch(2_200_000, 5, v.min(0) * 1.5, v.max(0) * 1.5, device=device)   # streaming launch
+    h2 = r.intersects_closest(o2, d2)
+    assert torch.equal(h2[0], r.intersects_any(o2, d2)) and torch.equal(h2[2], r.intersects_first(o2, d2))
+    r2 = make(v, f, device)
+    hit2, front2, tri2, loc2, uv2 = r2.intersects_closest(ot, dt)
+    assert torch.equal(tri2, tri) and torch.equal(loc2, loc) and torch.equal(uv2, uv) and torch.equal(front2, front)
