@@ -194,8 +194,9 @@ int tr_trace_stats_query(const tr_bvh *bvh, const tr_rays *rays, int query, tr_t
  *    them in separate wave-level leaf phases instead of on every trip; default 1), "leaf_vote"
  *    (1..64 lanes with a queued leaf that trigger such a phase), "tile_small" (0..4: pixel
  *    footprint of a wave for image-shaped batches below the "tile" threshold), "stream" (0/1/2),
- *    "stream_rays", "stream_refill" (streaming launch with wave-level ray refill for large
- *    incoherent batches), "split" (0 off / 1 auto / N >= 2: the nblocks >> N most expensive blocks of
+ *    "stream_rays", "stream_refill", "stream_dynamic" (streaming launch with wave-level ray refill
+ *    for large incoherent batches: rays per range, idle lanes that trigger a refill, ranges handed
+ *    out by a work counter instead of one static range per wave), "split" (0 off / 1 auto / N >= 2: the nblocks >> N most expensive blocks of
  *    the learned launch order are traced by two -- the first quarter by four -- launch slots of
  *    half / quarter lane density whose idle lanes steal from trip "split_steal" on).
  *    None of them changes results.  Returns TR_ERR_INVALID_ARG for unknown names or values out

@@ -118,3 +118,15 @@ def test_product_never_touches_the_oracle():
             if fn.endswith((".py", ".h", ".hip", ".cpp", "Makefile")):
                 txt = open(os.path.join(dp, fn), errors="replace").read()
                 assert "libtriro_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, fn
+
+
+def test_every_option_is_documented():
+    """every tr_set_option name of csrc/api.hip appears in the C header and in INTEGRATION.md"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    api = open(os.path.join(root, "trimesh-ray-optix_amd", "csrc", "api.hip")).read()
+    names = re.findall(r'\{"(\w+)", &tr_options::', api)
+    assert len(names) >= 15
+    hdr = open(os.path.join(root, "include", "triro_hip.h")).read()
+    integ = open(os.path.join(root, "INTEGRATION.md")).read()
+    assert [n for n in names if f'"{n}"' not in hdr] == []
+    assert [n for n in names if f"`{n}`" not in integ] == []
