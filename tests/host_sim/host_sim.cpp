@@ -250,7 +250,22 @@ static void run_query(const tr_bvh_view& v, const float* o, const float* d, int6
             tr_traverse_unordered<Q, 1, true>(v, r, valid, res, top, &cnt, ring, lq);
         } else if (v.num_tris >= 2 && (g_fused & 3)) {
             tr_result_init(res);
-            if (valid) {
+            if (valid && (g_fused & 4)) {
+                // the streaming launch's flavour: 32-byte grid nodes, no intervals in the leaf FIFO
+                if ((g_fused & 3) == 1) {
+                    tr_state_t<uint64_t, false> fs; tr_state_init(fs);
+                    while (!tr_done(fs)) {
+                        tr_fused_step<Q, 1, true, false, uint64_t, false, true, true>(v, r, fs, res, top, &cnt, ring);
+                        if (!tr_done(fs)) tr_fused_step<Q, 1, true, false, uint64_t, false, false, true>(v, r, fs, res, top, &cnt, ring);
+                    }
+                } else {
+                    tr_state_t<uint32_t, false> fs; tr_state_init(fs);
+                    while (!tr_done(fs)) {
+                        tr_fused_step<Q, 1, true, true, uint32_t, false, true, true>(v, r, fs, res, top, &cnt, ring);
+                        if (!tr_done(fs)) tr_fused_step<Q, 1, true, true, uint32_t, false, false, true>(v, r, fs, res, top, &cnt, ring);
+                    }
+                }
+            } else if (valid) {
                 if ((g_fused & 3) == 1) {
                     tr_state_t<uint64_t> fs; tr_state_init(fs);
                     // as the kernels run it: trips with and without the leaf block alternate

@@ -127,7 +127,7 @@ def use_ring(on: bool):
 
 
 def use_fused(mode: int):
-    """0 = generic node/leaf schedule, 1 = fused trip, 2 = fused trip with 32-bit state/offsets"""
+    """0 = generic node/leaf schedule, 1 = fused trip, 2 = fused trip with 32-bit state/offsets; +4 = over the 32-byte grid nodes (no intervals in the leaf FIFO)"""
     lib().sim_use_fused(mode)
 
 

@@ -116,9 +116,10 @@ def test_height_fallback_to_bounded_keys():
     assert R.intersects_count(o[:1], d[:1])[0] >= 4000
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 5, 6])
 def test_fused_trip_variants(mode):
-    """the kernels' fused trip (64-bit and compact 32-bit state) == oracle"""
+    """the kernels' fused trip (64-bit and compact 32-bit state; +4: over the 32-byte grid nodes with
+    the full predicate at the leaves, as the streaming launch runs it) == oracle"""
     import sim
     sim.use_fused(mode)
     try:
@@ -127,7 +128,7 @@ def test_fused_trip_variants(mode):
         v, f = W.random_soup(2500, seed=8)
         o, d = W.hash_rays(12000, 4, v.min(0) * 1.5, v.max(0) * 1.5)
         compare_all(v, f, o, d)
-        if mode == 1:                            # deep trees need the 64-bit trail
+        if mode in (1, 5):                       # deep trees need the 64-bit trail
             compare_all(v, f, o, d, morton_shift=63)
     finally:
         sim.use_fused(0)

@@ -21,6 +21,7 @@
 // path still owes its far child) plus parent/sibling links (Hapala 2011 / Afra &
 // Szirmay-Kalos 2014 style backtracking).  The builder guarantees depth <= 64.
 #pragma once
+#include <type_traits>
 #include "tr_math.h"
 #include "../../include/triro_hip.h"   // tr_hit_entry
 
@@ -225,6 +226,12 @@ TR_HD const tr_f4* tr_node_ptr(const tr_bvh_view& b, int32_t node) {
     return reinterpret_cast<const tr_f4*>(b.nodes + node);
 }
 template <bool COMPACT>
+TR_HD const tr_i4* tr_qnode_ptr(const tr_bvh_view& b, int32_t node) {
+    if (COMPACT)
+        return reinterpret_cast<const tr_i4*>(reinterpret_cast<const char*>(b.qnodes) + ((uint32_t)node << 5));
+    return reinterpret_cast<const tr_i4*>(b.qnodes + node);
+}
+template <bool COMPACT>
 TR_HD const tr_f4* tr_tri_ptr(const tr_bvh_view& b, int32_t slot) {
     if (COMPACT)
         return reinterpret_cast<const tr_f4*>(reinterpret_cast<const char*>(b.tris) + (uint32_t)slot * 48u);
@@ -255,11 +262,17 @@ TR_HD tr_tri tr_load_tri(const tr_bvh_view& b, int32_t slot, tr_counters* cnt) {
 // Fold one accepted/rejected leaf test into the per-query state.  `live` = the lane really
 // owns this leaf (the code runs unpredicated for the whole wave).  Returns true when the ray
 // is finished (ANY query, first accepted hit).
-template <int Q, int K>
+// IV: the slab interval (tn, tf) of the leaf's box comes with the call (it was produced by the exact
+// parent node's test and carried through the leaf FIFO).  !IV: the full predicate -- the interval is
+// recomputed from the triangle's vertices, same bits; this is what a trip over the 32-byte grid nodes
+// needs (their boxes are only conservative), and it takes six registers out of the traversal state.
+template <int Q, int K, bool IV = true>
 TR_HD bool tr_fold_leaf(bool live, const tr_ray& r, const tr_tri& t, int32_t slot, float tn, float tf,
                         tr_result& res, tr_topk<K>& top) {
     tr_hit h;
-    const bool hit = tr_tri_mt(r, t.ax, t.ay, t.az, t.bx, t.by, t.bz, t.cx, t.cy, t.cz, tn, tf, h) && live;
+    bool hit;
+    if (IV) hit = tr_tri_mt(r, t.ax, t.ay, t.az, t.bx, t.by, t.bz, t.cx, t.cy, t.cz, tn, tf, h) && live;
+    else hit = tr_tri_hit(r, t.ax, t.ay, t.az, t.bx, t.by, t.bz, t.cx, t.cy, t.cz, h) && live;
     if (Q == TR_Q_ANY) {
         if (hit) res.best_face = t.face;
         return hit;
@@ -290,7 +303,7 @@ struct tr_ring {
 
 // Per-lane traversal state between two iterations.  W = uint64_t in general; uint32_t when
 // the hierarchy is at most 32 levels high (halves the 64-bit shift/clz work per trip).
-template <typename W>
+template <typename W, bool IV = true>
 struct tr_state_t {
     int32_t node;     // next internal node to visit, -1 = hierarchy exhausted
     uint32_t depth;
@@ -300,9 +313,15 @@ struct tr_state_t {
     // triangle loads overlap the next node's load (one memory round trip per iteration)
     int32_t p0, p1;   // tri slots, -1 = none
     float p0n, p0f, p1n, p1f;   // their slab intervals
-#if TR_LEAF_QUEUE
     int32_t p2; float p2n, p2f;  // third queue slot (one leaf is tested per trip, up to two arrive)
-#endif
+};
+// without the intervals (IV = false, see tr_fold_leaf)
+template <typename W>
+struct tr_state_t<W, false> {
+    int32_t node;
+    uint32_t depth;
+    W trail, owned;
+    int32_t p0, p1, p2;
 };
 typedef tr_state_t<uint64_t> tr_state;
 typedef tr_state_t<uint32_t> tr_state32;
@@ -312,19 +331,17 @@ TR_HD uint32_t tr_top_bit(uint32_t x) { return 31u - (uint32_t)__builtin_clz(x);
 TR_HD uint64_t tr_ring_mask(uint64_t) { return TR_RING_MASK; }
 TR_HD uint32_t tr_ring_mask(uint32_t) { return 0x00010001u; }
 
-template <typename W>
-TR_HD void tr_state_init(tr_state_t<W>& st) {
+template <typename W, bool IV>
+TR_HD void tr_state_init(tr_state_t<W, IV>& st) {
     st.node = 0; st.depth = 0; st.trail = 0; st.owned = 0;
-    st.p0 = -1; st.p1 = -1; st.p0n = st.p0f = st.p1n = st.p1f = 0.f;
-#if TR_LEAF_QUEUE
-    st.p2 = -1; st.p2n = st.p2f = 0.f;
-#endif
+    st.p0 = -1; st.p1 = -1; st.p2 = -1;
+    if constexpr (IV) { st.p0n = st.p0f = st.p1n = st.p1f = st.p2n = st.p2f = 0.f; }
 }
 
-template <typename W>
-TR_HD bool tr_pending(const tr_state_t<W>& st) { return st.p0 >= 0 || st.p1 >= 0; }
-template <typename W>
-TR_HD bool tr_done(const tr_state_t<W>& st) { return st.node < 0 && st.p0 < 0 && st.p1 < 0; }
+template <typename W, bool IV>
+TR_HD bool tr_pending(const tr_state_t<W, IV>& st) { return st.p0 >= 0 || st.p1 >= 0; }
+template <typename W, bool IV>
+TR_HD bool tr_done(const tr_state_t<W, IV>& st) { return st.node < 0 && st.p0 < 0 && st.p1 < 0; }
 
 #ifndef TR_PK_SLAB
 #define TR_PK_SLAB 1
@@ -447,165 +464,6 @@ TR_HD void tr_leaf_step(const tr_bvh_view& b, const tr_ray& r, tr_state& st, tr_
 // node + the test of a leaf queued by an EARLIER trip.  The node loads are issued first, so
 // the triangle loads and the node loads are in flight together: one memory round trip per
 // trip.  Lanes never sit out.
-#if !TR_LEAF_QUEUE
-#error "the fused trip needs the 3-slot leaf FIFO (TR_LEAF_QUEUE)"
-#endif
-// everything of a trip after the node record has arrived (n0..n3: in vector registers, or -- on
-// trips where the whole wave visits the same node -- in scalar registers)
-// TEST = false: a trip WITHOUT the leaf block (tr_fused_step)
-template <int Q, int K, bool STATS, bool COMPACT, typename W, bool TEST = true>
-TR_HD void tr_fused_body(const tr_bvh_view& b, const tr_ray& r, tr_state_t<W>& st, tr_result& res,
-                         tr_topk<K>& top, tr_counters* cnt, const tr_ring ring, const bool has_node,
-                         const tr_f4& n0, const tr_f4& n1, const tr_f4& n2, const tr_f4& n3) {
-    const bool ordered = (Q == TR_Q_FIRST || Q == TR_Q_CLOSEST);
-    if (STATS && has_node) cnt->nodes++;
-    bool fin = false;
-    const int32_t q0 = st.p0;
-    if (TEST && TR_WAVE_ANY(q0 >= 0)) {
-        tr_counters* nc = nullptr;
-        const tr_tri t0 = tr_load_tri<false, COMPACT>(b, q0 >= 0 ? q0 : 0, nc);
-        // a queued leaf whose box entry lies beyond the best hit found meanwhile cannot win
-        const bool live = q0 >= 0 && (!ordered || st.p0n <= res.best_t);
-        if (STATS && live) cnt->tris++;
-        fin = tr_fold_leaf<Q, K>(live, r, t0, q0, st.p0n, st.p0f, res, top);
-    }
-    if (Q == TR_Q_ANY && fin) { st.node = -1; st.p1 = -1; st.p2 = -1; }
-    // n3 = c0 c1 parent sibling
-    float tn0, tf0, tn1, tf1;
-    tr_node_slabs(r, n0, n1, n2, tn0, tf0, tn1, tf1);
-    union { float f; int32_t i; } u0, u1, u2, u3;
-    u0.f = n3.x; u1.f = n3.y; u2.f = n3.z; u3.f = n3.w;
-    const int32_t c0 = u0.i, c1 = u1.i;
-    int32_t parent = u2.i, sibling = u3.i;
-    const float lim = ordered ? res.best_t : TR_TMAX;
-    const bool go = has_node && st.node >= 0;
-    bool h0 = tr_slab_hit(tn0, tf0, lim) && go;
-    bool h1 = tr_slab_hit(tn1, tf1, lim) && go;
-#if TR_LEAF_QUEUE
-    // New FIFO = (carried entries, new leaf of child 0, new leaf of child 1), written as selects
-    // (no shift-then-push: every move is a v_cndmask).  The head (p0) was consumed above; b =
-    // old p1 and c = old p2 are carried.  When c is valid the node waited (go is false, no new
-    // leaves) and c takes the place of "leaf of child 1" in the formulas below.
-    if (!TEST) {
-        // the head was NOT consumed; a lane that visits its node on such a trip holds at most one
-        // queued leaf (p0), so FIFO = (p0, new leaf of child 0, new leaf of child 1) still fits.
-        // Lanes that do not visit keep their FIFO as it is.
-        const bool l0 = h0 && c0 < 0, l1 = h1 && c1 < 0;
-        h0 = h0 && c0 >= 0;
-        h1 = h1 && c1 >= 0;
-        if (go) {
-            const bool hb = st.p0 >= 0, two = l0 && l1;
-            const int32_t xi = l0 ? ~c0 : (l1 ? ~c1 : -1);
-            const float xe = l0 ? tn0 : tn1, xx = l0 ? tf0 : tf1;
-            st.p2 = (hb && two) ? ~c1 : -1;   st.p2n = tn1;   st.p2f = tf1;
-            st.p1 = hb ? xi : (two ? ~c1 : -1);   st.p1n = hb ? xe : tn1;   st.p1f = hb ? xx : tf1;
-            st.p0 = hb ? st.p0 : xi;   st.p0n = hb ? st.p0n : xe;   st.p0f = hb ? st.p0f : xx;
-        }
-    } else {
-        const bool l0 = h0 && c0 < 0;
-        const bool wait = st.p2 >= 0;
-        const bool l1 = (h1 && c1 < 0) || wait;
-        h0 = h0 && c0 >= 0;
-        h1 = h1 && c1 >= 0;
-        const int32_t i1 = wait ? st.p2 : ~c1;
-        const float e1 = wait ? st.p2n : tn1, x1 = wait ? st.p2f : tf1;
-        const bool hb = st.p1 >= 0, two = l0 && l1;
-        const int32_t xi = l0 ? ~c0 : (l1 ? i1 : -1);      // first new entry
-        const float xe = l0 ? tn0 : e1, xx = l0 ? tf0 : x1;
-        st.p0 = hb ? st.p1 : xi;   st.p0n = hb ? st.p1n : xe;   st.p0f = hb ? st.p1f : xx;
-        st.p1 = hb ? xi : (two ? i1 : -1);   st.p1n = hb ? xe : e1;   st.p1f = hb ? xx : x1;
-        st.p2 = (hb && two) ? i1 : -1;   st.p2n = e1;   st.p2f = x1;
-    }
-#else
-    if (h0 && c0 < 0) { st.p0 = ~c0; st.p0n = tn0; st.p0f = tf0; h0 = false; }
-    if (h1 && c1 < 0) { st.p1 = ~c1; st.p1n = tn1; st.p1f = tf1; h1 = false; }
-#endif
-    if (go) {
-        if (h0 || h1) {
-            const bool both = h0 && h1;
-            const bool swap = (both && tn1 < tn0) || !h0;   // descend into c1?
-            if (both) {
-                st.trail |= (W(1) << st.depth);
-                if (ring.base) {
-                    const uint32_t slot = st.depth & (TR_RING - 1);
-                    ring.base[slot * ring.stride] = swap ? c0 : c1;
-                    st.owned = (st.owned & ~(tr_ring_mask(W(0)) << slot)) | (W(1) << st.depth);
-                }
-            }
-            st.node = swap ? c1 : c0;
-            st.depth++;
-        } else if (st.trail == 0) {
-            st.node = -1;
-        } else {
-            const uint32_t j = tr_top_bit(st.trail);
-            st.trail &= ~(W(1) << j);
-            if (ring.base && ((st.owned >> j) & W(1))) {
-                st.node = ring.base[(j & (TR_RING - 1)) * ring.stride];
-            } else {
-                int32_t node = st.node;
-                uint32_t depth = st.depth;
-                while (depth > j + 1) {
-                    node = parent;
-                    const tr_link l = b.links[node];
-                    parent = l.parent; sibling = l.sibling;
-                    depth--;
-                    if (STATS) cnt->climbs++;
-                }
-                st.node = sibling;
-            }
-            st.depth = j + 1;
-        }
-    }
-}
-
-
-// UNI: look for wave-uniform trips (below).  Worth it for large coherent batches (4 M rays: -4 %,
-// 16.7 M: -5 %), a loss where the texture path is not the busiest unit or uniform trips are rare
-// (1 M rays +-0, 262 k rays +5 %, coarse meshes +3 %, incoherent batches +2 %): the test costs two
-// ballots and a readlane on every trip.
-//
-// TEST: this trip has a leaf block.  The leaf block -- three triangle loads, Moller-Trumbore, a
-// division: 3 of the trip's 7 vector-memory instructions and about half of its VALU instructions --
-// is executed by the whole wave whenever ANY lane has a queued leaf, i.e. on nearly every trip, while
-// only ~8 % of the lane-trips have one.  The callers therefore alternate trips with and without it:
-// on a trip without, a lane visits its node if it holds at most one queued leaf (so that two new
-// ones still fit).  A leaf is tested at most one trip later than before; same tests, same results.
-template <int Q, int K, bool STATS, bool COMPACT = false, typename W = uint64_t, bool UNI = false, bool TEST = true>
-TR_HD void tr_fused_step(const tr_bvh_view& b, const tr_ray& r, tr_state_t<W>& st, tr_result& res,
-                         tr_topk<K>& top, tr_counters* cnt, const tr_ring ring) {
-    // one leaf test per trip: the head of the lane's FIFO (p0, p1, p2).  The node is visited
-    // unless the FIFO is full (it then waits one trip: no fetch, no new leaves).
-    const int32_t room = TEST ? st.p2 : st.p1;     // must be empty (-1) for the node to be visited
-    const bool has_node = st.node >= 0 && room < 0;
-#if defined(__HIP_DEVICE_COMPILE__)
-    // Wave-uniform trips: 36-44 % of the node visits of an image-shaped batch happen on trips where
-    // every visiting lane is at the SAME node (the top of the tree under an 8x8 pixel tile).  The
-    // record is then fetched once, by the scalar unit, instead of by a 64-lane gather of four
-    // dwordx4 that all hit the same line: no texture-path work at all for that trip.
-    if (UNI) {
-        const unsigned long long m = __ballot(has_node);
-        if (m != 0ull) {
-            const int32_t nu = __builtin_amdgcn_readlane(st.node, (int)__builtin_ctzll(m));
-            if (__ballot(has_node && st.node != nu) == 0ull) {
-                // constant address space: the node array is read-only while queries run, and a
-                // uniform address in that space is what selects the scalar memory path
-                typedef const __attribute__((address_space(4))) tr_f4* tr_cf4p;
-                const tr_cf4p sp = (tr_cf4p)(unsigned long long)tr_node_ptr<COMPACT>(b, nu);
-                const tr_f4 n0 = sp[0], n1 = sp[1], n2 = sp[2], n3 = sp[3];
-                tr_fused_body<Q, K, STATS, COMPACT, W, TEST>(b, r, st, res, top, cnt, ring, has_node, n0, n1, n2, n3);
-                return;
-            }
-        }
-    }
-#endif
-    // node index or 0, from the sign bits (a select here loses the SGPR-base + 32-bit-offset
-    // addressing of the four node loads)
-    const int32_t nidx = st.node & ~(st.node >> 31) & (room >> 31);
-    const tr_f4* np = tr_node_ptr<COMPACT>(b, nidx);
-    const tr_f4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
-    tr_fused_body<Q, K, STATS, COMPACT, W, TEST>(b, r, st, res, top, cnt, ring, has_node, n0, n1, n2, n3);
-}
-
 // Slab intervals of both children of a 32-byte grid node held in two 16-byte registers:
 // w0 = q[0..3], w1 = q[4], q[5], c0, c1.  Decode: plane = fma(q, scale, base) per 16-bit half; then
 // the contract's subtract and multiply per plane.  On the device both steps are packed FP32.
@@ -655,6 +513,222 @@ TR_HD int32_t tr_climb(const tr_bvh_view& b, int32_t node, uint32_t depth, uint3
     }
     return l.sibling;
 }
+
+// A fetched node record for the fused trip: the exact 64-byte node (four 16-byte words) or the
+// 32-byte grid node (two).  With the full predicate at the leaves (tr_fold_leaf) the trip only needs
+// CONSERVATIVE child boxes, so the pruning queries can walk the grid nodes too: two gathers per
+// visit instead of four, for a decode of 18 VALU instructions.
+struct tr_rec_f { tr_f4 n0, n1, n2, n3; };
+struct tr_rec_q { tr_i4 w0, w1; };
+TR_HD void tr_rec_slabs(const tr_bvh_view&, const tr_ray& r, const tr_rec_f& n, float& tn0, float& tf0, float& tn1, float& tf1) {
+    tr_node_slabs(r, n.n0, n.n1, n.n2, tn0, tf0, tn1, tf1);
+}
+TR_HD void tr_rec_slabs(const tr_bvh_view& b, const tr_ray& r, const tr_rec_q& n, float& tn0, float& tf0, float& tn1, float& tf1) {
+    tr_qnode_slabs(r, b.frame, n.w0, n.w1, tn0, tf0, tn1, tf1);
+}
+TR_HD void tr_rec_children(const tr_rec_f& n, int32_t& c0, int32_t& c1) {
+    union { float f; int32_t i; } u0, u1;
+    u0.f = n.n3.x; u1.f = n.n3.y; c0 = u0.i; c1 = u1.i;
+}
+TR_HD void tr_rec_children(const tr_rec_q& n, int32_t& c0, int32_t& c1) { c0 = n.w1.z; c1 = n.w1.w; }
+// parent / sibling of the visited node: the first step of a climb comes with the exact record
+// (n3 = c0 c1 parent sibling); the grid node does not carry them (tr_climb reads links[])
+TR_HD void tr_rec_links(const tr_rec_f& n, int32_t& parent, int32_t& sibling) {
+    union { float f; int32_t i; } u2, u3;
+    u2.f = n.n3.z; u3.f = n.n3.w; parent = u2.i; sibling = u3.i;
+}
+TR_HD void tr_rec_links(const tr_rec_q&, int32_t& parent, int32_t& sibling) { parent = -1; sibling = -1; }
+
+#if !TR_LEAF_QUEUE
+#error "the fused trip needs the 3-slot leaf FIFO (TR_LEAF_QUEUE)"
+#endif
+// everything of a trip after the node record has arrived (n0..n3: in vector registers, or -- on
+// trips where the whole wave visits the same node -- in scalar registers)
+// TEST = false: a trip WITHOUT the leaf block (tr_fused_step)
+template <int Q, int K, bool STATS, bool COMPACT, typename W, bool TEST, typename REC>
+TR_HD void tr_fused_body(const tr_bvh_view& b, const tr_ray& r,
+                         tr_state_t<W, std::is_same<REC, tr_rec_f>::value>& st, tr_result& res,
+                         tr_topk<K>& top, tr_counters* cnt, const tr_ring ring, const bool has_node,
+                         const REC& rec) {
+    constexpr bool IV = std::is_same<REC, tr_rec_f>::value;   // exact nodes: intervals travel with the leaves
+    const bool ordered = (Q == TR_Q_FIRST || Q == TR_Q_CLOSEST);
+    if (STATS && has_node) cnt->nodes++;
+    bool fin = false;
+    const int32_t q0 = st.p0;
+    if (TEST && TR_WAVE_ANY(q0 >= 0)) {
+        tr_counters* nc = nullptr;
+        const tr_tri t0 = tr_load_tri<false, COMPACT>(b, q0 >= 0 ? q0 : 0, nc);
+        bool live = q0 >= 0;
+        float ln = 0.f, lf = 0.f;
+        if constexpr (IV) {
+            // a queued leaf whose box entry lies beyond the best hit found meanwhile cannot win
+            live = live && (!ordered || st.p0n <= res.best_t);
+            ln = st.p0n; lf = st.p0f;
+        }
+        if (STATS && live) cnt->tris++;
+        fin = tr_fold_leaf<Q, K, IV>(live, r, t0, q0, ln, lf, res, top);
+    }
+    if (Q == TR_Q_ANY && fin) { st.node = -1; st.p1 = -1; st.p2 = -1; }
+    float tn0, tf0, tn1, tf1;
+    tr_rec_slabs(b, r, rec, tn0, tf0, tn1, tf1);
+    int32_t c0, c1, parent, sibling;
+    tr_rec_children(rec, c0, c1);
+    tr_rec_links(rec, parent, sibling);
+    const float lim = ordered ? res.best_t : TR_TMAX;
+    const bool go = has_node && st.node >= 0;
+    bool h0 = tr_slab_hit(tn0, tf0, lim) && go;
+    bool h1 = tr_slab_hit(tn1, tf1, lim) && go;
+#if TR_LEAF_QUEUE
+    // New FIFO = (carried entries, new leaf of child 0, new leaf of child 1), written as selects
+    // (no shift-then-push: every move is a v_cndmask).  The head (p0) was consumed above; b =
+    // old p1 and c = old p2 are carried.  When c is valid the node waited (go is false, no new
+    // leaves) and c takes the place of "leaf of child 1" in the formulas below.
+    if (!TEST) {
+        // the head was NOT consumed; a lane that visits its node on such a trip holds at most one
+        // queued leaf (p0), so FIFO = (p0, new leaf of child 0, new leaf of child 1) still fits.
+        // Lanes that do not visit keep their FIFO as it is.
+        const bool l0 = h0 && c0 < 0, l1 = h1 && c1 < 0;
+        h0 = h0 && c0 >= 0;
+        h1 = h1 && c1 >= 0;
+        if (go) {
+            const bool hb = st.p0 >= 0, two = l0 && l1;
+            const int32_t xi = l0 ? ~c0 : (l1 ? ~c1 : -1);
+            st.p2 = (hb && two) ? ~c1 : -1;
+            st.p1 = hb ? xi : (two ? ~c1 : -1);
+            st.p0 = hb ? st.p0 : xi;
+            if constexpr (IV) {
+                const float xe = l0 ? tn0 : tn1, xx = l0 ? tf0 : tf1;
+                st.p2n = tn1;   st.p2f = tf1;
+                st.p1n = hb ? xe : tn1;   st.p1f = hb ? xx : tf1;
+                st.p0n = hb ? st.p0n : xe;   st.p0f = hb ? st.p0f : xx;
+            }
+        }
+    } else {
+        const bool l0 = h0 && c0 < 0;
+        const bool wait = st.p2 >= 0;
+        const bool l1 = (h1 && c1 < 0) || wait;
+        h0 = h0 && c0 >= 0;
+        h1 = h1 && c1 >= 0;
+        const int32_t i1 = wait ? st.p2 : ~c1;
+        const bool hb = st.p1 >= 0, two = l0 && l1;
+        const int32_t xi = l0 ? ~c0 : (l1 ? i1 : -1);      // first new entry
+        if constexpr (IV) {
+            const float e1 = wait ? st.p2n : tn1, x1 = wait ? st.p2f : tf1;
+            const float xe = l0 ? tn0 : e1, xx = l0 ? tf0 : x1;
+            st.p0n = hb ? st.p1n : xe;   st.p0f = hb ? st.p1f : xx;
+            st.p1n = hb ? xe : e1;   st.p1f = hb ? xx : x1;
+            st.p2n = e1;   st.p2f = x1;
+        }
+        st.p0 = hb ? st.p1 : xi;
+        st.p1 = hb ? xi : (two ? i1 : -1);
+        st.p2 = (hb && two) ? i1 : -1;
+    }
+#else
+#error "unused"
+#endif
+    if (go) {
+        if (h0 || h1) {
+            const bool both = h0 && h1;
+            const bool swap = (both && tn1 < tn0) || !h0;   // descend into c1?
+            if (both) {
+                st.trail |= (W(1) << st.depth);
+                if (ring.base) {
+                    const uint32_t slot = st.depth & (TR_RING - 1);
+                    ring.base[slot * ring.stride] = swap ? c0 : c1;
+                    st.owned = (st.owned & ~(tr_ring_mask(W(0)) << slot)) | (W(1) << st.depth);
+                }
+            }
+            st.node = swap ? c1 : c0;
+            st.depth++;
+        } else if (st.trail == 0) {
+            st.node = -1;
+        } else {
+            const uint32_t j = tr_top_bit(st.trail);
+            st.trail &= ~(W(1) << j);
+            if (ring.base && ((st.owned >> j) & W(1))) {
+                st.node = ring.base[(j & (TR_RING - 1)) * ring.stride];
+            } else if constexpr (std::is_same<REC, tr_rec_f>::value) {
+                int32_t node = st.node;
+                uint32_t depth = st.depth;
+                while (depth > j + 1) {
+                    node = parent;
+                    const tr_link l = b.links[node];
+                    parent = l.parent; sibling = l.sibling;
+                    depth--;
+                    if (STATS) cnt->climbs++;
+                }
+                st.node = sibling;
+            } else {
+                st.node = tr_climb<STATS>(b, st.node, st.depth, j, cnt);
+            }
+            st.depth = j + 1;
+        }
+    }
+}
+
+
+// UNI: look for wave-uniform trips (below).  Worth it for large coherent batches (4 M rays: -4 %,
+// 16.7 M: -5 %), a loss where the texture path is not the busiest unit or uniform trips are rare
+// (1 M rays +-0, 262 k rays +5 %, coarse meshes +3 %, incoherent batches +2 %): the test costs two
+// ballots and a readlane on every trip.
+//
+// TEST: this trip has a leaf block.  The leaf block -- three triangle loads, Moller-Trumbore, a
+// division: 3 of the trip's 7 vector-memory instructions and about half of its VALU instructions --
+// is executed by the whole wave whenever ANY lane has a queued leaf, i.e. on nearly every trip, while
+// only ~8 % of the lane-trips have one.  The callers therefore alternate trips with and without it:
+// on a trip without, a lane visits its node if it holds at most one queued leaf (so that two new
+// ones still fit).  A leaf is tested at most one trip later than before; same tests, same results.
+// QN: walk the 32-byte grid nodes instead of the exact 64-byte ones (see tr_rec_q).
+template <int Q, int K, bool STATS, bool COMPACT = false, typename W = uint64_t, bool UNI = false, bool TEST = true,
+          bool QN = false>
+TR_HD void tr_fused_step(const tr_bvh_view& b, const tr_ray& r, tr_state_t<W, !QN>& st, tr_result& res,
+                         tr_topk<K>& top, tr_counters* cnt, const tr_ring ring) {
+    // one leaf test per trip: the head of the lane's FIFO (p0, p1, p2).  The node is visited
+    // unless the FIFO is full (it then waits one trip: no fetch, no new leaves).
+    const int32_t room = TEST ? st.p2 : st.p1;     // must be empty (-1) for the node to be visited
+    const bool has_node = st.node >= 0 && room < 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // Wave-uniform trips: 36-44 % of the node visits of an image-shaped batch happen on trips where
+    // every visiting lane is at the SAME node (the top of the tree under an 8x8 pixel tile).  The
+    // record is then fetched once, by the scalar unit, instead of by a 64-lane gather of four
+    // dwordx4 that all hit the same line: no texture-path work at all for that trip.
+    if (UNI) {
+        const unsigned long long m = __ballot(has_node);
+        if (m != 0ull) {
+            const int32_t nu = __builtin_amdgcn_readlane(st.node, (int)__builtin_ctzll(m));
+            if (__ballot(has_node && st.node != nu) == 0ull) {
+                // constant address space: the node array is read-only while queries run, and a
+                // uniform address in that space is what selects the scalar memory path
+                if constexpr (QN) {
+                    typedef const __attribute__((address_space(4))) tr_i4* tr_ci4p;
+                    const tr_ci4p sp = (tr_ci4p)(unsigned long long)tr_qnode_ptr<COMPACT>(b, nu);
+                    const tr_rec_q rec = {sp[0], sp[1]};
+                    tr_fused_body<Q, K, STATS, COMPACT, W, TEST>(b, r, st, res, top, cnt, ring, has_node, rec);
+                } else {
+                    typedef const __attribute__((address_space(4))) tr_f4* tr_cf4p;
+                    const tr_cf4p sp = (tr_cf4p)(unsigned long long)tr_node_ptr<COMPACT>(b, nu);
+                    const tr_rec_f rec = {sp[0], sp[1], sp[2], sp[3]};
+                    tr_fused_body<Q, K, STATS, COMPACT, W, TEST>(b, r, st, res, top, cnt, ring, has_node, rec);
+                }
+                return;
+            }
+        }
+    }
+#endif
+    // node index or 0, from the sign bits (a select here loses the SGPR-base + 32-bit-offset
+    // addressing of the four node loads)
+    const int32_t nidx = st.node & ~(st.node >> 31) & (room >> 31);
+    if constexpr (QN) {
+        const tr_i4* np = tr_qnode_ptr<COMPACT>(b, nidx);
+        const tr_rec_q rec = {np[0], np[1]};
+        tr_fused_body<Q, K, STATS, COMPACT, W, TEST>(b, r, st, res, top, cnt, ring, has_node, rec);
+    } else {
+        const tr_f4* np = tr_node_ptr<COMPACT>(b, nidx);
+        const tr_rec_f rec = {np[0], np[1], np[2], np[3]};
+        tr_fused_body<Q, K, STATS, COMPACT, W, TEST>(b, r, st, res, top, cnt, ring, has_node, rec);
+    }
+}
+
 
 // ---- unordered two-phase schedule (any / count / location) --------------------------------------
 // Queries that do not prune by distance gain nothing from near-first order or from testing a

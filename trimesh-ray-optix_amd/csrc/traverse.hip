@@ -122,6 +122,9 @@ template <> struct tr_word<true, false> { typedef uint32_t T; };
 // hierarchy is more than 32 levels high), 32-bit trail / owned words.  Chosen on the host per BVH.
 // COMPACT + DEEP is what meshes of a few million triangles and more get (5.2 M-triangle sphere: 34
 // levels): 80 instead of 82 VGPRs in the stealing closest kernel, i.e. 6 instead of 5 waves/SIMD.
+#ifndef TR_STREAM_QN
+#define TR_STREAM_QN true     // the streaming launch walks the 32-byte grid nodes (tr_rec_q)
+#endif
 #ifndef TR_ALTERNATE
 #define TR_ALTERNATE 1        // every second trip runs without the leaf block (tr_fused_step<..., TEST>)
 #endif
@@ -774,7 +777,7 @@ __global__ __launch_bounds__(BS) void k_query_stream(tr_bvh_view b, RayFetch rf,
     int64_t rid = -1;          // ray this lane holds (-1 none); its result is stored when the lane is refilled
     bool busy = false;         // still traversing
     tr_ray r;
-    tr_state_t<W> fs;
+    tr_state_t<W, !TR_STREAM_QN> fs;     // grid nodes: no intervals in the leaf FIFO (tr_fold_leaf)
     tr_result res;
     tr_topk<1> top;
     tr_state_init(fs);
@@ -824,14 +827,14 @@ __global__ __launch_bounds__(BS) void k_query_stream(tr_bvh_view b, RayFetch rf,
         int idle_now;
         do {
             if (busy) {
-                tr_fused_step<Q, 1, STATS, COMPACT, W, false, true>(b, r, fs, res, top, &cnt, ring);
+                tr_fused_step<Q, 1, STATS, COMPACT, W, false, true, TR_STREAM_QN>(b, r, fs, res, top, &cnt, ring);
                 busy = !tr_done(fs);
             }
             TR_CONVERGE();
 #pragma unroll
             for (int a = 0; a < TR_ALTERNATE; a++) {
                 if (busy) {
-                    tr_fused_step<Q, 1, STATS, COMPACT, W, false, false>(b, r, fs, res, top, &cnt, ring);
+                    tr_fused_step<Q, 1, STATS, COMPACT, W, false, false, TR_STREAM_QN>(b, r, fs, res, top, &cnt, ring);
                     busy = !tr_done(fs);
                 }
                 TR_CONVERGE();
