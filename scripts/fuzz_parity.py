@@ -19,7 +19,7 @@ T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
 DEFAULTS = {"steal": 1, "tile": 1, "block_size": 128, "adaptive": 1, "xcd_chunk": 128, "compact": 1, "scramble": 1,
             "persistent": 0, "blocks_per_cu": 8,
             "tile_small": 4, "unordered": 1, "leaf_vote": 32, "stream": 1, "stream_rays": 256, "stream_refill": 32, "stream_dynamic": 1,
-            "split": 1, "split_steal": 8}
+            "split": 1, "split_steal": 8, "grid_nodes": 1}
 bad = 0
 for it in range(a.iters):
     kind = rng.integers(0, 5)
@@ -63,7 +63,8 @@ for it in range(a.iters):
             "stream": int(rng.choice([0, 1, 2, 2])), "stream_rays": int(rng.choice([64, 100, 512, 4096])),
             "stream_refill": int(rng.choice([1, 8, 16, 40, 64])), "stream_dynamic": int(rng.choice([0, 1, 1])),
             # block splitting of the stealing launch shapes (from the second launch of a batch on)
-            "split": int(rng.choice([0, 1, 1, 2, 3, 4])), "split_steal": int(rng.choice([0, 2, 8, 64]))}
+            "split": int(rng.choice([0, 1, 1, 2, 3, 4])), "split_steal": int(rng.choice([0, 2, 8, 64])),
+            "grid_nodes": int(rng.choice([0, 1, 2, 2]))}
     for k, val in opts.items(): hops.set_option(k, val)
     try:
         r = RayMeshIntersector(vertices=T(v), faces=T(f)); R = OracleIntersector(v, f, 1)

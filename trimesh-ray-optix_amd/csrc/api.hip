@@ -39,6 +39,7 @@ const opt_desc OPTS[] = {
     {"stream_refill", &tr_options::stream_refill, 1, 64, false},
     {"stream_dynamic", &tr_options::stream_dynamic, 0, 1, false},
     {"leaf_vote", &tr_options::leaf_vote, 1, 64, false},
+    {"grid_nodes", &tr_options::grid_nodes, 0, 2, false},
     {"split", &tr_options::split, 0, 12, false},
     {"split_steal", &tr_options::split_steal, 0, 4096, false},
 };
@@ -274,8 +275,11 @@ int tr_bvh_destroy(tr_bvh* bvh) {
         if (g.enter(bvh->device) == TR_OK) {
             if (bvh->arena && hipFree(bvh->arena) != hipSuccess) status = tr_fail(TR_ERR_HIP, "hipFree(arena)");
             if (bvh->refit_temp && hipFree(bvh->refit_temp) != hipSuccess) status = tr_fail(TR_ERR_HIP, "hipFree(refit_temp)");
-            for (int k = 0; k < TR_SCHED_SLOTS; k++)
+            for (int k = 0; k < TR_SCHED_SLOTS; k++) {
                 if (bvh->sched[k].buf && hipFree(bvh->sched[k].buf) != hipSuccess) status = tr_fail(TR_ERR_HIP, "hipFree(sched)");
+                for (int e = 0; e < 4; e++)
+                    if (bvh->sched[k].gn_ev[e]) (void)hipEventDestroy(bvh->sched[k].gn_ev[e]);
+            }
         }
     }
     delete bvh->sched_mutex;

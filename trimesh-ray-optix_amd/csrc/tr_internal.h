@@ -40,6 +40,13 @@ struct tr_sched_slot {
     int64_t split = 0;      // ... and the number of split blocks per XCD the order was written with
     int64_t launches = 0;   // launches with this block count so far
     bool used = false;
+    // node-flavour tuner of the stealing closest / first launches (grid_nodes = 1): two launches on
+    // the exact nodes and two on the grid nodes are timed with events, the faster flavour stays
+    int64_t gn_key = 0;     // (block count, query) the state below belongs to
+    int gn_count = 0;       // launches with this key
+    int gn_choice = -1;     // -1 undecided, 0 exact nodes, 1 grid nodes
+    bool gn_events = false;
+    hipEvent_t gn_ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 // the opaque handle ---------------------------------------------------------------------
@@ -140,6 +147,7 @@ struct tr_options {
     int stream_refill = 32;   // idle lanes that trigger a refill
     int stream_dynamic = 1;   // ranges handed out by a work counter to a resident-sized grid (0: one static range per wave)
     int unordered = 1;    // count / location (2: also any) use the unordered two-phase schedule (queued leaves)
+    int grid_nodes = 1;   // stealing closest / first launches on the 32-byte grid nodes: 0 never, 1 measured (the faster flavour of the first launches of a batch stays), 2 always
     int split = 1;        // block splitting: 0 off, 1 auto, N >= 2: the nblocks >> N most expensive blocks of the previous launch get two launch slots
     int split_steal = 8;  // ... and give subtrees away from this trip on
     int leaf_vote = 32;   // unordered schedule: lanes with a queued leaf that fire a leaf phase

@@ -175,7 +175,7 @@ __device__ __forceinline__ int lane_rank(unsigned long long mask) {   // set bit
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
 
-template <int Q, bool STATS, bool COMPACT, bool DEEP = false>
+template <int Q, bool STATS, bool COMPACT, bool DEEP = false, bool QN = false>
 __device__ __forceinline__ bool wave_traverse_steal(const tr_bvh_view& b, tr_ray& r, bool go,
                                                     tr_result& res, tr_counters* cnt,
                                                     const tr_ring ring, int32_t* wl, int lane,
@@ -183,7 +183,7 @@ __device__ __forceinline__ bool wave_traverse_steal(const tr_bvh_view& b, tr_ray
     typedef typename tr_word<COMPACT, DEEP>::T W;
     tr_result_init(res);
     tr_topk<1> top;
-    tr_state_t<W> fs;
+    tr_state_t<W, !QN> fs;
     tr_state_init(fs);
     if (!go) fs.node = -1;
     int owner = lane;          // lane whose ray this lane is working on
@@ -231,11 +231,11 @@ __device__ __forceinline__ bool wave_traverse_steal(const tr_bvh_view& b, tr_ray
 #pragma unroll 1
 #if TR_ALTERNATE
         for (uint32_t k = 0; k <= TR_STEAL_EVERY; k += 1 + TR_ALTERNATE) {
-            if (!tr_done(fs)) tr_fused_step<Q, 1, STATS, COMPACT, W, false, true>(b, r, fs, res, top, cnt, ring);
+            if (!tr_done(fs)) tr_fused_step<Q, 1, STATS, COMPACT, W, false, true, QN>(b, r, fs, res, top, cnt, ring);
             TR_CONVERGE();
 #pragma unroll
             for (int a = 0; a < TR_ALTERNATE; a++) {
-                if (!tr_done(fs)) tr_fused_step<Q, 1, STATS, COMPACT, W, false, false>(b, r, fs, res, top, cnt, ring);
+                if (!tr_done(fs)) tr_fused_step<Q, 1, STATS, COMPACT, W, false, false, QN>(b, r, fs, res, top, cnt, ring);
                 TR_CONVERGE();
             }
         }
@@ -386,7 +386,7 @@ __device__ __forceinline__ void process_ray(const tr_bvh_view& b, const RayFetch
     if (in_range) write_result<Q>(b, out, i, r, res);
 }
 
-template <int Q, bool STATS, bool COMPACT, bool DEEP = false>
+template <int Q, bool STATS, bool COMPACT, bool DEEP = false, bool QN = false>
 __device__ __forceinline__ void process_ray_steal(const tr_bvh_view& b, const RayFetch& rf,
                                                   const QueryOut& out, int64_t i, bool in_range,
                                                   tr_counters* cnt, const tr_ring ring, int32_t* wl,
@@ -397,7 +397,7 @@ __device__ __forceinline__ void process_ray_steal(const tr_bvh_view& b, const Ra
     const bool valid = tr_ray_setup(r, o[0], o[1], o[2], d[0], d[1], d[2]) && in_range;
     tr_result res;
     bool split = false;
-    if (b.num_tris >= 2) split = wave_traverse_steal<Q, STATS, COMPACT, DEEP>(b, r, valid, res, cnt, ring, wl, (int)(threadIdx.x & 63), steal_min);
+    if (b.num_tris >= 2) split = wave_traverse_steal<Q, STATS, COMPACT, DEEP, QN>(b, r, valid, res, cnt, ring, wl, (int)(threadIdx.x & 63), steal_min);
     else brute_one<Q>(b, r, valid, res);   // no hierarchy below two triangles
     if (split && in_range) {   // this lane may hold another lane's ray now: take its own again
         fetch_ray(rf, i, o, d);
@@ -474,7 +474,7 @@ __device__ unsigned long long g_timeline[4 * TR_TIMELINE];
 
 // MODE: 0 fused ordered trip, 1 fused trip + intra-wave work stealing, 2 unordered two-phase
 // schedule (any / count / location on hierarchies of at least two triangles)
-template <int Q, bool STATS, bool COMPACT, int BS, int MODE = 0, bool DEEP = false>
+template <int Q, bool STATS, bool COMPACT, int BS, int MODE = 0, bool DEEP = false, bool QN = false>
 __global__ __launch_bounds__(BS) void k_query_direct(tr_bvh_view b, RayFetch rf, QueryOut out,
                                                       int xcd_map, int scramble, int tile_w, int steal_min,
                                                       const uint32_t* __restrict__ order, int order_split,
@@ -568,7 +568,7 @@ __global__ __launch_bounds__(BS) void k_query_direct(tr_bvh_view b, RayFetch rf,
         // from the trip in the upper half of the argument on (the lower half: everybody else)
         const bool mine = (((int)threadIdx.x ^ part) & ((1 << parts_lg) - 1)) == 0;
         const uint32_t smin = parts_lg ? (uint32_t)steal_min >> 16 : (uint32_t)steal_min & 0xffffu;
-        process_ray_steal<Q, STATS, COMPACT, DEEP>(b, rf, out, i, i < rf.n && mine, &cnt, ring,
+        process_ray_steal<Q, STATS, COMPACT, DEEP, QN>(b, rf, out, i, i < rf.n && mine, &cnt, ring,
                                              steal_lds + (threadIdx.x >> 6) * 384, smin);
 #ifdef TR_TIMELINE
         tl_extra = (unsigned)(steal_lds[(threadIdx.x >> 6) * 384] & 0xffff) |
@@ -1176,6 +1176,50 @@ void sched_acquire(const tr_bvh* bvh, const tr_options& opt, hipStream_t stream,
     if (slot->launches < 3 || (slot->launches & 3) == 3) *cost = slot->buf;
 }
 
+// Node flavour of a stealing closest / first launch under grid_nodes = 1.  Whether the 32-byte grid
+// nodes beat the exact ones depends on how many distinct nodes the lanes of a wave are on (headline
+// image -2...-5 %, 21 M triangles -8 %, the shell scene +1.5...+4 %), which the host cannot know -- so
+// it is measured: launches 0-4 of a (batch size, query) run on the exact nodes, 5-8 on the grid nodes,
+// launches 3-4 and 7-8 are bracketed by events (each span holds one re-sort of the launch order), and
+// as soon as both spans have completed the faster flavour stays (the grid nodes have to win by 2 %).
+// Never blocks: until the events are done, and while a stream is being captured, launches use the
+// exact nodes.  Speed only.  *ev_before / *ev_after: events to record around this launch.
+int gn_pick(const tr_bvh* bvh, hipStream_t stream, int cls, int64_t key, hipEvent_t* ev_before, hipEvent_t* ev_after) {
+    *ev_before = nullptr; *ev_after = nullptr;
+    tr_bvh* mb = const_cast<tr_bvh*>(bvh);
+    if (!mb->sched_mutex) return 0;
+    std::lock_guard<std::mutex> lock(*mb->sched_mutex);
+    tr_sched_slot* t = sched_slot(mb, stream, cls);
+    if (!t) return 0;
+    if (t->gn_key != key) { t->gn_key = key; t->gn_count = 0; t->gn_choice = -1; }
+    if (t->gn_choice >= 0) return t->gn_choice;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return 0; }
+    if (!t->gn_events) {
+        for (int k = 0; k < 4; k++)
+            if (hipEventCreate(&t->gn_ev[k]) != hipSuccess) { (void)hipGetLastError(); t->gn_choice = 0; return 0; }
+        t->gn_events = true;
+    }
+    const int c = t->gn_count++;
+    if (c == 3) *ev_before = t->gn_ev[0];
+    if (c == 4) *ev_after = t->gn_ev[1];
+    if (c == 7) *ev_before = t->gn_ev[2];
+    if (c == 8) *ev_after = t->gn_ev[3];
+    if (c <= 4) return 0;
+    if (c <= 8) return 1;
+    if (hipEventQuery(t->gn_ev[1]) == hipSuccess && hipEventQuery(t->gn_ev[3]) == hipSuccess) {
+        float a = 0.f, b = 0.f;
+        if (hipEventElapsedTime(&a, t->gn_ev[0], t->gn_ev[1]) == hipSuccess &&
+            hipEventElapsedTime(&b, t->gn_ev[2], t->gn_ev[3]) == hipSuccess && a > 0.f && b > 0.f)
+            t->gn_choice = b < 0.98f * a ? 1 : 0;
+        else
+            t->gn_choice = 0;
+        return t->gn_choice;
+    }
+    (void)hipGetLastError();     // hipErrorNotReady is not an error of this call
+    return 0;
+}
+
 template <int Q, bool STATS>
 int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
                  unsigned long long* d_stats, hipStream_t stream) {
@@ -1345,6 +1389,7 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
         const int steal_arg = steal_min | (opt.split_steal << 16);   // trip thresholds: ordinary | split blocks
         const uint32_t* order = nullptr;
         uint32_t* cost = nullptr;
+        hipEvent_t gn_after = nullptr;      // node-flavour tuner: event to record behind this launch
         if (!STATS) sched_acquire(bvh, opt, stream, nblocks_direct, split, &order, &cost);
         const int64_t nslots = nblocks_direct + (order ? 8 * (split + 2 * split4) : 0);
         // ... and with split blocks the pruning queries take 8x8 tiles at any size
@@ -1376,7 +1421,30 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
             }
         } else
         if (steal) {
-            if (compact)
+            bool steal_launched = false;
+            // Closest / first can walk the 32-byte grid nodes like the streaming launch does: two gathers
+            // per visit instead of four.  It pays where the lanes of a wave are on different deep nodes
+            // (headline -2...-5 %, 5.2 M / 21 M triangles -6 / -8 %) and costs where they share lines (C2
+            // +14 %, the shell scene +1.5...+4 %); any-hit loses 3 % and keeps the exact nodes.  Option
+            // grid_nodes: 0 never, 1 measured per batch (gn_pick), 2 always.
+            bool qn = opt.grid_nodes == 2;
+            hipEvent_t ev_before = nullptr;
+            if (opt.grid_nodes == 1 && (Q == TR_Q_CLOSEST || Q == TR_Q_FIRST) && (compact || deep) && opt.adaptive)
+                qn = gn_pick(bvh, stream, split > 0, nblocks_direct * 8 + Q, &ev_before, &gn_after) != 0;
+            if (ev_before) (void)hipEventRecord(ev_before, stream);
+            if constexpr (Q == TR_Q_CLOSEST || Q == TR_Q_FIRST) {
+                if (qn && compact) {
+                    hipLaunchKernelGGL((k_query_direct<Q, false, true, 128, 1, false, true>), dim3((unsigned)nslots), dim3(128), 0, stream,
+                                       view, rf, out, xc, scramble, tile_w, steal_arg, order, (int)split, cost, d_stats, sel);
+                    steal_launched = true;
+                } else if (qn && deep) {
+                    hipLaunchKernelGGL((k_query_direct<Q, false, true, 128, 1, true, true>), dim3((unsigned)nslots), dim3(128), 0, stream,
+                                       view, rf, out, xc, scramble, tile_w, steal_arg, order, (int)split, cost, d_stats, sel);
+                    steal_launched = true;
+                }
+            }
+            if (steal_launched) {
+            } else if (compact)
                 hipLaunchKernelGGL((k_query_direct<Q, false, true, 128, 1>), dim3((unsigned)nslots), dim3(128), 0, stream,
                                    view, rf, out, xc, scramble, tile_w, steal_arg, order, (int)split, cost, d_stats, sel);
             else if (deep)
@@ -1393,6 +1461,7 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
         if (cost)
             hipLaunchKernelGGL(k_sched_sort, dim3(1), dim3(1024), 0, stream, cost, cost + TR_SCHED_MAX,
                                (int)nblocks_direct, xc, (int)split, (int)split4);
+        if (gn_after) (void)hipEventRecord(gn_after, stream);
     }
     TR_HIP_TRY(hipGetLastError());
     return TR_OK;
