@@ -337,9 +337,23 @@ def run_rank(args):
 
     if rank == 0:
         value = n_total * args.steps / elapsed / 1e6
-        bvh_bytes = info["node_bytes"] + info["tri_bytes"]
+        # the node array the timed launches walked: the exact 64-byte nodes or the 32-byte grid nodes
+        # (the streaming launch always, the direct closest launch when the library measured them
+        # faster: tr_bvh_last_launch) -- "one read of the BVH" counts the arrays that kernel can touch
+        grid_nodes = False
+        if not stub:
+            if args.workload == "c5ii":
+                grid_nodes = True
+            else:
+                try:
+                    grid_nodes = bool(r.as_wrapper.last_launch()["grid_nodes"])
+                except Exception:
+                    grid_nodes = False
+        node_bytes_used = info["num_nodes"] * 32 if grid_nodes else info["node_bytes"]
+        bvh_bytes = node_bytes_used + info["tri_bytes"]
         algo_bytes = n * BYTES_PER_RAY_CLOSEST + bvh_bytes          # per launch (= per rank and step)
         achieved = algo_bytes / (kernel_avg_ms * 1e-3) / 1e9
+        algo_bytes_exact = n * BYTES_PER_RAY_CLOSEST + info["node_bytes"] + info["tri_bytes"]
         compulsory = n * BYTES_PER_RAY_CLOSEST / (kernel_avg_ms * 1e-3) / 1e9
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -376,10 +390,14 @@ def run_rank(args):
                          "kernel": "k_query_direct<CLOSEST>", "kernel_avg_ms": round(kernel_avg_ms, 4),
                          "kernel_min_ms": round(kernel_ms[0], 4), "first_call_ms": round(first_call_ms, 4),
                          "algorithmic_bytes": int(algo_bytes),
+                         "node_flavour": "32-byte grid nodes" if grid_nodes else "exact 64-byte nodes",
+                         "frac_on_exact_node_bytes": round(algo_bytes_exact / (kernel_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
                          "compulsory_frac": round(compulsory / HBM_PEAK_GBPS, 5),
-                         "note": "achieved = (50 B/ray compulsory I/O + one read of the BVH arena) per launch / "
+                         "note": "achieved = (50 B/ray compulsory I/O + one read of the node and triangle arrays the launch walks) per launch / "
                                  "event-timed kernel_avg_ms; compulsory_frac counts the 50 B/ray only; the path is "
-                                 "cache-latency / instruction-issue bound, not HBM-bandwidth bound (DESIGN.md 5)"},
+                                 "cache-latency / instruction-issue bound, not HBM-bandwidth bound (DESIGN.md 5); "
+                                 "frac_on_exact_node_bytes = the same time against round 1's numerator (64-byte nodes), "
+                                 "for comparison across rounds only"},
         }
         if gather_on:
             res["roofline"]["note"] += "; kernel_avg_ms here includes the result gather"

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define TR_ABI_VERSION 4
+#define TR_ABI_VERSION 5
 #define TR_MAX_ANYHIT_SIZE 8 /* LaunchParams.h:8  (per-ray cap of intersects_location) */
 #define TR_MAX_SIZE_LENGTH 4 /* LaunchParams.h:9  (ray tensors have <= 4 dims)         */
 #define TR_MAX_HITS_CAP 32   /* largest `cap` tr_intersects_location_fill accepts      */
@@ -77,6 +77,21 @@ typedef struct tr_trace_stats {
     uint64_t climb_steps;   /* parent-link loads while backtracking */
 } tr_trace_stats;
 
+/* How the last direct-launch query of a handle was shaped (diagnostics; none of it changes results). */
+typedef struct tr_launch_info {
+    int64_t rays;           /* rays of the batch                                              */
+    int64_t blocks;         /* ray blocks of 128 (block_size) rays                            */
+    int64_t slots;          /* launch slots = blocks + extra slots of split blocks            */
+    int32_t query;          /* TR_Q_* of the launch                                           */
+    int32_t shape;          /* 0 plain, 1 stealing, 2 unordered two-phase schedule            */
+    int32_t tile_rows_lg;   /* 0: 64 rays of one row per wave, 1: 2x32, 2: 4x16, 3: 8x8 tiles  */
+    int32_t split_blocks;   /* blocks per XCD that were dealt to 2 / 4 launch slots           */
+    int32_t learned_order;  /* 1: the launch used a learned launch order                      */
+    int32_t grid_nodes;     /* 1: the launch walked the 32-byte grid nodes, 0: the exact ones */
+    int32_t addressing;     /* 0: 64-bit, 1: 32-bit offsets + 32-bit trail, 2: 32-bit offsets + 64-bit trail */
+    int32_t reserved;
+} tr_launch_info;
+
 /* -- runtime bring-up: replaces initOptix/createOptixContext/createOptixModule/
  *    createOptixPipelines/buildSBT (base.cpp:31-157, binding.cpp:41-48).  Idempotent,
  *    thread-safe; device < 0 selects the current HIP device.                             */
@@ -106,6 +121,10 @@ int64_t tr_bvh_serialized_size(const tr_bvh *bvh);
 int tr_bvh_serialize(const tr_bvh *bvh, void *h_buffer, int64_t size, void *stream);
 int tr_bvh_deserialize(const void *h_buffer, int64_t size, void *stream, tr_bvh **out);
 int tr_bvh_get_info(const tr_bvh *bvh, tr_bvh_info *info);
+/*    diagnostics: the shape of the last query of this handle that took the direct launch (a batch the
+ *    coherence probe handed to the streaming launch still reports the direct shape it enqueued).
+ *    TR_ERR_INVALID_ARG before the first such query.                                          */
+int tr_bvh_last_launch(const tr_bvh *bvh, tr_launch_info *info);
 /*    test hook: copy the traversal arrays to HOST buffers (any may be NULL).
  *    nodes: num_nodes*16 words (64 B), links: num_nodes*2 int32, tris: num_tris*12 words. */
 int tr_bvh_download(const tr_bvh *bvh, void *h_nodes, void *h_links, void *h_tris,

@@ -494,3 +494,36 @@ def test_large_meshes_deep_trees_and_arrays_above_4gib(device, subdiv):
     r2 = make(v, f, device)
     hit2, front2, tri2, loc2, uv2 = r2.intersects_closest(ot, dt)
     assert torch.equal(tri2, tri) and torch.equal(loc2, loc) and torch.equal(uv2, uv) and torch.equal(front2, front)
+
+
+def test_last_launch_reports_the_shape_and_the_measured_node_flavour(device):
+    """tr_bvh_last_launch: shape of the last direct launch; with grid_nodes = 0 / 2 the stealing closest
+    launch reports the exact / grid nodes, with 1 it settles on one of them after the timed launches,
+    and every flavour gives the oracle's answers."""
+    import triro.backend.ops as hops
+    v, f = W.icosphere(5)
+    v = W.displaced(v, seed=11, amplitude=0.08)
+    r = make(v, f, device)
+    R = OracleIntersector(v, f, 1)
+    o, d = W.pinhole_grid(320, 256, distance=2.5)
+    ot, dt = T(o, device), T(d, device)
+    exp = R.closest_raw(o.reshape(-1, 3), d.reshape(-1, 3))
+    try:
+        for gn in (0, 2, 1):
+            hops.set_option("grid_nodes", gn)
+            for rep in range(14):
+                got = [g.reshape((-1,) + tuple(g.shape[2:])) for g in r.intersects_closest(ot, dt)]
+                assert_closest_bitexact(got, exp, f"grid_nodes={gn} launch {rep}")
+                assert np.array_equal(r.intersects_first(ot, dt).cpu().numpy().reshape(-1), exp[2])
+            torch.cuda.synchronize()
+            r.intersects_closest(ot, dt)
+            li = r.as_wrapper.last_launch()
+            assert li["rays"] == 320 * 256 and li["blocks"] == 640 and li["query"] == 2 and li["shape"] == 1
+            assert li["learned_order"] == 1 and li["slots"] >= li["blocks"] and li["addressing"] in (1, 2)
+            if gn == 0: assert li["grid_nodes"] == 0
+            if gn == 2: assert li["grid_nodes"] == 1
+        r.intersects_count(ot, dt)
+        li = r.as_wrapper.last_launch()
+        assert li["query"] == 3 and li["shape"] == 2 and li["grid_nodes"] == 1 and li["tile_rows_lg"] == 3
+    finally:
+        hops.set_option("grid_nodes", 1)

@@ -287,6 +287,15 @@ int tr_bvh_destroy(tr_bvh* bvh) {
     return status;
 }
 
+int tr_bvh_last_launch(const tr_bvh* bvh, tr_launch_info* info) {
+    if (!bvh || !info) return tr_fail(TR_ERR_INVALID_ARG, "null argument");
+    if (!bvh->sched_mutex) return tr_fail(TR_ERR_INVALID_ARG, "handle without scheduling state");
+    std::lock_guard<std::mutex> lock(*bvh->sched_mutex);
+    if (!bvh->have_last_launch) return tr_fail(TR_ERR_INVALID_ARG, "no direct launch recorded for this handle yet");
+    *info = bvh->last_launch;
+    return TR_OK;
+}
+
 int tr_bvh_get_info(const tr_bvh* bvh, tr_bvh_info* info) {
     if (!bvh || !info) return tr_fail(TR_ERR_INVALID_ARG, "null argument");
     info->device = bvh->device;

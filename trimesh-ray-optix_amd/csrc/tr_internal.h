@@ -72,6 +72,8 @@ struct tr_bvh {
     // queried this handle, so launches on different streams never share hint buffers.
     tr_sched_slot sched[TR_SCHED_SLOTS];
     std::mutex* sched_mutex = nullptr;
+    tr_launch_info last_launch = {};     // tr_bvh_last_launch (written under sched_mutex)
+    bool have_last_launch = false;
 };
 
 // per-device runtime state (tr_init) ------------------------------------------------------

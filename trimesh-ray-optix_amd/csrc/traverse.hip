@@ -1403,6 +1403,7 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
 #define TR_LAUNCH_DIRECT(C, B, D)                                                                          \
     hipLaunchKernelGGL((k_query_direct<Q, STATS, C, B, 0, D>), dim3((unsigned)nslots), dim3(B), 0, stream, \
                        view, rf, out, xc, scramble, tile_w, steal_min, order, (int)split, cost, d_stats, sel)
+        bool qn_used = false;          // set by the stealing branch below
         static const bool debug_launch = getenv("TRIRO_DEBUG_LAUNCH") != nullptr;
         if (debug_launch)
             fprintf(stderr, "[triro] query %d: rays %lld blocks %lld slots %lld tile 0x%x split %lld order %d cost %d steal %d unordered %d compact %d\n",
@@ -1432,6 +1433,7 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
             if (opt.grid_nodes == 1 && (Q == TR_Q_CLOSEST || Q == TR_Q_FIRST) && (compact || deep) && opt.adaptive)
                 qn = gn_pick(bvh, stream, split > 0, nblocks_direct * 8 + Q, &ev_before, &gn_after) != 0;
             if (ev_before) (void)hipEventRecord(ev_before, stream);
+            qn_used = qn && (Q == TR_Q_CLOSEST || Q == TR_Q_FIRST) && (compact || deep);
             if constexpr (Q == TR_Q_CLOSEST || Q == TR_Q_FIRST) {
                 if (qn && compact) {
                     hipLaunchKernelGGL((k_query_direct<Q, false, true, 128, 1, false, true>), dim3((unsigned)nslots), dim3(128), 0, stream,
@@ -1462,6 +1464,20 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
             hipLaunchKernelGGL(k_sched_sort, dim3(1), dim3(1024), 0, stream, cost, cost + TR_SCHED_MAX,
                                (int)nblocks_direct, xc, (int)split, (int)split4);
         if (gn_after) (void)hipEventRecord(gn_after, stream);
+        if (!STATS && bvh->sched_mutex) {
+            tr_bvh* mb = const_cast<tr_bvh*>(bvh);
+            std::lock_guard<std::mutex> lock(*mb->sched_mutex);
+            tr_launch_info& li = mb->last_launch;
+            li.rays = rf.n; li.blocks = nblocks_direct; li.slots = nslots; li.query = Q;
+            li.shape = unord ? 2 : (steal ? 1 : 0);
+            li.tile_rows_lg = tile_w ? (tile_w >> 28) & 3 : 0;
+            li.split_blocks = order ? (int32_t)split : 0;
+            li.learned_order = order != nullptr;
+            li.grid_nodes = qn_used || unord;
+            li.addressing = compact ? 1 : (deep ? 2 : 0);
+            li.reserved = 0;
+            mb->have_last_launch = true;
+        }
     }
     TR_HIP_TRY(hipGetLastError());
     return TR_OK;

@@ -30,7 +30,7 @@ MAX_ANYHIT_SIZE = 8   # LaunchParams.h:8
 MAX_SIZE_LENGTH = 4   # LaunchParams.h:9
 
 _LIB_NAME = "libtriro_hip.so"
-ABI_VERSION = 4     # TR_ABI_VERSION of include/triro_hip.h this binding was written against
+ABI_VERSION = 5     # TR_ABI_VERSION of include/triro_hip.h this binding was written against
 _lib = None
 _lib_error = None
 
@@ -46,6 +46,13 @@ class TrBvhInfo(C.Structure):
                 ("depth", C.c_int32), ("key_mode", C.c_int32), ("arena_bytes", C.c_int64),
                 ("node_bytes", C.c_int64), ("tri_bytes", C.c_int64),
                 ("aabb_min", C.c_float * 3), ("aabb_max", C.c_float * 3)]
+
+
+class TrLaunchInfo(C.Structure):
+    _fields_ = [("rays", C.c_int64), ("blocks", C.c_int64), ("slots", C.c_int64), ("query", C.c_int32),
+                ("shape", C.c_int32), ("tile_rows_lg", C.c_int32), ("split_blocks", C.c_int32),
+                ("learned_order", C.c_int32), ("grid_nodes", C.c_int32), ("addressing", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class TrTraceStats(C.Structure):
@@ -75,6 +82,7 @@ ABI = {
     "tr_bvh_serialize": (_int, [_vp, _vp, _i64, _vp]),
     "tr_bvh_deserialize": (_int, [_vp, _i64, _vp, C.POINTER(_vp)]),
     "tr_bvh_get_info": (_int, [_vp, C.POINTER(TrBvhInfo)]),
+    "tr_bvh_last_launch": (_int, [_vp, C.POINTER(TrLaunchInfo)]),
     "tr_bvh_download": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "tr_bvh_download_qnodes": (_int, [_vp, _vp, _vp, _vp]),
     "tr_intersects_any": (_int, [_vp, C.POINTER(TrRays), _vp, _vp]),

@@ -263,6 +263,12 @@ class OptixAccelStructureWrapper:
         self._inner = handle.value
         self.device_index = self.info()["device"]
 
+    def last_launch(self) -> dict:
+        """shape of the last query that took the direct launch (diagnostics; tr_bvh_last_launch)"""
+        li = hops.TrLaunchInfo()
+        hops._check(hops.get_module().tr_bvh_last_launch(self._inner, C.byref(li)))
+        return {k: int(getattr(li, k)) for k, _ in li._fields_ if k != "reserved"}
+
     def info(self) -> dict:
         inf = hops.TrBvhInfo()
         hops._check(hops.get_module().tr_bvh_get_info(self._inner, C.byref(inf)))
