@@ -10,8 +10,11 @@ test/performance_test.py:54-57); rays and BVH are resident in HBM before the tim
 Workloads
   c5i  (default, the metric's config): one 1024x1024 pinhole ray batch per GPU against the
        1 310 720-triangle headline mesh.  N > 1: every rank owns a BVH replica
-       and its own 1024^2 batch -> "scaling": "weak" (`--gather` adds the RCCL gather of the
-       results to rank 0 to the timed region).
+       and its own 1024^2 batch -> "scaling": "weak"; `--scaling strong` cuts ONE 1024^2 batch into
+       N row bands instead.  For N > 1 the results are gathered to rank 0 INSIDE the timed region
+       ("all outputs resident on the caller's GPU"; `--no-gather` leaves them in place):
+       12-byte packed records over RCCL, expanded on rank 0 (triro.ray.sharded), step k's exchange
+       overlapping step k+1's trace.
   c5ii (BASELINE.json config 5): ONE batch of 100 000 000 hash rays (seed 99) split into N
        contiguous shards (triro.ray.sharded.shard_bounds), BVH replicated, results gathered to
        rank 0 INSIDE the timed region -> "scaling": "strong".
@@ -49,7 +52,11 @@ def parse(argv=None):
     ap.add_argument("--res", type=int, default=1024, help="c5i: ray grid is res x res")
     ap.add_argument("--rays", choices=["pinhole", "hash"], default="pinhole", help="c5i ray family")
     ap.add_argument("--total-rays", type=int, default=C5II_RAYS, help="c5ii: size of the one sharded batch")
-    ap.add_argument("--gather", action="store_true", help="c5i: gather results to rank 0 inside the timed region")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="c5i with N > 1: weak = one res x res batch per GPU (default), strong = ONE res x res batch cut into N row bands")
+    ap.add_argument("--gather", action="store_true", help="(default for N > 1) results are gathered to rank 0 inside the timed region")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: leave every rank's results on its own GPU (no exchange)")
+    ap.add_argument("--chunks", type=int, default=0, help="N > 1: chunks per shard of the trace / gather pipeline (0 = auto)")
     ap.add_argument("--min-warmup-ms", type=float, default=50.0, help="keep warming up until this much time has passed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-companions", action="store_true", help="skip the cold / moving-camera / gather-ceiling companions")
@@ -212,10 +219,31 @@ def run_rank(args):
     v, f = W.headline_mesh(args.subdiv)
     rad = float(np.linalg.norm(v, axis=1).max())
     o_np = d_np = None
-    if args.workload == "c5i":
+    strong_c5i = args.workload == "c5i" and args.scaling == "strong" and world > 1
+    bshape = None                      # shape of the gathered batch on rank 0
+    if strong_c5i:
+        # ONE res x res batch, rank r traces its band of rows (whole rows, so the band keeps the image
+        # launch shapes) -- or its flat range when the rows do not divide
+        n_total = args.res * args.res
+        lo_ray, hi_ray = shard_bounds(n_total, world, rank)
+        n = hi_ray - lo_ray
+        bshape = (args.res, args.res)
+        if args.rays == "pinhole":
+            o_np, d_np = W.pinhole_grid(args.res, args.res, distance=2.5 * rad)
+            if args.res % world == 0:
+                o_np, d_np = o_np[lo_ray // args.res:hi_ray // args.res], d_np[lo_ray // args.res:hi_ray // args.res]
+            else:
+                o_np, d_np = o_np.reshape(-1, 3)[lo_ray:hi_ray], d_np.reshape(-1, 3)[lo_ray:hi_ray]
+            origins = torch.from_numpy(np.ascontiguousarray(o_np)).to(dev)
+            dirs = torch.from_numpy(np.ascontiguousarray(d_np)).to(dev)
+        else:
+            lo, hi = v.min(0) * 1.5, v.max(0) * 1.5
+            origins, dirs = W.hash_rays_torch(n, 99, lo, hi, start=lo_ray, device=dev)
+    elif args.workload == "c5i":
         n_total = args.res * args.res * world
         n = args.res * args.res
         lo_ray = rank * n
+        bshape = (world * args.res, args.res) if args.rays == "pinhole" else (n_total,)
         if args.rays == "pinhole":
             o_np, d_np = W.pinhole_grid(args.res, args.res, distance=2.5 * rad)
             # every rank traces its own batch: same camera, rolled by `rank` rows so shards differ
@@ -246,21 +274,32 @@ def run_rank(args):
     build_ms = (time.perf_counter() - t0) * 1e3
     info = r.bvh_info()
 
-    gather_on = dist_on and (args.workload == "c5ii" or args.gather)
+    gather_on = dist_on and world > 1 and not args.no_gather
     S = ShardedRayMeshIntersector(r) if dist_on else None
     lead = origins.dim() - 1
+    packed_ok = gather_on and S._can_pack()       # the real tracer; stand-ins take the per-output exchange
+    pending = []
 
     def flat(x):
         return x.reshape(n, *x.shape[lead:])
 
     def step():
-        out = r.intersects_closest(origins, dirs)
-        if gather_on:
-            if args.workload == "c5ii":
-                # ONE batch of n_total rays: chunks land in slices of rank 0's full-size outputs
-                return [S._gather_fixed(flat(x), n_total, 0) for x in out]
-            # c5i + --gather: each rank's own batch, collected on rank 0 (world x n rows)
-            return [S._gather_fixed(flat(x), n * world, 0) for x in out]
+        """one call; with the gather on, the pipeline is double-buffered: step k's exchange + expansion
+        (RCCL stream, side stream) overlap step k+1's trace, and step() hands back step k-1's outputs"""
+        if not gather_on:
+            return r.intersects_closest(origins, dirs)
+        if not packed_ok:
+            out = r.intersects_closest(origins, dirs)
+            # chunks land in slices of rank 0's full-size outputs (c5ii / strong: ONE batch; weak: world x n rows)
+            return [S._gather_fixed(flat(x), n_total, 0) for x in out]
+        pending.append(S.closest_of_shard_async(origins, dirs, n_total, batch_shape=bshape, dst=0,
+                                                chunks=args.chunks or None))
+        return pending.pop(0).wait() if len(pending) > 1 else None
+
+    def drain():
+        out = None
+        while pending:
+            out = pending.pop(0).wait()
         return out
 
     def barrier():
@@ -294,8 +333,12 @@ def run_rank(args):
     sync()
     t_first = time.perf_counter()
     out = step()                      # very first call: lazy initialisation + no learned launch order yet
+    if pending:
+        out = drain()
     sync()
     first_call_ms = (time.perf_counter() - t_first) * 1e3
+    # what the cold call returned: the steady-state launches of the timed region must reproduce it bit for bit
+    first_out = [x.clone() for x in out] if out is not None and out[0] is not None else None
     # Everything that would leave the GPU idle between warm-up and the timed region (creating the
     # event objects, a garbage collection) happens BEFORE the warm-up: after a few milliseconds of
     # idleness the chip needs ~50 launches to come back to its steady clock, which is all a
@@ -313,14 +356,18 @@ def run_rank(args):
         w_done += 1
         if w_done % 8 == 0:
             sync()
+    drain()
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
         if ev[k]:
             ev[k][0].record()
-        out = step()
+        o_k = step()
+        out = o_k if o_k is not None else out
         if ev[k]:
             ev[k][1].record()
+    if pending:
+        out = drain()                 # the last step's exchange is inside the timed region
     barrier()
     elapsed = time.perf_counter() - t0
     gc.enable()
@@ -335,6 +382,11 @@ def run_rank(args):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
 
+    # the last timed step against the cold first call (different launch order, split set, tiles and
+    # node flavour; same rays): any difference is a bug in a "speed only" mechanism
+    verified = None
+    if first_out is not None and out is not None and out[0] is not None:
+        verified = all(torch.equal(a, b) for a, b in zip(out, first_out))
     if rank == 0:
         value = n_total * args.steps / elapsed / 1e6
         # the node array the timed launches walked: the exact 64-byte nodes or the 32-byte grid nodes
@@ -357,37 +409,58 @@ def run_rank(args):
         compulsory = n * BYTES_PER_RAY_CLOSEST / (kernel_avg_ms * 1e-3) / 1e9
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if args.workload == "c5i" and args.res == 1024 and args.rays == "pinhole" and os.path.exists(tpath):
+        default_c5i = args.workload == "c5i" and args.res == 1024 and args.rays == "pinhole" and not strong_c5i
+        default_c5ii = args.workload == "c5ii" and args.total_rays == C5II_RAYS
+        if (default_c5i or default_c5ii) and os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                traffic = tj.get("closest_hbm_bytes_per_launch")
+                if default_c5i:
+                    traffic = tj.get("closest_hbm_bytes_per_launch")
+                else:       # per launch of one rank: scaled from the profiled 12.5 M-ray shard to this rank's rays
+                    per_ray = tj.get("c5ii_hbm_bytes_per_ray")
+                    traffic = int(per_ray * n) if per_ray else None
                 traffic_src = f"profiles/traffic.json (static: rocprofv3 PMC passes of {tj.get('round', 'an earlier round')}, not measured in this run)"
             except Exception:
                 traffic = None
-        hit0 = out[0] if out[0] is not None else None
-        if args.workload == "c5i":
+        hit0 = out[0] if out is not None and out[0] is not None else None
+        gather_txt = ""
+        if gather_on:
+            gather_txt = ", results gathered to rank 0 inside the timed region"
+            if packed_ok:
+                gather_txt += " (12 B/ray packed records over RCCL, expanded on rank 0, exchange of step k overlaps trace of step k+1)"
+        metric = "Mrays/s closest-hit, 1M-tri mesh, 1024^2 ray batch"
+        kernel_name = "k_query_direct<CLOSEST>"
+        if strong_c5i:
+            wl = (f"C5(i): icosphere({args.subdiv})+displacement seed 0, {len(f)} tris; ONE {args.res}x{args.res} "
+                  f"{args.rays} batch cut into {world} row bands; intersects_closest (stream_compaction=False)")
+            par = f"ray-sharded x{world}, BVH replicated" + gather_txt
+            scaling = "strong"
+        elif args.workload == "c5i":
             wl = (f"C5(i): icosphere({args.subdiv})+displacement seed 0, {len(f)} tris; {args.res}x{args.res} "
                   f"{args.rays} rays per GPU; intersects_closest (stream_compaction=False)")
-            par = f"ray-sharded x{world}, BVH replicated" + (", results gathered to rank 0" if gather_on else "")
+            par = f"ray-sharded x{world}, BVH replicated" + gather_txt
             scaling = "weak"
         else:
+            metric = "Mrays/s closest-hit, 1M-tri mesh, 100M-ray batch (BASELINE.json config 5; not the 1024^2 headline batch)"
+            kernel_name = "k_query_stream<CLOSEST>"
             wl = (f"C5(ii): icosphere({args.subdiv})+displacement seed 0, {len(f)} tris; ONE batch of {n_total} hash rays "
                   f"(seed 99) in {world} contiguous shard(s); intersects_closest (stream_compaction=False)")
-            par = f"ray-sharded x{world}, BVH replicated" + (", results gathered to rank 0 inside the timed region" if gather_on else "")
+            par = f"ray-sharded x{world}, BVH replicated" + gather_txt
             scaling = "strong"
         res = {
-            "metric": "Mrays/s closest-hit, 1M-tri mesh, 1024^2 ray batch",
+            "metric": metric,
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32",
             "data": "synthetic" if not stub else "stub tracer: launcher self-test, NOT a measurement",
+            "verified": verified,
             "config": {"workload": wl, "rays_per_gpu": n, "rays_total": n_total, "triangles": int(len(f)),
                        "parallelism": par, "warmup_steps_done": w_done,
                        "bvh_depth": info["depth"], "bvh_bytes": int(bvh_bytes), "bvh_build_ms": round(build_ms, 2),
                        "hit_fraction": round(float(hit0.float().mean().item()), 4) if hit0 is not None else None},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "k_query_direct<CLOSEST>", "kernel_avg_ms": round(kernel_avg_ms, 4),
+                         "kernel": kernel_name, "kernel_avg_ms": round(kernel_avg_ms, 4),
                          "kernel_min_ms": round(kernel_ms[0], 4), "first_call_ms": round(first_call_ms, 4),
                          "algorithmic_bytes": int(algo_bytes),
                          "node_flavour": "32-byte grid nodes" if grid_nodes else "exact 64-byte nodes",
@@ -400,7 +473,9 @@ def run_rank(args):
                                  "for comparison across rounds only"},
         }
         if gather_on:
-            res["roofline"]["note"] += "; kernel_avg_ms here includes the result gather"
+            res["roofline"]["note"] += ("; kernel_avg_ms here is the caller-stream time of a step (trace; the exchange and the "
+                                        "expansion run on RCCL's and a side stream)" if packed_ok else
+                                        "; kernel_avg_ms here includes the result gather")
         single = world == 1 and not stub
         if single and not args.no_companions and args.workload == "c5i":
             # honest companions of the steady-state figure: the same launch
@@ -445,10 +520,13 @@ def run_rank(args):
                 m = min(n, 1 << 20)
                 res["cpu_baseline"] = cpu_baseline(v, f, origins[:m].cpu().numpy(), dirs[:m].cpu().numpy())
         print(json.dumps(res), flush=True)
+    if verified is False:
+        print("bench.py: the last timed step's outputs differ from the first call's -- a scheduling hint changed results",
+              file=sys.stderr)
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
-    return 0
+    return 3 if verified is False else 0
 
 
 def main(argv=None):

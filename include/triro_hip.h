@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define TR_ABI_VERSION 5
+#define TR_ABI_VERSION 6
 #define TR_MAX_ANYHIT_SIZE 8 /* LaunchParams.h:8  (per-ray cap of intersects_location) */
 #define TR_MAX_SIZE_LENGTH 4 /* LaunchParams.h:9  (ray tensors have <= 4 dims)         */
 #define TR_MAX_HITS_CAP 32   /* largest `cap` tr_intersects_location_fill accepts      */
@@ -147,6 +147,26 @@ int tr_intersects_closest(const tr_bvh *bvh, const tr_rays *rays, uint8_t *d_hit
                           uint8_t *d_front, int32_t *d_tri, float *d_loc, float *d_uv,
                           void *stream);
 int tr_intersects_count(const tr_bvh *bvh, const tr_rays *rays, int32_t *d_count, void *stream);
+
+/* -- closest hit in 12 bytes per ray (ABI 6; no counterpart in the reference, which is single-GPU:
+ *    base.cpp:15-17).  A ray-sharded run gathers results over xGMI; the five dense outputs of
+ *    intersectsClosest (ray.cpp:231-289) are 26 B/ray, but everything in them is a function of
+ *    (triangle, front flag, u, v) and the mesh:  tri = face index | front << 30, 0xffffffff on a miss
+ *    (face indices must be below 2^30); u, v = barycentric weights of face vertices 1 and 2.
+ *    tr_closest_expand turns such records back into hit / front / tri / loc / uv with the operations
+ *    tr_intersects_closest itself uses (loc = u*V1 + v*V2 + (1-u-v)*V0, uv = (1-u-v, u):
+ *    shaders.cu:143-149) on d_vertices [nv,3] / d_faces [nf,3] -- the arrays the BVH was built
+ *    from -- so expand(packed) is bit-identical to the dense outputs.  Any output may be NULL.
+ *    Works on whatever device the pointers live on (no BVH handle involved).                    */
+typedef struct tr_packed_hit {
+    uint32_t tri;
+    float u, v;
+} tr_packed_hit;
+int tr_intersects_closest_packed(const tr_bvh *bvh, const tr_rays *rays, tr_packed_hit *d_packed,
+                                 void *stream);
+int tr_closest_expand(const tr_packed_hit *d_packed, int64_t n, const float *d_vertices, int64_t nv,
+                      const int32_t *d_faces, int64_t nf, uint8_t *d_hit, uint8_t *d_front,
+                      int32_t *d_tri, float *d_loc, float *d_uv, void *stream);
 
 /* -- multi-hit (intersectsLocation, ray.cpp:324-378):
  *    tr_hits_scan replaces the torch glue of ray.cpp:333-342: d_offsets[i] = exclusive

@@ -14,14 +14,38 @@ class StubTracer:
     def bvh_info(self):
         return {"depth": 0, "node_bytes": 64 * max(self.nf - 1, 0), "tri_bytes": 48 * self.nf}
 
-    def intersects_closest(self, origins, directions, stream_compaction=False):
+    # 12-byte records {tri | front << 30 (-1: miss), s bits, 0} and their expansion: the shape of the
+    # packed pipeline of triro.ray.sharded; intersects_closest is expand(packed), so both paths agree
+    def intersects_closest_packed(self, origins, directions, out=None):
         b = origins.shape[:-1]
-        s = (origins.expand(*b, 3) * 3.0 + directions).sum(-1)
+        s = (origins.expand(*b, 3) * 3.0 + directions).sum(-1).reshape(-1).to(torch.float32)
         hit = s > 0
         tri = (s.abs() * 1000).to(torch.int32) % max(self.nf, 1)
-        loc = origins.expand(*b, 3) + directions
-        uv = directions[..., :2].clone()
-        return hit, ~hit, tri, loc.contiguous(), uv
+        rec = torch.zeros((s.numel(), 3), dtype=torch.int32)
+        rec[:, 0] = torch.where(hit, tri | ((tri & 1) << 30), torch.full_like(tri, -1))
+        rec[:, 1] = s.view(torch.int32)
+        if out is None:
+            return rec
+        out.copy_(rec)
+        return out
+
+    def closest_expand(self, packed, batch_shape=None, outs=None):
+        hit = packed[:, 0] >= 0
+        tri = torch.where(hit, packed[:, 0] & 0x3fffffff, torch.full_like(packed[:, 0], -1))
+        front = hit & (((packed[:, 0] >> 30) & 1) == 1)
+        s = torch.where(hit, packed[:, 1].contiguous().view(torch.float32), torch.zeros(len(hit)))
+        loc = torch.stack([s, 2 * s, 3 * s], -1)
+        uv = torch.stack([s, -s], -1)
+        res = (hit, front, tri, loc, uv)
+        if outs is not None:
+            for dst_, src_ in zip(outs, res):
+                dst_.copy_(src_)
+            return outs
+        b = tuple(batch_shape) if batch_shape is not None else (len(hit),)
+        return hit.reshape(b), front.reshape(b), tri.reshape(b), loc.reshape(*b, 3), uv.reshape(*b, 2)
+
+    def intersects_closest(self, origins, directions, stream_compaction=False):
+        return self.closest_expand(self.intersects_closest_packed(origins, directions), origins.shape[:-1])
 
 
 def make(v, f, device):

@@ -47,6 +47,29 @@ def test_gpus2_weak_scaling_default_workload():
     assert r["config"]["rays_per_gpu"] == 64 * 64 and r["config"]["rays_total"] == 2 * 64 * 64
 
 
+@pytest.mark.timeout(300)
+def test_gpus2_gathers_by_default_and_strong_scaling_of_one_image():
+    """N > 1: the gather to rank 0 is inside the timed region by default (packed records, double-buffered
+    pipeline: bench.py's `verified` compares the last step with the first call); `--scaling strong` cuts ONE
+    res x res batch into row bands; `--no-gather` leaves the results in place."""
+    common = ["--gpus", "2", "--backend", "gloo", "--stub", "bench_stub:make", "--subdiv", "2", "--res", "64",
+              "--steps", "3", "--warmup", "1", "--min-warmup-ms", "0"]
+    p = run_bench(*common)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads(p.stdout.strip().splitlines()[-1])
+    assert r["scaling"] == "weak" and r["config"]["rays_total"] == 2 * 64 * 64 and r["verified"] is True
+    assert "gathered to rank 0 inside the timed region (12 B/ray packed" in r["config"]["parallelism"]
+    p = run_bench(*common, "--scaling", "strong")
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads(p.stdout.strip().splitlines()[-1])
+    assert r["scaling"] == "strong" and r["config"]["rays_total"] == 64 * 64 and r["config"]["rays_per_gpu"] == 32 * 64
+    assert r["verified"] is True and "row bands" in r["config"]["workload"]
+    p = run_bench(*common, "--no-gather")
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads(p.stdout.strip().splitlines()[-1])
+    assert "gathered" not in r["config"]["parallelism"] and r["verified"] is True
+
+
 @pytest.mark.skipif(torch.cuda.device_count() >= 2, reason="needs a node with fewer than 2 GPUs")
 def test_gpus2_refuses_when_fewer_devices_are_visible():
     p = run_bench("--gpus", "2", "--steps", "2", "--warmup", "1")

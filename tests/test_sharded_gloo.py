@@ -22,6 +22,43 @@ class CpuLocal:
 
     def __init__(self, v, f):
         self.R = OracleIntersector(v, f, 1, threads=2)
+        self.v, self.f = np.asarray(v, np.float32), np.asarray(f, np.int64)
+        self.packed_calls = []       # (rays, shape) of every packed trace: the chunking under test
+
+    # the packed pipeline of triro.ray.sharded: 12 B/ray records and their expansion.  The stand-in
+    # keeps (tri | front << 30, w bits, u bits) and re-derives loc from them in numpy -- consistent with
+    # its own intersects_closest below (which is expand(packed)), not with the product's arithmetic:
+    # what is tested here is the exchange, the chunking and the row bookkeeping.
+    def intersects_closest_packed(self, o, d, out=None):
+        self.packed_calls.append((o.numel() // 3, tuple(o.shape)))
+        hit, front, tri, loc, uv = self.R.intersects_closest(o.numpy().reshape(-1, 3), d.numpy().reshape(-1, 3))
+        rec = np.empty((len(hit), 3), np.int32)
+        rec[:, 0] = np.where(hit, tri | (front.astype(np.int32) << 30), -1)
+        rec[:, 1:] = np.ascontiguousarray(uv, np.float32).view(np.int32)
+        t = torch.from_numpy(rec)
+        if out is None:
+            return t
+        out.copy_(t)
+        return out
+
+    def closest_expand(self, packed, batch_shape=None, outs=None):
+        rec = packed.numpy()
+        hit = rec[:, 0] >= 0
+        tri = np.where(hit, rec[:, 0] & 0x3fffffff, -1).astype(np.int32)
+        front = hit & ((rec[:, 0] >> 30) & 1).astype(bool)
+        uv = np.ascontiguousarray(rec[:, 1:]).view(np.float32).copy()
+        w, u = uv[:, 0:1], uv[:, 1:2]
+        tv = self.v[self.f[np.where(hit, tri, 0)]]
+        loc = (w * tv[:, 0] + u * tv[:, 1] + (np.float32(1) - w - u) * tv[:, 2]).astype(np.float32)
+        loc[~hit] = 0
+        uv[~hit] = 0
+        res = self._t(hit, front, tri, loc, uv)
+        if outs is not None:
+            for dst_, src_ in zip(outs, res):
+                dst_.copy_(src_)
+            return outs
+        b = tuple(batch_shape) if batch_shape is not None else (len(hit),)
+        return (res[0].reshape(b), res[1].reshape(b), res[2].reshape(b), res[3].reshape(*b, 3), res[4].reshape(*b, 2))
 
     @staticmethod
     def _t(*xs):
@@ -37,7 +74,12 @@ class CpuLocal:
         return self._t(self.R.intersects_count(o.numpy(), d.numpy()))[0]
 
     def intersects_closest(self, o, d, stream_compaction=False):
-        return self._t(*self.R.intersects_closest(o.numpy(), d.numpy(), stream_compaction=stream_compaction))
+        if not stream_compaction:
+            return self.closest_expand(self.intersects_closest_packed(o, d), batch_shape=o.shape[:-1])
+        hit, front, tri, loc, uv = self.intersects_closest(o, d)
+        hit = hit.reshape(-1)
+        ridx = torch.arange(hit.numel(), dtype=torch.int32)[hit]
+        return hit.reshape(o.shape[:-1]), front.reshape(-1)[hit], ridx, tri.reshape(-1)[hit], loc.reshape(-1, 3)[hit], uv.reshape(-1, 2)[hit]
 
     def intersects_location(self, o, d):
         return self._t(*self.R.intersects_location(o.numpy(), d.numpy()))
@@ -54,7 +96,7 @@ def _worker(rank, world, port, q):
         v, f = W.nested_shells(2, radii=(1.0, 0.7, 0.5, 0.35, 0.2))
         o_np, d_np = W.pinhole_grid(37, 23)              # 851 rays: not divisible by world
         o, d = torch.from_numpy(np.ascontiguousarray(o_np)), torch.from_numpy(d_np)
-        S = ShardedRayMeshIntersector(CpuLocal(v, f))
+        S = ShardedRayMeshIntersector(CpuLocal(v, f), gather_mode="dense")
         ref = CpuLocal(v, f)
         # every allocation of the gather path is recorded: receives must land in the final
         # outputs (no padded per-rank buffers, no concatenation copies)
@@ -119,6 +161,56 @@ def _worker(rank, world, port, q):
             ok &= torch.equal(a, e)
         covered = sum(hi - lo for lo, hi in (shard_bounds(851, world, r) for r in range(world)))
         ok &= covered == 851 and shard_bounds(851, world, 0)[0] == 0
+        # ---- the packed, chunked, asynchronous closest-hit pipeline (round 3) ---------------------
+        P = ShardedRayMeshIntersector(CpuLocal(v, f))                 # gather_mode "packed" is the default
+        ok &= P._can_pack()
+        allocs.clear()
+        P._alloc = counting_alloc
+        got = P.intersects_closest(o, d, dst=0, chunks=3)             # ragged shards (426 / 425), 3 chunks each
+        lo_, hi_ = shard_bounds(851, world, rank)
+        ok &= [c[0] for c in P.local.packed_calls] == [shard_bounds(hi_ - lo_, 3, k)[1] - shard_bounds(hi_ - lo_, 3, k)[0] for k in range(3)]
+        if rank == 0:       # the full packed buffer + the five outputs; the other rank only its own records
+            ok &= allocs == [((851, 3), torch.int32), ((23, 37), torch.bool), ((23, 37), torch.bool), ((23, 37), torch.int32),
+                             ((23, 37, 3), torch.float32), ((23, 37, 2), torch.float32)]
+            for a, e in zip(got, exp):
+                ok &= torch.equal(a.reshape(e.shape), e)
+        else:
+            ok &= allocs == [((425, 3), torch.int32)] and got is None
+        for dst_, ch in ((1, 1), (None, 2), (None, 5)):
+            h = P.intersects_closest_async(o2, d2, dst=dst_, chunks=ch)     # equal shards: one collective per chunk
+            g2 = h.wait()
+            if dst_ is None or dst_ == rank:
+                for a, e in zip(g2, e2):
+                    ok &= torch.equal(a, e)
+            else:
+                ok &= g2 is None
+        # an image-shaped batch cut at row boundaries keeps its shape on every rank (tiles on the GPU)
+        o3_np, d3_np = W.pinhole_grid(37, 24)
+        o3, d3 = torch.from_numpy(np.ascontiguousarray(o3_np)), torch.from_numpy(d3_np)
+        P.local.packed_calls.clear()
+        g3 = P.intersects_closest(o3, d3, dst=0, chunks=4)
+        ok &= [c[1] for c in P.local.packed_calls] == [(3, 37, 3)] * 4
+        e3 = ref.intersects_closest(o3, d3)
+        if rank == 0:
+            ok &= g3[0].shape == (24, 37) and g3[3].shape == (24, 37, 3)
+            for a, e in zip(g3, e3):
+                ok &= torch.equal(a, e)
+        ok &= torch.equal(P.intersects_count(o3, d3, dst=None), ref.intersects_count(o3, d3))
+        # a rank that holds ONLY its shard (bench.py c5ii): closest_of_shard_async
+        h = P.closest_of_shard_async(fo[lo_:hi_], fd[lo_:hi_], 851, dst=0, chunks=2)
+        g4 = h.wait()
+        if rank == 0:
+            for a, e in zip(g4, exp):
+                ok &= torch.equal(a.reshape(e.shape), e)
+        # round 1's padded exchange stays selectable (fallback until the in-place path has run on RCCL)
+        Q = ShardedRayMeshIntersector(CpuLocal(v, f), gather_mode="padded")
+        g5 = Q.intersects_closest(o, d, dst=0)
+        l5 = Q.intersects_location(o, d, dst=None)
+        if rank == 0:
+            for a, e in zip(g5, exp):
+                ok &= torch.equal(a.reshape(e.shape), e)
+        for a, e in zip(l5, ref.intersects_location(fo, fd)):
+            ok &= torch.equal(a, e)
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

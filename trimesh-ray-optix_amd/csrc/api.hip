@@ -277,7 +277,7 @@ int tr_bvh_destroy(tr_bvh* bvh) {
             if (bvh->refit_temp && hipFree(bvh->refit_temp) != hipSuccess) status = tr_fail(TR_ERR_HIP, "hipFree(refit_temp)");
             for (int k = 0; k < TR_SCHED_SLOTS; k++) {
                 if (bvh->sched[k].buf && hipFree(bvh->sched[k].buf) != hipSuccess) status = tr_fail(TR_ERR_HIP, "hipFree(sched)");
-                for (int e = 0; e < 4; e++)
+                for (int e = 0; e < 8; e++)
                     if (bvh->sched[k].gn_ev[e]) (void)hipEventDestroy(bvh->sched[k].gn_ev[e]);
             }
         }
@@ -351,6 +351,10 @@ int tr_set_option(const char* name, int64_t value) {
         g_opts.v[k].store((int)value, std::memory_order_relaxed);
         return TR_OK;
     }
+    // options of launch shapes that no longer exist (round-1 refill kernel, early XCD map): accepted and
+    // ignored, so that callers written against ABI 2-3 keep working -- no option ever changed results
+    for (const char* retired : {"refill", "refill_min", "xcd_segments", "leaf_min"})
+        if (!strcmp(name, retired)) return TR_OK;
     return tr_fail(TR_ERR_INVALID_ARG, std::string("unknown option: ") + name);
 }
 

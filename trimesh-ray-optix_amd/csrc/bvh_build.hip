@@ -477,7 +477,7 @@ void tr_bvh_reset(tr_bvh* bvh) {
     bvh->frame = tr_qframe{{0.f, 0.f, 0.f}, {1.f, 1.f, 1.f}};
     bvh->num_tris = 0; bvh->num_nodes = 0; bvh->depth = 0; bvh->key_mode = 0;
     for (int k = 0; k < 3; k++) { bvh->aabb_min[k] = 0.f; bvh->aabb_max[k] = 0.f; }
-    for (int k = 0; k < TR_SCHED_SLOTS; k++) bvh->sched[k].nblocks = 0;
+    for (int k = 0; k < TR_SCHED_SLOTS; k++) { bvh->sched[k].nblocks = 0; bvh->sched[k].gn_reset(); }
 }
 
 int tr_build_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_t* d_faces,
@@ -503,7 +503,8 @@ int tr_build_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_
     // A learned launch order describes the rays, not the mesh: after a rebuild (an animation step,
     // `update_raw`) it is one frame stale, which is a far better hint than none -- keep it and
     // measure again on the next launches
-    for (int k = 0; k < TR_SCHED_SLOTS; k++) bvh->sched[k].launches = 0;
+    // (the node-flavour tuner starts over: its measurement windows are counted in launches of this mesh)
+    for (int k = 0; k < TR_SCHED_SLOTS; k++) { bvh->sched[k].launches = 0; bvh->sched[k].gn_reset(); }
     for (int k = 0; k < 3; k++) { bvh->aabb_min[k] = 0.f; bvh->aabb_max[k] = 0.f; }
     if (nf == 0) return TR_OK;
 

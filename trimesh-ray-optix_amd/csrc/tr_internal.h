@@ -43,10 +43,15 @@ struct tr_sched_slot {
     // node-flavour tuner of the stealing closest / first launches (grid_nodes = 1): two launches on
     // the exact nodes and two on the grid nodes are timed with events, the faster flavour stays
     int64_t gn_key = 0;     // (block count, query) the state below belongs to
-    int gn_count = 0;       // launches with this key
-    int gn_choice = -1;     // -1 undecided, 0 exact nodes, 1 grid nodes
+    int gn_count = 0;       // launches of the measurement in progress
+    int gn_choice = -1;     // -1 measuring, 0 exact nodes, 1 grid nodes
+    int gn_rounds = 0;      // completed measurements (the decision is final after two that agree, or three)
+    int gn_prev = -1;       // result of the previous measurement
+    int gn_since = 0;       // launches since the last decision
+    bool gn_final = false;
     bool gn_events = false;
-    hipEvent_t gn_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t gn_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    void gn_reset() { gn_key = 0; gn_count = 0; gn_choice = -1; gn_rounds = 0; gn_prev = -1; gn_since = 0; gn_final = false; }
 };
 
 // the opaque handle ---------------------------------------------------------------------

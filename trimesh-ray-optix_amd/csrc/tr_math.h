@@ -180,14 +180,24 @@ TR_HD bool tr_closer(float t, int32_t tri, float bt, int32_t btri) {
 }
 
 // outputs of a hit: shaders.cu:137-153.  loc = u*V1 + v*V2 + (1-u-v)*V0 (:143-146),
-// uv = (1-u-v, u) (:149)
-TR_HD void tr_hit_outputs(const tr_hit& h, float ax, float ay, float az, float bx, float by,
-                          float bz, float cx, float cy, float cz, float* loc, float* uv) {
-    float u = h.U / h.det, v = h.V / h.det;
+// uv = (1-u-v, u) (:149).  In two steps so that a result can travel as (triangle, u, v) -- 12 bytes
+// instead of 26 -- and be expanded elsewhere with the very same operations (tr_closest_expand).
+TR_HD void tr_hit_bary(const tr_hit& h, float& u, float& v) {
+    u = h.U / h.det;
+    v = h.V / h.det;
+}
+TR_HD void tr_bary_outputs(float u, float v, float ax, float ay, float az, float bx, float by,
+                           float bz, float cx, float cy, float cz, float* loc, float* uv) {
     float w = (1.0f - u) - v;
     loc[0] = fmaf(w, ax, fmaf(v, cx, u * bx));
     loc[1] = fmaf(w, ay, fmaf(v, cy, u * by));
     loc[2] = fmaf(w, az, fmaf(v, cz, u * bz));
     uv[0] = w;
     uv[1] = u;
+}
+TR_HD void tr_hit_outputs(const tr_hit& h, float ax, float ay, float az, float bx, float by,
+                          float bz, float cx, float cy, float cz, float* loc, float* uv) {
+    float u, v;
+    tr_hit_bary(h, u, v);
+    tr_bary_outputs(u, v, ax, ay, az, bx, by, bz, cx, cy, cz, loc, uv);
 }

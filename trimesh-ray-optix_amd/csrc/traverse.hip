@@ -38,6 +38,7 @@ struct QueryOut {
     int32_t* count;
     tr_hit_entry* hits;   // TR_Q_LOCATION: [n, cap] unsorted nearest hits (tr_topk<0>)
     int32_t cap;
+    tr_packed_hit* packed;   // TR_Q_CLOSEST: when set, 12 bytes per ray instead of the five arrays
 };
 
 // strided fetch of ray `idx`: the reference's getRay/getIndices (shaders.cu:27-63) with
@@ -78,6 +79,21 @@ __device__ __forceinline__ void write_result(const tr_bvh_view& b, const QueryOu
     } else if (Q == TR_Q_CLOSEST) {
         float loc[3] = {0.f, 0.f, 0.f}, uv[2] = {0.f, 0.f};
         uint8_t hit = 0, front = 0;
+        if (out.packed) {
+            // packed form (tr_intersects_closest_packed): {face | front << 30, u, v}; tr_closest_expand
+            // applies tr_bary_outputs to the same (u, v) and the same vertices -> the same bits
+            tr_packed_hit ph = {0xffffffffu, 0.f, 0.f};
+            if (res.best_face >= 0) {
+                tr_counters* nc = nullptr;
+                tr_tri t = tr_load_tri<false>(b, res.best_slot, nc);
+                tr_hit h; h.t = res.best_t;
+                tr_tri_duv(r, t.ax, t.ay, t.az, t.bx, t.by, t.bz, t.cx, t.cy, t.cz, h.det, h.U, h.V);
+                tr_hit_bary(h, ph.u, ph.v);
+                ph.tri = (uint32_t)res.best_face | (h.det > 0.f ? 0x40000000u : 0u);
+            }
+            out.packed[i] = ph;
+            return;
+        }
         if (res.best_face >= 0) {
             tr_counters* nc = nullptr;
             tr_tri t = tr_load_tri<false>(b, res.best_slot, nc);
@@ -1050,6 +1066,38 @@ __global__ __launch_bounds__(256) void k_compact_closest(
     if (uv_o) { uv_o[2 * j] = uv[2 * i]; uv_o[2 * j + 1] = uv[2 * i + 1]; }
 }
 
+// ---- packed closest-hit results -> the five dense outputs (tr_closest_expand) ---------------------
+// One thread per ray: {face | front << 30, u, v} -> hit, front, tri, loc, uv with tr_bary_outputs on
+// the mesh's own vertex / face arrays (the arena's triangle records are verbatim copies of them), so
+// the outputs carry the bits tr_intersects_closest would have written.  Any output may be NULL.
+__global__ __launch_bounds__(256) void k_closest_expand(const tr_packed_hit* __restrict__ packed, int64_t n,
+                                                        const float* __restrict__ verts, int64_t nv,
+                                                        const int32_t* __restrict__ faces, int64_t nf,
+                                                        uint8_t* __restrict__ hit, uint8_t* __restrict__ front,
+                                                        int32_t* __restrict__ tri, float* __restrict__ loc,
+                                                        float* __restrict__ uv) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const tr_packed_hit ph = packed[i];
+    float l3[3] = {0.f, 0.f, 0.f}, u2[2] = {0.f, 0.f};
+    uint8_t h = 0, fr = 0;
+    int32_t t = -1;
+    const uint32_t face = ph.tri & 0x3fffffffu;
+    if (!(ph.tri & 0x80000000u) && (int64_t)face < nf) {
+        const int32_t i0 = faces[3 * (int64_t)face], i1 = faces[3 * (int64_t)face + 1], i2 = faces[3 * (int64_t)face + 2];
+        if ((uint32_t)i0 < (uint64_t)nv && (uint32_t)i1 < (uint64_t)nv && (uint32_t)i2 < (uint64_t)nv) {
+            const float* a = verts + 3 * (int64_t)i0; const float* b = verts + 3 * (int64_t)i1; const float* c = verts + 3 * (int64_t)i2;
+            tr_bary_outputs(ph.u, ph.v, a[0], a[1], a[2], b[0], b[1], b[2], c[0], c[1], c[2], l3, u2);
+            h = 1; fr = (ph.tri >> 30) & 1u; t = (int32_t)face;
+        }
+    }
+    if (hit) hit[i] = h;
+    if (front) front[i] = fr;
+    if (tri) tri[i] = t;
+    if (loc) { loc[3 * i] = l3[0]; loc[3 * i + 1] = l3[1]; loc[3 * i + 2] = l3[2]; }
+    if (uv) { uv[2 * i] = u2[0]; uv[2 * i + 1] = u2[1]; }
+}
+
 // ---- host side ----------------------------------------------------------------------------------
 int make_fetch(const tr_rays* rays, RayFetch* rf) {
     if (!rays) return tr_fail(TR_ERR_INVALID_ARG, "rays == NULL");
@@ -1179,11 +1227,15 @@ void sched_acquire(const tr_bvh* bvh, const tr_options& opt, hipStream_t stream,
 // Node flavour of a stealing closest / first launch under grid_nodes = 1.  Whether the 32-byte grid
 // nodes beat the exact ones depends on how many distinct nodes the lanes of a wave are on (headline
 // image -2...-5 %, 21 M triangles -8 %, the shell scene +1.5...+4 %), which the host cannot know -- so
-// it is measured: launches 0-4 of a (batch size, query) run on the exact nodes, 5-8 on the grid nodes,
-// launches 3-4 and 7-8 are bracketed by events (each span holds one re-sort of the launch order), and
-// as soon as both spans have completed the faster flavour stays (the grid nodes have to win by 2 %).
-// Never blocks: until the events are done, and while a stream is being captured, launches use the
-// exact nodes.  Speed only.  *ev_before / *ev_after: events to record around this launch.
+// it is measured: launches 0-4 of a (batch size, query) run on the exact nodes, 5-8 on the grid nodes;
+// the QUERY KERNELS of launches 3, 4, 7 and 8 are bracketed by events (the re-sort of the launch order
+// that may follow a launch is outside the bracket), and as soon as all four have completed the faster
+// flavour stays (the grid nodes have to win by 2 %).  One noisy sample must not pin a workload to the
+// slower flavour: the measurement is repeated 64 launches later and the decision is final once two
+// measurements agree (a third one, 128 launches on, breaks a tie).  A rebuild / refit starts over
+// (tr_build_impl, tr_bvh_reset).  Never blocks: until the events are done, and while a stream is being
+// captured, launches use the exact nodes.  Speed only.  *ev_before / *ev_after: events to record
+// immediately before / after this launch's query kernel.
 int gn_pick(const tr_bvh* bvh, hipStream_t stream, int cls, int64_t key, hipEvent_t* ev_before, hipEvent_t* ev_after) {
     *ev_before = nullptr; *ev_after = nullptr;
     tr_bvh* mb = const_cast<tr_bvh*>(bvh);
@@ -1191,33 +1243,38 @@ int gn_pick(const tr_bvh* bvh, hipStream_t stream, int cls, int64_t key, hipEven
     std::lock_guard<std::mutex> lock(*mb->sched_mutex);
     tr_sched_slot* t = sched_slot(mb, stream, cls);
     if (!t) return 0;
-    if (t->gn_key != key) { t->gn_key = key; t->gn_count = 0; t->gn_choice = -1; }
-    if (t->gn_choice >= 0) return t->gn_choice;
+    if (t->gn_key != key) { t->gn_reset(); t->gn_key = key; }
+    if (t->gn_choice >= 0) {
+        if (t->gn_final) return t->gn_choice;
+        if (++t->gn_since < (t->gn_rounds == 1 ? 64 : 128)) return t->gn_choice;
+        t->gn_prev = t->gn_choice; t->gn_choice = -1; t->gn_count = 0;      // measure again
+    }
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return 0; }
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return t->gn_prev > 0; }
     if (!t->gn_events) {
-        for (int k = 0; k < 4; k++)
-            if (hipEventCreate(&t->gn_ev[k]) != hipSuccess) { (void)hipGetLastError(); t->gn_choice = 0; return 0; }
+        for (int k = 0; k < 8; k++)
+            if (hipEventCreate(&t->gn_ev[k]) != hipSuccess) { (void)hipGetLastError(); t->gn_choice = 0; t->gn_final = true; return 0; }
         t->gn_events = true;
     }
     const int c = t->gn_count++;
-    if (c == 3) *ev_before = t->gn_ev[0];
-    if (c == 4) *ev_after = t->gn_ev[1];
-    if (c == 7) *ev_before = t->gn_ev[2];
-    if (c == 8) *ev_after = t->gn_ev[3];
+    const int sample = c == 3 ? 0 : (c == 4 ? 1 : (c == 7 ? 2 : (c == 8 ? 3 : -1)));
+    if (sample >= 0) { *ev_before = t->gn_ev[2 * sample]; *ev_after = t->gn_ev[2 * sample + 1]; }
     if (c <= 4) return 0;
     if (c <= 8) return 1;
-    if (hipEventQuery(t->gn_ev[1]) == hipSuccess && hipEventQuery(t->gn_ev[3]) == hipSuccess) {
-        float a = 0.f, b = 0.f;
-        if (hipEventElapsedTime(&a, t->gn_ev[0], t->gn_ev[1]) == hipSuccess &&
-            hipEventElapsedTime(&b, t->gn_ev[2], t->gn_ev[3]) == hipSuccess && a > 0.f && b > 0.f)
-            t->gn_choice = b < 0.98f * a ? 1 : 0;
-        else
-            t->gn_choice = 0;
+    if (hipEventQuery(t->gn_ev[3]) == hipSuccess && hipEventQuery(t->gn_ev[7]) == hipSuccess) {
+        float ms[4] = {0.f, 0.f, 0.f, 0.f};
+        bool ok = true;
+        for (int k = 0; k < 4; k++) ok = ok && hipEventElapsedTime(&ms[k], t->gn_ev[2 * k], t->gn_ev[2 * k + 1]) == hipSuccess && ms[k] > 0.f;
+        const int measured = ok && (ms[2] + ms[3]) < 0.98f * (ms[0] + ms[1]) ? 1 : 0;
+        if (!ok) (void)hipGetLastError();
+        t->gn_rounds++;
+        t->gn_final = !ok || t->gn_rounds >= 3 || (t->gn_rounds == 2 && measured == t->gn_prev);
+        t->gn_choice = measured;
+        t->gn_since = 0;
         return t->gn_choice;
     }
     (void)hipGetLastError();     // hipErrorNotReady is not an error of this call
-    return 0;
+    return t->gn_prev > 0;       // undecided: the previous measurement's flavour (exact nodes the first time)
 }
 
 template <int Q, bool STATS>
@@ -1460,10 +1517,10 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
         else if (bs == 128) { if (compact) TR_LAUNCH_DIRECT(true, 128, false); else if (deep) TR_LAUNCH_DIRECT(true, 128, true); else TR_LAUNCH_DIRECT(false, 128, false); }
         else { if (compact) TR_LAUNCH_DIRECT(true, 256, false); else TR_LAUNCH_DIRECT(false, 256, false); }
 #undef TR_LAUNCH_DIRECT
+        if (gn_after) (void)hipEventRecord(gn_after, stream);      // brackets the query kernel only
         if (cost)
             hipLaunchKernelGGL(k_sched_sort, dim3(1), dim3(1024), 0, stream, cost, cost + TR_SCHED_MAX,
                                (int)nblocks_direct, xc, (int)split, (int)split4);
-        if (gn_after) (void)hipEventRecord(gn_after, stream);
         if (!STATS && bvh->sched_mutex) {
             tr_bvh* mb = const_cast<tr_bvh*>(bvh);
             std::lock_guard<std::mutex> lock(*mb->sched_mutex);
@@ -1548,6 +1605,26 @@ int tr_intersects_closest(const tr_bvh* bvh, const tr_rays* rays, uint8_t* d_hit
         return tr_fail(TR_ERR_INVALID_ARG, "null output pointer");
     QueryOut out = {d_hit, d_front, d_tri, d_loc, d_uv, nullptr};
     return launch_query<TR_Q_CLOSEST, false>(bvh, rays, out, nullptr, (hipStream_t)stream);
+}
+
+int tr_intersects_closest_packed(const tr_bvh* bvh, const tr_rays* rays, tr_packed_hit* d_packed, void* stream) {
+    if (rays && rays->nray > 0 && !d_packed) return tr_fail(TR_ERR_INVALID_ARG, "d_packed == NULL");
+    if (bvh && bvh->num_tris >= ((int64_t)1 << 30)) return tr_fail(TR_ERR_INVALID_ARG, "packed results hold face indices below 2^30");
+    QueryOut out = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, d_packed};
+    return launch_query<TR_Q_CLOSEST, false>(bvh, rays, out, nullptr, (hipStream_t)stream);
+}
+
+int tr_closest_expand(const tr_packed_hit* d_packed, int64_t n, const float* d_vertices, int64_t nv,
+                      const int32_t* d_faces, int64_t nf, uint8_t* d_hit, uint8_t* d_front, int32_t* d_tri,
+                      float* d_loc, float* d_uv, void* stream) {
+    if (n < 0 || nv < 0 || nf < 0) return tr_fail(TR_ERR_INVALID_ARG, "negative size");
+    if (n == 0) return TR_OK;
+    if (!d_packed) return tr_fail(TR_ERR_INVALID_ARG, "d_packed == NULL");
+    if (nf > 0 && (!d_vertices || !d_faces)) return tr_fail(TR_ERR_INVALID_ARG, "null mesh pointer");
+    hipLaunchKernelGGL(k_closest_expand, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       d_packed, n, d_vertices, nv, d_faces, nf, d_hit, d_front, d_tri, d_loc, d_uv);
+    TR_HIP_TRY(hipGetLastError());
+    return TR_OK;
 }
 
 int tr_intersects_count(const tr_bvh* bvh, const tr_rays* rays, int32_t* d_count, void* stream) {

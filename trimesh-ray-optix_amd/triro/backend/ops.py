@@ -30,7 +30,7 @@ MAX_ANYHIT_SIZE = 8   # LaunchParams.h:8
 MAX_SIZE_LENGTH = 4   # LaunchParams.h:9
 
 _LIB_NAME = "libtriro_hip.so"
-ABI_VERSION = 5     # TR_ABI_VERSION of include/triro_hip.h this binding was written against
+ABI_VERSION = 6     # TR_ABI_VERSION of include/triro_hip.h this binding was written against
 _lib = None
 _lib_error = None
 
@@ -89,6 +89,8 @@ ABI = {
     "tr_intersects_first": (_int, [_vp, C.POINTER(TrRays), _vp, _vp]),
     "tr_intersects_closest": (_int, [_vp, C.POINTER(TrRays), _vp, _vp, _vp, _vp, _vp, _vp]),
     "tr_intersects_count": (_int, [_vp, C.POINTER(TrRays), _vp, _vp]),
+    "tr_intersects_closest_packed": (_int, [_vp, C.POINTER(TrRays), _vp, _vp]),
+    "tr_closest_expand": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tr_hits_scan": (_int, [_vp, _i64, _i32, _vp, _vp, C.POINTER(_i64), _vp]),
     "tr_intersects_location_fill": (_int, [_vp, C.POINTER(TrRays), _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
     "tr_intersects_count_topk": (_int, [_vp, C.POINTER(TrRays), _i32, _vp, _vp, _vp]),
@@ -247,6 +249,61 @@ def intersects_closest(accel_structure, origins, dirs) -> Tuple[torch.Tensor, ..
         _check(get_module().tr_intersects_closest(
             _handle(accel_structure, origins), C.byref(make_rays(origins, dirs)), hit.data_ptr(), front.data_ptr(),
             tri.data_ptr(), loc.data_ptr(), uv.data_ptr(), _stream_ptr(dev)))
+    return hit, front, tri, loc, uv
+
+
+def intersects_closest_packed(accel_structure, origins, dirs, out: torch.Tensor = None) -> torch.Tensor:
+    """Closest hit as 12 bytes per ray: int32 [n, 3] rows {face | front << 30 (-1 on a miss), u bits,
+    v bits} (tr_packed_hit).  What a ray-sharded run sends over xGMI instead of the 26 B/ray of the five
+    dense outputs; `closest_expand` rebuilds those bit for bit.  `out`: optional preallocated [n, 3]
+    int32 destination (a slice of a gather buffer)."""
+    check_rays(origins, dirs)
+    n, dev = origins.numel() // 3, origins.device
+    if out is None:
+        out = torch.empty((n, 3), dtype=torch.int32, device=dev)
+    elif out.dtype != torch.int32 or tuple(out.shape) != (n, 3) or not out.is_contiguous() or out.device != dev:
+        raise ValueError("out must be a contiguous int32 [n, 3] tensor on the rays' device")
+    with torch.cuda.device(dev):
+        _check(get_module().tr_intersects_closest_packed(_handle(accel_structure, origins), C.byref(make_rays(origins, dirs)),
+                                                         out.data_ptr(), _stream_ptr(dev)))
+    return out
+
+
+def closest_expand(packed: torch.Tensor, vertices: torch.Tensor, faces: torch.Tensor, batch_shape=None, outs=None):
+    """tr_closest_expand: packed [n, 3] int32 -> (hit, front, tri_idx, loc, uv) shaped `batch_shape`
+    (default [n]), bit-identical to intersects_closest on the same rays.  vertices / faces: the float32
+    [nv, 3] / int32 [nf, 3] arrays the BVH was built from, on the device of `packed`.  `outs`: optional
+    preallocated contiguous destinations (bool [n], bool [n], int32 [n], float32 [n, 3], float32 [n, 2]
+    -- e.g. row slices of full-size outputs)."""
+    if packed.dtype != torch.int32 or packed.dim() != 2 or packed.shape[1] != 3 or not packed.is_contiguous():
+        raise ValueError("packed must be a contiguous int32 [n, 3] tensor")
+    if vertices.dtype != torch.float32 or faces.dtype != torch.int32 or not vertices.is_contiguous() or not faces.is_contiguous():
+        raise ValueError("vertices must be contiguous float32 [nv, 3] and faces contiguous int32 [nf, 3]")
+    dev = packed.device
+    if not packed.is_cuda or vertices.device != dev or faces.device != dev:
+        raise ValueError("packed, vertices and faces must live on the same GPU")
+    n = packed.shape[0]
+    if outs is not None:
+        want = ((torch.bool, (n,)), (torch.bool, (n,)), (torch.int32, (n,)), (torch.float32, (n, 3)), (torch.float32, (n, 2)))
+        if len(outs) != 5 or any(t.dtype != dt or tuple(t.shape) != sh or not t.is_contiguous() or t.device != dev
+                                 for t, (dt, sh) in zip(outs, want)):
+            raise ValueError("outs must be contiguous (bool[n], bool[n], int32[n], float32[n,3], float32[n,2]) on the device of packed")
+        with torch.cuda.device(dev):
+            _check(get_module().tr_closest_expand(packed.data_ptr(), n, vertices.data_ptr(), vertices.shape[0],
+                                                  faces.data_ptr(), faces.shape[0], *(t.data_ptr() for t in outs), _stream_ptr(dev)))
+        return tuple(outs)
+    b = tuple(batch_shape) if batch_shape is not None else (n,)
+    hit = torch.empty(b, dtype=torch.bool, device=dev)
+    front = torch.empty(b, dtype=torch.bool, device=dev)
+    tri = torch.empty(b, dtype=torch.int32, device=dev)
+    loc = torch.empty((*b, 3), dtype=torch.float32, device=dev)
+    uv = torch.empty((*b, 2), dtype=torch.float32, device=dev)
+    if hit.numel() != n:
+        raise ValueError(f"batch_shape {b} does not hold {n} rays")
+    with torch.cuda.device(dev):
+        _check(get_module().tr_closest_expand(packed.data_ptr(), n, vertices.data_ptr(), vertices.shape[0],
+                                              faces.data_ptr(), faces.shape[0], hit.data_ptr(), front.data_ptr(),
+                                              tri.data_ptr(), loc.data_ptr(), uv.data_ptr(), _stream_ptr(dev)))
     return hit, front, tri, loc, uv
 
 

@@ -110,6 +110,19 @@ class RayMeshIntersector:
             return hit, front_c, ray_idx, tri_c, loc_c, uv_c
         return hit, front, tri_idx, loc, uv
 
+    def intersects_closest_packed(self, origins, directions, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Closest hit as int32 [n, 3] rows {tri_idx | front << 30 (-1: miss), u bits, v bits}: 12 bytes
+        per ray (not in the reference; what a ray-sharded run sends over xGMI, triro.ray.sharded)."""
+        return hops.intersects_closest_packed(self.as_wrapper, origins, directions, out)
+
+    def closest_expand(self, packed: torch.Tensor, batch_shape=None, outs=None):
+        """packed rows -> (hit, front, tri_idx, loc, uv), bit-identical to intersects_closest on the same
+        rays; uses this intersector's mesh (any rank's replica will do: the meshes are identical)."""
+        dev = packed.device
+        v = self.mesh_vertices if self.mesh_vertices.device == dev else self.mesh_vertices.to(dev)
+        f = self.mesh_faces if self.mesh_faces.device == dev else self.mesh_faces.to(dev)
+        return hops.closest_expand(packed, v, f, batch_shape, outs)
+
     def intersects_location(self, origins, directions) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """ray_optix.py:157-164.  (loc[h,3], ray_idx[h], tri_idx[h]), <= 8 hits per ray."""
         return hops.intersects_location(self.as_wrapper, origins, directions)
@@ -225,6 +238,12 @@ class OptixAccelStructureWrapper:
         if vertices.dtype != torch.float32 or faces.dtype != torch.int32:
             raise ValueError("vertices must be float32 and faces int32")
         vertices, faces = vertices.contiguous(), faces.contiguous()
+        if faces.device != vertices.device:
+            raise ValueError("vertices and faces are on different devices")
+        if self._inner and self.device_index is not None and vertices.device.index != self.device_index:
+            # tr_bvh_update rebuilds inside the handle's arena, which stays on its device
+            raise ValueError(f"the acceleration structure lives on cuda:{self.device_index} but the new mesh is on "
+                             f"{vertices.device}; move the mesh or build a new intersector on that device")
         lib = hops.get_module()
         with torch.cuda.device(vertices.device):
             stream = torch.cuda.current_stream(vertices.device).cuda_stream
@@ -236,11 +255,13 @@ class OptixAccelStructureWrapper:
                 hops._check(lib.tr_bvh_build(vertices.data_ptr(), vertices.shape[0], faces.data_ptr(),
                                              faces.shape[0], stream, C.byref(handle)))
                 self._inner = handle.value
-        self.device_index = vertices.device.index
+        self.device_index = int(self.info()["device"])     # the GPU that owns the arena, as the library sees it
 
     def refit(self, vertices: torch.Tensor, faces: torch.Tensor):
         if not self._inner:
             raise RuntimeError("acceleration structure has not been built")
+        if not vertices.is_cuda or not faces.is_cuda or vertices.device.index != self.device_index or faces.device != vertices.device:
+            raise ValueError(f"refit needs vertices and faces on cuda:{self.device_index}, the device of the acceleration structure")
         with torch.cuda.device(vertices.device):
             stream = torch.cuda.current_stream(vertices.device).cuda_stream
             hops._check(hops.get_module().tr_bvh_refit(self._inner, vertices.data_ptr(), vertices.shape[0],
