@@ -237,7 +237,9 @@ int tr_trace_stats_query(const tr_bvh *bvh, const tr_rays *rays, int query, tr_t
  *    for large incoherent batches: rays per range, idle lanes that trigger a refill, ranges handed
  *    out by a work counter instead of one static range per wave), "split" (0 off / 1 auto / N >= 2: the nblocks >> N most expensive blocks of
  *    the learned launch order are traced by two -- the first quarter by four -- launch slots of
- *    half / quarter lane density whose idle lanes steal from trip "split_steal" on).
+ *    half / quarter lane density whose idle lanes steal from trip "split_steal" on; of those blocks only the
+ *    ones that cost at least "split_outlier" eighths of the mean block cost and at least "split_floor"
+ *    microseconds per wave are really split -- decided on the device from the measured costs).
  *    "grid_nodes" (0 never / 1 measured on the first launches of a batch size / 2 always: closest and first launches that steal walk the
  *    32-byte grid nodes -- two 16-byte loads per visit -- instead of the exact 64-byte nodes).
  *    None of them changes results.  Returns TR_ERR_INVALID_ARG for unknown names or values out

@@ -70,6 +70,15 @@ report("C4 location (count+scan+fill), 4 nested shells 1310720 tris, 1024^2 pinh
        timeit(lambda: r.intersects_location(ot, dt), reps=10), tris=len(f), hits=nh)
 report("C4 closest + stream compaction", 1 << 20, timeit(lambda: r.intersects_closest(ot, dt, stream_compaction=True)), tris=len(f))
 report("C4 count", 1 << 20, timeit(lambda: r.intersects_count(ot, dt)), tris=len(f))
+v, f = W.interior_room()
+r = RayMeshIntersector(vertices=T(v), faces=T(f))
+_, d = W.ref_shape_rays(W.INTERIOR_EYE, W.INTERIOR_TARGET)
+ot = torch.from_numpy(np.array(W.INTERIOR_EYE, np.float32)).to(dev).expand(360, 640, 3)
+dt = T(d)
+report("ROOM closest, interior scene 909088 tris, camera inside, 640x360 reference-shaped rays", 640 * 360,
+       timeit(lambda: r.intersects_closest(ot, dt), reps=50, warm=20), tris=len(f))
+report("ROOM count, same rays", 640 * 360, timeit(lambda: r.intersects_count(ot, dt), reps=30, warm=12), tris=len(f))
+report("ROOM location, same rays", 640 * 360, timeit(lambda: r.intersects_location(ot, dt), reps=20, warm=8), tris=len(f))
 v, f = W.headline_mesh(8)
 t0 = time.perf_counter()
 r = RayMeshIntersector(vertices=T(v), faces=T(f))

@@ -167,4 +167,5 @@ def test_sharded_exchange_on_rccl_world1():
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "nccl_world1.py")
     p = subprocess.run([sys.executable, script, str(29600 + os.getpid() % 300)], capture_output=True, text=True, timeout=540, env=env)
-    assert p.returncode == 0 and p.stdout.strip().endswith("OK"), (p.stdout[-1500:], p.stderr[-3000:])
+    # (RCCL prints its version banner to stdout when the communicator is torn down)
+    assert p.returncode == 0 and "OK" in p.stdout.split(), (p.stdout[-1500:], p.stderr[-3000:])

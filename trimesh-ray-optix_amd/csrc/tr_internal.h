@@ -157,6 +157,8 @@ struct tr_options {
     int grid_nodes = 1;   // stealing closest / first launches on the 32-byte grid nodes: 0 never, 1 measured (the faster flavour of the first launches of a batch stays), 2 always
     int split = 1;        // block splitting: 0 off, 1 auto, N >= 2: the nblocks >> N most expensive blocks of the previous launch get two launch slots
     int split_steal = 8;  // ... and give subtrees away from this trip on
+    int split_outlier = 1;    // ... but only blocks that cost at least N eighths of the mean block cost (0: all of them, 1: N by how full the chip is)
+    int split_floor = 40;     // ... and at least this many microseconds (device clock) per wave
     int leaf_vote = 32;   // unordered schedule: lanes with a queued leaf that fire a leaf phase
 };
 tr_options tr_opts();   // snapshot by value

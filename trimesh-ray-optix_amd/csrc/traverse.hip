@@ -538,6 +538,7 @@ __global__ __launch_bounds__(BS) void k_query_direct(tr_bvh_view b, RayFetch rf,
         // launch slots the block's rays were dealt to, bits 28-29 = this slot's part.
         const uint32_t e = order[blockIdx.x];
         blk = e & 0x0fffffffu;
+        if (blk >= nblk) return;          // a launch slot the sort left unused (fewer blocks split than the grid allows)
         parts_lg = (int)(e >> 30);
         part = (int)((e >> 28) & 3u);
         if (MODE != 1) {                  // (split orders are only written for the shapes that steal)
@@ -627,7 +628,8 @@ __global__ __launch_bounds__(BS) void k_query_direct(tr_bvh_view b, RayFetch rf,
 // Resets the cost array for the next measurement.
 __global__ __launch_bounds__(1024) void k_sched_sort(uint32_t* __restrict__ cost,
                                                       uint32_t* __restrict__ order, int nblocks,
-                                                      int xcd_map, int split, int split4) {
+                                                      int xcd_map, int split, int split4,
+                                                      int outlier8, int floor_ticks) {
     // list x: blocks whose home in the XCD-chunked map is XCD x (see k_query_direct; the blocks
     // past the last whole span are dealt round-robin there, so their home is i % 8).  Launch
     // slot j*8+x runs on XCD x, so list x fills the slots of XCD x in cost order: expensive
@@ -635,17 +637,23 @@ __global__ __launch_bounds__(1024) void k_sched_sort(uint32_t* __restrict__ cost
     // |list x| = number of slots of XCD x because the whole spans are multiples of 8 blocks.
     __shared__ uint32_t bins[8][256];
     __shared__ uint32_t smax;
+    __shared__ unsigned long long ssum;
+    __shared__ uint32_t nsplit[8];       // blocks of list x that are really split (<= split)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int k = tid; k < 8 * 256; k += 1024) (&bins[0][0])[k] = 0;
-    if (tid == 0) smax = 1;
+    if (tid == 0) { smax = 1; ssum = 0ull; }
     __syncthreads();
     const int T = xcd_map;
     const int nfull = T > 0 ? nblocks / (8 * T) * (8 * T) : 0;
     uint32_t m = 0;
-    for (int i = tid; i < nblocks; i += 1024) { const uint32_t c = cost[i]; m = c > m ? c : m; }
+    unsigned long long sum = 0;
+    for (int i = tid; i < nblocks; i += 1024) { const uint32_t c = cost[i]; m = c > m ? c : m; sum += c; }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) { const uint32_t o = __shfl_xor(m, off); m = o > m ? o : m; }
-    if (lane == 0) atomicMax(&smax, m);
+    for (int off = 32; off >= 1; off >>= 1) {
+        const uint32_t o = __shfl_xor(m, off); m = o > m ? o : m;
+        sum += __shfl_xor(sum, off);
+    }
+    if (lane == 0) { atomicMax(&smax, m); atomicAdd(&ssum, sum); }
     __syncthreads();
     // any monotone quantisation will do: level 0 = most expensive (costs are < 2^19 ticks)
     const float scale = 255.0f / (float)smax;
@@ -655,26 +663,61 @@ __global__ __launch_bounds__(1024) void k_sched_sort(uint32_t* __restrict__ cost
         atomicAdd(&bins[x][q], 1u);
     }
     __syncthreads();
+    // Which blocks are WORTH splitting is decided here, from the costs: a block gets extra launch slots
+    // only if it sticks out -- at least outlier8 / 8 times the mean block cost -- and is long enough for
+    // hand-overs to pay (floor_ticks: waves of a few dozen trips end before a thief has done anything).
+    // The grid has room for `split` blocks per XCD; what is not used stays empty (sentinel entries).
+    // An interior scene with evenly expensive rays splits nothing (0.050 -> 0.036 ms at 230 k rays), a
+    // silhouette image splits its silhouette (profiles/r03_policy_matrix.jsonl, r03_sweep_outlier.jsonl).
+    uint32_t thr = 0;
+    if (outlier8 > 0) {
+        const float mean = (float)ssum / (float)nblocks;
+        const float t = fmaxf(mean * (float)outlier8 * 0.125f, (float)floor_ticks);
+        thr = t >= 4.0e9f ? 0xffffffffu : (uint32_t)t;
+    }
+    // (the level of the threshold: blocks of a level are kept or dropped together)
+    const uint32_t thr_level = thr > smax ? 0u : 255u - min(255u, (uint32_t)((float)thr * scale));
     if (wave < 8) {   // exclusive scan of list `wave`: 4 bins per lane
-        uint32_t v[4], sum = 0;
+        uint32_t v[4], sum4 = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) { v[k] = bins[wave][4 * lane + k]; sum += v[k]; }
-        uint32_t inc = sum;
+        for (int k = 0; k < 4; k++) { v[k] = bins[wave][4 * lane + k]; sum4 += v[k]; }
+        uint32_t inc = sum4;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(inc, off); if (lane >= off) inc += o; }
-        uint32_t run = inc - sum;
+        uint32_t run = inc - sum4;
+        // blocks at levels < thr_level (strictly more expensive than the threshold's level) qualify
+        uint32_t above = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) { bins[wave][4 * lane + k] = run; run += v[k]; }
+        for (int k = 0; k < 4; k++) {
+            bins[wave][4 * lane + k] = run;
+            if ((uint32_t)(4 * lane + k) == thr_level) above = run;
+            run += v[k];
+        }
+        // exactly one lane holds the prefix count at thr_level
+        const unsigned long long who = __ballot((uint32_t)(4 * lane) <= thr_level && thr_level < (uint32_t)(4 * lane + 4));
+        const uint32_t cnt = __shfl(above, (int)__builtin_ctzll(who));
+        if (lane == 0) nsplit[wave] = thr > smax ? 0u : min((uint32_t)split, outlier8 > 0 ? cnt : (uint32_t)split);
     }
     __syncthreads();
+    // unused extra slots of every XCD: sentinel entries (the query kernel returns at once)
+    {
+        const uint32_t spmax = (uint32_t)split, q4max = (uint32_t)split4;
+        const uint32_t extra_max = spmax + 2u * q4max;
+        for (uint32_t k = tid; k < 8u * extra_max; k += 1024u) {
+            const uint32_t x = k & 7u, e = k >> 3;
+            const uint32_t sp = nsplit[x], q4 = sp >> 2;
+            const uint32_t len = (uint32_t)((nblocks >> 3) + (((uint32_t)nblocks & 7u) > x ? 1 : 0));
+            if (e >= sp + 2u * q4) order[(len + e) * 8u + x] = 0x0fffffffu;
+        }
+    }
     for (int i = tid; i < nblocks; i += 1024) {
         const uint32_t q = 255u - min(255u, (uint32_t)((float)cost[i] * scale));
         const int x = i < nfull ? (i / T) & 7 : i & 7;
         const uint32_t j = atomicAdd(&bins[x][q], 1u);
-        // block splitting: the `split` most expensive blocks of every XCD get two launch slots
+        // block splitting: the `sp` most expensive blocks of XCD x get two launch slots
         // each (halves of their rays, see k_query_direct); the launch has 8 * split slots more
-        // (the first `split4` of them four: quarters of their rays)
-        const uint32_t sp = (uint32_t)split, q4 = (uint32_t)split4;
+        // (the first quarter of them four: quarters of their rays)
+        const uint32_t sp = nsplit[x], q4 = sp >> 2;
         if (j < q4) {
             for (uint32_t k = 0; k < 4u; k++)
                 order[(4u * j + k) * 8u + (uint32_t)x] = (uint32_t)i | (2u << 30) | (k << 28);
@@ -1436,13 +1479,28 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
         int split_shift = 0;
         if (steal && opt.split > 1) split_shift = opt.split;
         else if (steal && opt.split == 1 && rf.n <= ((int64_t)1 << 22) && Q != TR_Q_COUNT) {
-            if (can_tile8 && !small_tris) split_shift = nblocks_direct <= 8192 ? 4 : (nblocks_direct < 32768 ? 5 : 0);
+            // (the fewer waves a launch has, the more of them are worth splitting: at 262 k rays -- 2 048
+            // blocks, 0.6 waves per slot of the chip -- a quarter of the blocks, 0.136 -> 0.115 ms; at
+            // 410 k rays an eighth, 0.142 -> 0.125 ms: profiles/r03_sweep_small_split.jsonl)
+            if (can_tile8 && !small_tris) split_shift = nblocks_direct <= 2048 ? 2 : (nblocks_direct <= 4096 ? 3 : (nblocks_direct <= 8192 ? 4 : (nblocks_direct < 32768 ? 5 : 0)));
             else if (!can_tile8 && nblocks_direct <= 2048) split_shift = 4;
         }
         int64_t split = 0;
         if (split_shift > 0 && bs == 128 && nblocks_direct >= (opt.split > 1 ? 64 : 512)) split = (nblocks_direct >> split_shift) / 8;
         if (nblocks_direct + 12 * split > TR_SCHED_MAX || !opt.adaptive) split = 0;   // no learned order, no split
         const int64_t split4 = split >> 2;
+        // ... of which the sort behind the launch really splits the blocks that stick out of the measured
+        // cost distribution (k_sched_sort): at least outlier8 / 8 times the mean block cost.  A launch that
+        // leaves wave slots of the chip empty can afford to split whatever is above the mean (262 k rays of
+        // the headline image: 0.136 -> 0.112 ms); one of several rounds of waves only its real outliers
+        // (2.5 x the mean from 2 rounds on: headline 1 M rays 0.219 -> 0.211 ms, the interior scene at
+        // 0.9 M rays 0.097 -> 0.089 ms: profiles/r03_sweep_outlier.jsonl).  split_outlier: 0 every block
+        // the grid has room for, 1 this rule, >= 2 eighths.
+        int outlier8 = opt.split_outlier;
+        if (outlier8 == 1) {
+            const double fill = 2.0 * (double)nblocks_direct / ((double)st->num_cus * 28.0);   // rounds of waves
+            outlier8 = fill <= 1.0 ? 8 : (fill >= 2.0 ? 20 : 8 + (int)(12.0 * (fill - 1.0)));
+        }
         const int steal_arg = steal_min | (opt.split_steal << 16);   // trip thresholds: ordinary | split blocks
         const uint32_t* order = nullptr;
         uint32_t* cost = nullptr;
@@ -1520,7 +1578,7 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
         if (gn_after) (void)hipEventRecord(gn_after, stream);      // brackets the query kernel only
         if (cost)
             hipLaunchKernelGGL(k_sched_sort, dim3(1), dim3(1024), 0, stream, cost, cost + TR_SCHED_MAX,
-                               (int)nblocks_direct, xc, (int)split, (int)split4);
+                               (int)nblocks_direct, xc, (int)split, (int)split4, outlier8, opt.split_floor * 100);
         if (!STATS && bvh->sched_mutex) {
             tr_bvh* mb = const_cast<tr_bvh*>(bvh);
             std::lock_guard<std::mutex> lock(*mb->sched_mutex);

@@ -10,6 +10,8 @@ Everything is a deterministic function of its arguments (no network, no files):
   * pinhole_grid                      -- BASELINE.md C2/C5(i): 40 deg vFOV, raster order
   * hash_rays                         -- BASELINE.md C3/C5(ii): pure function of the
     global ray index; numpy and torch versions produce identical bits
+  * interior_room / ref_shape_rays    -- an interior scene with the camera INSIDE and the ray shape
+    of the reference's own published timing (test/performance_test.py:10-20, 39-44)
 """
 from __future__ import annotations
 
@@ -134,6 +136,84 @@ def deep_tree_mesh(reps: int = 4000):
     return v, np.arange(len(v), dtype=np.int32).reshape(-1, 3)
 
 
+def _grid_patch(p0, du, dv, nu: int, nv: int, height=None):
+    """(nu+1) x (nv+1) vertices p0 + i/nu*du + j/nv*dv (+ height(i/nu, j/nv) along du x dv), 2*nu*nv
+    triangles wound counter-clockwise seen from the side the normal du x dv points to."""
+    p0, du, dv = (np.asarray(a, np.float64) for a in (p0, du, dv))
+    iu, iv = np.meshgrid(np.arange(nu + 1), np.arange(nv + 1), indexing="ij")
+    s, t = iu / nu, iv / nv
+    v = p0 + s[..., None] * du + t[..., None] * dv
+    if height is not None:
+        n = np.cross(du, dv)
+        v = v + height(s, t)[..., None] * (n / np.linalg.norm(n))
+    idx = (iu * (nv + 1) + iv)
+    a, b, c, d = idx[:-1, :-1], idx[1:, :-1], idx[1:, 1:], idx[:-1, 1:]
+    f = np.concatenate([np.stack([a, b, c], -1).reshape(-1, 3), np.stack([a, c, d], -1).reshape(-1, 3)], 0)
+    return v.reshape(-1, 3), f
+
+
+def _box(center, half, n: int):
+    """axis-aligned box, every face an n x n grid, outward-wound"""
+    c, h = np.asarray(center, np.float64), np.asarray(half, np.float64)
+    vs, fs, base = [], [], 0
+    ex, ey, ez = np.eye(3) * 2 * h
+    for p0, du, dv in ((c - h, ey, ex), (c - h + ez, ex, ey),          # z- (normal -z), z+
+                       (c - h, ez, ey), (c - h + ex, ey, ez),          # x-, x+
+                       (c - h, ex, ez), (c - h + ey, ez, ex)):         # y-, y+
+        v, f = _grid_patch(p0, du, dv, n, n)
+        vs.append(v)
+        fs.append(f + base)
+        base += len(v)
+    return np.concatenate(vs), np.concatenate(fs)
+
+
+def interior_room(seed: int = 0, detail: float = 1.0):
+    """An INTERIOR scene (the reference's only published timing is a camera inside a bedroom model,
+    test/performance_test.py:39-52; that asset is not obtainable here): a closed 8 x 3 x 6 room whose
+    walls face inwards, a finely tessellated floor with a small height field, 24 boxes of "furniture"
+    standing on it and 8 spheres.  detail = 1 -> about 0.9 M triangles; every ray cast from inside hits
+    something, most cross several objects (depth complexity >= 4 from the default camera)."""
+    rng = np.random.default_rng(seed)
+    k = lambda n: max(2, int(round(n * np.sqrt(detail))))          # noqa: E731
+    X, Y, Z = 4.0, 3.0, 3.0
+    parts = []
+    ph = rng.random(4) * 2 * np.pi
+
+    def floor_h(s, t):
+        return 0.02 * (np.sin(9 * np.pi * s + ph[0]) * np.sin(7 * np.pi * t + ph[1]) +
+                       0.5 * np.sin(23 * np.pi * s + ph[2]) * np.sin(19 * np.pi * t + ph[3]))
+    parts.append(_grid_patch((-X, 0, -Z), (0, 0, 2 * Z), (2 * X, 0, 0), k(360), k(480), floor_h))   # floor, normal +y
+    parts.append(_grid_patch((-X, Y, -Z), (2 * X, 0, 0), (0, 0, 2 * Z), k(80), k(60)))              # ceiling, normal -y
+    parts.append(_grid_patch((-X, 0, -Z), (2 * X, 0, 0), (0, Y, 0), k(80), k(30)))                  # wall z = -Z, normal +z
+    parts.append(_grid_patch((-X, 0, Z), (0, Y, 0), (2 * X, 0, 0), k(30), k(80)))                   # wall z = +Z, normal -z
+    parts.append(_grid_patch((-X, 0, -Z), (0, Y, 0), (0, 0, 2 * Z), k(30), k(60)))                  # wall x = -X, normal +x
+    parts.append(_grid_patch((X, 0, -Z), (0, 0, 2 * Z), (0, Y, 0), k(60), k(30)))                   # wall x = +X, normal -x
+    tops = []
+    for i in range(6):
+        for j in range(4):
+            cx = -X + (i + 0.5 + 0.3 * (rng.random() - 0.5)) * (2 * X / 6)
+            cz = -Z + (j + 0.5 + 0.3 * (rng.random() - 0.5)) * (2 * Z / 4)
+            hx, hz = 0.22 + 0.25 * rng.random(), 0.22 + 0.25 * rng.random()
+            hy = 0.2 + 0.7 * rng.random()
+            parts.append(_box((cx, 0.05 + hy, cz), (hx, hy, hz), k(36)))
+            tops.append((cx, 0.05 + 2 * hy, cz))
+    sv, sf = icosphere(max(2, int(round(5 + np.log2(max(detail, 1e-3)) / 2))))
+    for t in rng.choice(len(tops), 8, replace=False):
+        r = 0.18 + 0.1 * rng.random()
+        parts.append((sv.astype(np.float64) * r + np.array([tops[t][0], tops[t][1] + r + 0.02, tops[t][2]]), sf.astype(np.int64)))
+    vs, fs, base = [], [], 0
+    for v, f in parts:
+        vs.append(v)
+        fs.append(f + base)
+        base += len(v)
+    return np.concatenate(vs).astype(np.float32), np.concatenate(fs).astype(np.int32)
+
+
+# a camera in one corner, about a metre above the floor, looking across the room: 5.7 surfaces per
+# ray on average, up to 13 (more than the multi-hit cap of 8)
+INTERIOR_EYE, INTERIOR_TARGET = (-3.6, 1.0, -2.6), (3.2, 0.5, 2.3)
+
+
 # ----------------------------------------------------------------------------
 # rays (numpy; float32)
 # ----------------------------------------------------------------------------
@@ -171,6 +251,25 @@ def pinhole_grid(width: int = 1024, height: int = 1024, vfov_deg: float = 40.0,
     d /= np.linalg.norm(d, axis=-1, keepdims=True)
     c = np.asarray(center, np.float64)
     o = np.broadcast_to((c + np.array([0, 0, distance])).astype(np.float32), d.shape)
+    return o, d.astype(np.float32)
+
+
+def ref_shape_rays(eye, target, w: int = 640, h: int = 360, f: float = 444.0, up=(0.0, 1.0, 0.0)):
+    """The reference's published benchmark shape (test/performance_test.py:10-20, 29-31, 39-44): w x h
+    pinhole rays, focal length f pixels, unit directions x = col - (w-1)/2, y = row - (h-1)/2, z = -f
+    rotated by the camera matrix; the origin is ONE point broadcast with stride 0."""
+    eye, target, up = (np.asarray(a, np.float64) for a in (eye, target, up))
+    fwd = target - eye
+    fwd /= np.linalg.norm(fwd)
+    right = np.cross(fwd, up)
+    right /= np.linalg.norm(right)
+    down = np.cross(fwd, right)
+    ys, xs = np.meshgrid(np.arange(h, dtype=np.float64), np.arange(w, dtype=np.float64), indexing="ij")
+    d = np.stack([xs - (w - 1) / 2, ys - (h - 1) / 2, -np.full_like(xs, f)], -1)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    cam = np.stack([right, down, -fwd], 1)            # columns: image x, image y (down), backwards
+    d = d @ cam.T
+    o = np.broadcast_to(eye.astype(np.float32), d.shape)
     return o, d.astype(np.float32)
 
 
