@@ -487,6 +487,27 @@ def run_rank(args):
             cold = timed_steps(100, lambda k: r.intersects_closest(origins, dirs))
             hops.set_option("adaptive", 1)
             rl["cold_kernel_ms"] = round(float(np.mean(cold)), 4)
+            # what a one-shot call really gets: the FIRST launch of this batch shape on fresh handles (no
+            # order, exact nodes, BVH arena not yet in any cache); a small query first, so that the
+            # handle's scheduling buffers exist and only GPU work lies between the events
+            small_o, small_d = origins[:64].contiguous(), dirs[:64].contiguous()
+            firsts = []
+            for _ in range(8):
+                rr = RayMeshIntersector(vertices=vt, faces=ft)
+                rr.intersects_closest(small_o, small_d)
+                sync()
+                e0, e1 = event_pair()
+                e0.record()
+                rr.intersects_closest(origins, dirs)
+                e1.record()
+                sync()
+                firsts.append(e0.elapsed_time(e1))
+                del rr
+            rl["first_launch_kernel_ms"] = round(float(np.median(firsts)), 4)
+            rl["first_launch_note"] = ("median over 8 fresh handles of the first full-size launch (query kernel on a cold "
+                                       "arena + k_sched_sort); cold_kernel_ms = steady launches with adaptive=0 (no order, rows). "
+                                       "A sampling pre-pass for first launches was built and measured: no gain "
+                                       "(profiles/r03_prepass_first_launch.jsonl)")
             if args.rays == "pinhole":
                 frames = []
                 for k in range(8):      # camera orbiting by 0.25 degrees per frame

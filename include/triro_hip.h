@@ -83,7 +83,7 @@ typedef struct tr_launch_info {
     int64_t blocks;         /* ray blocks of 128 (block_size) rays                            */
     int64_t slots;          /* launch slots = blocks + extra slots of split blocks            */
     int32_t query;          /* TR_Q_* of the launch                                           */
-    int32_t shape;          /* 0 plain, 1 stealing, 2 unordered two-phase schedule            */
+    int32_t shape;          /* 0 plain, 1 stealing, 2 unordered two-phase schedule, 3 unordered + stealing */
     int32_t tile_rows_lg;   /* 0: 64 rays of one row per wave, 1: 2x32, 2: 4x16, 3: 8x8 tiles  */
     int32_t split_blocks;   /* blocks per XCD that were dealt to 2 / 4 launch slots           */
     int32_t learned_order;  /* 1: the launch used a learned launch order                      */
@@ -240,6 +240,8 @@ int tr_trace_stats_query(const tr_bvh *bvh, const tr_rays *rays, int query, tr_t
  *    half / quarter lane density whose idle lanes steal from trip "split_steal" on; of those blocks only the
  *    ones that cost at least "split_outlier" eighths of the mean block cost and at least "split_floor"
  *    microseconds per wave are really split -- decided on the device from the measured costs).
+ *    "usteal" (0 off / 1 on / N >= 2 forced with that trip threshold: count launches of the unordered
+ *    schedule hand owed subtrees over between the lanes of a wave and take split launch slots).
  *    "grid_nodes" (0 never / 1 measured on the first launches of a batch size / 2 always: closest and first launches that steal walk the
  *    32-byte grid nodes -- two 16-byte loads per visit -- instead of the exact 64-byte nodes).
  *    None of them changes results.  Returns TR_ERR_INVALID_ARG for unknown names or values out

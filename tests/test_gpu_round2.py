@@ -524,6 +524,7 @@ def test_last_launch_reports_the_shape_and_the_measured_node_flavour(device):
             if gn == 2: assert li["grid_nodes"] == 1
         r.intersects_count(ot, dt)
         li = r.as_wrapper.last_launch()
-        assert li["query"] == 3 and li["shape"] == 2 and li["grid_nodes"] == 1 and li["tile_rows_lg"] == 3
+        # (shape 3 = the unordered schedule with hand-over between lanes, round 3; 2 with usteal = 0)
+        assert li["query"] == 3 and li["shape"] == 3 and li["grid_nodes"] == 1 and li["tile_rows_lg"] == 3
     finally:
         hops.set_option("grid_nodes", 1)

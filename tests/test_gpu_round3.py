@@ -169,3 +169,42 @@ def test_sharded_exchange_on_rccl_world1():
     p = subprocess.run([sys.executable, script, str(29600 + os.getpid() % 300)], capture_output=True, text=True, timeout=540, env=env)
     # (RCCL prints its version banner to stdout when the communicator is torn down)
     assert p.returncode == 0 and "OK" in p.stdout.split(), (p.stdout[-1500:], p.stderr[-3000:])
+
+
+@pytest.mark.parametrize("usteal,split", [(1, 1), (2, 2), (4, 3), (64, 1), (0, 1)])
+def test_unordered_count_with_stealing_matches_the_oracle(device, usteal, split):
+    """count launches of the unordered schedule with hand-over between lanes (wave_count_unordered_steal),
+    split launch slots for expensive blocks: forced thresholds, image / flat / on-surface batches, several launches each (cold ->
+    learned order -> split slots), interleaved with closest launches of the same batch."""
+    import triro.backend.ops as hops
+    from test_gpu_round2 import on_surface_rays
+    v, f = W.nested_shells(4)
+    r = make(v, f, device)
+    R = OracleIntersector(v, f, 1)
+    o_img, d_img = W.pinhole_grid(512, 384)                       # 196 608 rays = 1 536 blocks
+    o_on, d_on = on_surface_rays(v, f, r, device, n_each=6000, seed=7)
+    lo, hi = v.min(0) * 1.2, v.max(0) * 1.2
+    o_h, d_h = W.hash_rays(150_000, 5, lo, hi)
+    cases = [("image", o_img, d_img), ("flat", o_img.reshape(-1, 3), d_img.reshape(-1, 3)), ("on-surface", o_on, d_on), ("hash", o_h, d_h)]
+    try:
+        hops.set_option("usteal", usteal)
+        hops.set_option("split", split)
+        hops.set_option("split_floor", 0)          # small test launches: let every candidate split
+        for name, o, d in cases:
+            cnt = R.intersects_count(o.reshape(-1, 3), d.reshape(-1, 3))
+            tri = R.closest_raw(o.reshape(-1, 3), d.reshape(-1, 3))[2]
+            ot, dt = T(o, device), T(d, device)
+            for rep in range(7):
+                got = r.intersects_count(ot, dt).cpu().numpy().reshape(-1)
+                assert np.array_equal(got, cnt), f"{name} usteal={usteal} split={split} launch {rep}: {int((got != cnt).sum())} rays differ"
+                if rep % 3 == 2:
+                    assert np.array_equal(r.intersects_first(ot, dt).cpu().numpy().reshape(-1), tri)
+            if name == "image" and usteal:
+                li = r.as_wrapper.last_launch()
+                assert li["shape"] == 3 and li["learned_order"] == 1, li
+        # contains_points runs on count
+        pts = (np.random.default_rng(1).random((4000, 3)) * 2.2 - 1.1).astype(np.float32)
+        assert np.array_equal(r.contains_points(T(pts, device)).cpu().numpy(), R.contains_points(pts))
+    finally:
+        for k, val in (("usteal", 1), ("split", 1), ("split_floor", 40)):
+            hops.set_option(k, val)

@@ -43,6 +43,7 @@ const opt_desc OPTS[] = {
     {"split", &tr_options::split, 0, 12, false},
     {"split_steal", &tr_options::split_steal, 0, 4096, false},
     {"split_outlier", &tr_options::split_outlier, 0, 1024, false},
+    {"usteal", &tr_options::usteal, 0, 4095, false},
     {"split_floor", &tr_options::split_floor, 0, 100000, false},
 };
 constexpr int NUM_OPTS = (int)(sizeof(OPTS) / sizeof(OPTS[0]));

@@ -160,5 +160,6 @@ struct tr_options {
     int split_outlier = 1;    // ... but only blocks that cost at least N eighths of the mean block cost (0: all of them, 1: N by how full the chip is)
     int split_floor = 40;     // ... and at least this many microseconds (device clock) per wave
     int leaf_vote = 32;   // unordered schedule: lanes with a queued leaf that fire a leaf phase
+    int usteal = 1;       // unordered count launches hand owed subtrees over between lanes and use split launch slots: 0 off, 1 on, >= 2 forced trip threshold
 };
 tr_options tr_opts();   // snapshot by value

@@ -447,11 +447,124 @@ __device__ __forceinline__ void wave_traverse_unordered(const tr_bvh_view& b, co
     }
 }
 
+#ifdef TR_USTEAL_DEBUG
+__device__ unsigned g_usteal_debug[4];
+#endif
+// ---- the unordered schedule with work stealing (count) --------------------------------------------
+// A count launch has no culling, but on a silhouette image the grazing rays are outliers here too
+// (headline image: bulk done at 377 us of 556), and a launch that leaves wave slots of the chip empty
+// ends with its longest waves.  Both are answered by SPLIT launch slots (k_sched_sort): a slot owns
+// every 2nd / 4th ray of a block and its other lanes take owed subtrees of those rays from the first
+// trips on: headline count 0.545 -> 0.383 ms, C4 at 262 k rays 0.436 -> 0.348, the interior scene at
+// 230 k rays 0.254 -> 0.164 (profiles/r03_sweep_usteal.jsonl).  A launch of several rounds of EQUALLY
+// long waves (C4 at 1 M rays) gains nothing, also not from splitting the blocks of its last round
+// (tried: the ramp-down is half a wave's time whatever the last waves are, and split waves are not
+// 2-4x shorter; r03_sweep_usteal_uniform.jsonl).  Hand-over as in wave_traverse_steal, with two differences: (1) no LDS scratch --
+// the kernel sits exactly at the LDS budget of 7 waves per SIMD (ring + leaf queue), so donor lanes
+// are listed with ds_permute / ds_bpermute and counts are handed in through v_readlane loops; (2) the
+// merge is a sum, order-free.  Any partition of a tree among lanes visits the same leaves, so the
+// counts are bit-identical (tests force thresholds 0 ... 64 on every scene family).
 template <int Q, bool STATS, bool COMPACT, bool DEEP = false>
+__device__ __forceinline__ int wave_count_unordered_steal(const tr_bvh_view& b, tr_ray& r, bool go, tr_counters* cnt,
+                                                          const tr_ring ring, const tr_leafq lq, int leaf_min,
+                                                          int lane, uint32_t steal_min) {
+    typedef typename tr_word<COMPACT, DEEP>::T W;
+    tr_result res;
+    tr_result_init(res);
+    tr_topk<1> top;
+    tr_ustate_t<W> st;
+    tr_ustate_init(st);
+    if (!go) st.node = -1;
+    int owner = lane;      // lane whose ray this lane is working on
+    int acc = 0;           // hits of THIS lane's ray that have been handed in (by itself or by others)
+    uint32_t trip = 0;
+    // lanes with `want` hand the count they hold to the owner of the ray they worked on
+    auto hand_in = [&](bool want) {
+        unsigned long long m = __ballot(want && res.count != 0);
+        while (m != 0ull) {
+            const int t = (int)__builtin_ctzll(m);
+            const int o = __builtin_amdgcn_readlane(owner, t), c = __builtin_amdgcn_readlane(res.count, t);
+            if (lane == o) acc += c;
+            m &= m - 1ull;
+        }
+        if (want) res.count = 0;
+    };
+    for (;;) {
+        bool live = true;      // wave-uniform: some lane still has a node or a queued leaf
+#pragma unroll 1
+        for (int k = 0; k < 4 && live; k++) {
+            const bool can_node = tr_ucan_node(st);
+            const unsigned long long mn = __ballot(can_node), ml = __ballot(st.nq > 0);
+            live = (mn | ml) != 0ull;
+            if (live) {
+                const bool parked = st.node >= 0 && !can_node;
+                const bool leaf_phase = mn == 0ull || __ballot(parked) != 0ull || __popcll(ml) >= leaf_min;
+                tr_unord_step<Q, 1, STATS, COMPACT, W>(b, r, can_node, leaf_phase, st, res, top, cnt, ring, lq);
+            }
+            TR_CONVERGE();
+        }
+        trip += 4;
+        const bool done = tr_udone(st);
+        const unsigned long long idle = __ballot(done);
+        if (idle == ~0ull) break;
+#ifdef TR_USTEAL_DEBUG
+        if (trip > (1u << 16)) { if (lane == 0) atomicAdd(&g_usteal_debug[0], 1u); if (!done) atomicAdd(&g_usteal_debug[1], 1u); break; }
+#endif
+        if (idle == 0ull) continue;
+        const W cand = st.trail & st.owned;          // owed far children that are still in the ring
+        const bool can_give = !done && cand != 0 && trip >= steal_min;
+        const unsigned long long donors = __ballot(can_give);
+        const int ni = __popcll(idle), nd = __popcll(donors);
+        const int np = ni < nd ? ni : nd;
+        if (np == 0) continue;
+#ifdef TR_USTEAL_DEBUG
+        if (lane == 0) atomicAdd(&g_usteal_debug[2], (unsigned)np);
+#endif
+        const int drank = lane_rank(donors), irank = lane_rank(idle);
+        const bool give = can_give && drank < np;
+        const bool take = done && irank < np;
+        // compact list of the giving lanes without LDS: giver g sends its lane id to lane g (the other
+        // lanes send theirs to distinct lanes from the top, so that every lane is written exactly once)
+        const unsigned long long givers = __ballot(give);
+        const int tgt = give ? drank : 63 - lane_rank(~givers);
+        const int list = __builtin_amdgcn_ds_permute(tgt << 2, lane);
+        // (the read-back is executed by EVERY lane: ds_bpermute returns 0 for a source lane that is
+        // masked off, and list entry g lives in lane g, which need not be a taker itself)
+        const int pick = __shfl(list, irank & 63);
+        const int src = take ? pick : lane;
+        int gnode = 0, gdepth = 0;
+        if (give) {
+            const uint32_t j = (uint32_t)__builtin_ctzll((unsigned long long)cand);     // the shallowest: the biggest subtree
+            gnode = ring.base[(j & (TR_RING - 1)) * ring.stride];
+            gdepth = (int)(j + 1);
+            st.trail &= ~(W(1) << j);
+            st.owned &= ~(W(1) << j);
+        }
+        // a lane that takes new work first hands in what it counted for the ray it is leaving
+        if (take && owner == lane) { acc += res.count; res.count = 0; }
+        hand_in(take && owner != lane);
+        r.ox = __shfl(r.ox, src); r.oy = __shfl(r.oy, src); r.oz = __shfl(r.oz, src);
+        r.dx = __shfl(r.dx, src); r.dy = __shfl(r.dy, src); r.dz = __shfl(r.dz, src);
+        r.ix = __shfl(r.ix, src); r.iy = __shfl(r.iy, src); r.iz = __shfl(r.iz, src);
+        const int own2 = __shfl(owner, src), n2 = __shfl(gnode, src), d2 = __shfl(gdepth, src);
+        if (take) {
+            owner = own2;
+            tr_ustate_init(st);
+            st.node = n2;
+            st.depth = (uint32_t)d2;
+        }
+        TR_CONVERGE();
+    }
+    if (owner == lane) { acc += res.count; res.count = 0; }
+    hand_in(owner != lane);
+    return acc;
+}
+
+template <int Q, bool STATS, bool COMPACT, bool DEEP = false, bool USTEAL = false>
 __device__ __forceinline__ void process_ray_unordered(const tr_bvh_view& b, const RayFetch& rf,
                                                       const QueryOut& out, int64_t i, bool in_range,
                                                       tr_counters* cnt, const tr_ring ring,
-                                                      const tr_leafq lq, int leaf_min) {
+                                                      const tr_leafq lq, int leaf_min, uint32_t steal_min = 0) {
     float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
     if (in_range) fetch_ray(rf, i, o, d);
     tr_ray r;
@@ -463,6 +576,10 @@ __device__ __forceinline__ void process_ray_unordered(const tr_bvh_view& b, cons
         top.tris = b.tris;
         top.cap = out.cap;
         wave_traverse_unordered<Q, 0, STATS, COMPACT, DEEP>(b, r, valid, res, top, cnt, ring, lq, leaf_min);
+    } else if (USTEAL && Q == TR_Q_COUNT) {
+        tr_result_init(res);
+        res.count = wave_count_unordered_steal<Q, STATS, COMPACT, DEEP>(b, r, valid, cnt, ring, lq, leaf_min,
+                                                                       (int)(threadIdx.x & 63), steal_min);
     } else {
         tr_topk<1> top;
         wave_traverse_unordered<Q, 1, STATS, COMPACT, DEEP>(b, r, valid, res, top, cnt, ring, lq, leaf_min);
@@ -537,11 +654,11 @@ __global__ __launch_bounds__(BS) void k_query_direct(tr_bvh_view b, RayFetch rf,
         // measured order: most expensive blocks first.  Bits 30-31 of an entry = lg of the number of
         // launch slots the block's rays were dealt to, bits 28-29 = this slot's part.
         const uint32_t e = order[blockIdx.x];
-        blk = e & 0x0fffffffu;
+        blk = e & 0x07ffffffu;
         if (blk >= nblk) return;          // a launch slot the sort left unused (fewer blocks split than the grid allows)
         parts_lg = (int)(e >> 30);
         part = (int)((e >> 28) & 3u);
-        if (MODE != 1) {                  // (split orders are only written for the shapes that steal)
+        if (MODE != 1 && MODE != 3) {     // (split orders are only written for the shapes that steal)
             if (part) return;
             parts_lg = 0;
         }
@@ -578,6 +695,15 @@ __global__ __launch_bounds__(BS) void k_query_direct(tr_bvh_view b, RayFetch rf,
         __shared__ int32_t leafq_lds[TR_LEAFQ * BS];
         const tr_leafq lq = {leafq_lds + threadIdx.x, BS};
         process_ray_unordered<Q, STATS, COMPACT, DEEP>(b, rf, out, i, i < rf.n, &cnt, ring, lq, steal_min);
+    } else if (MODE == 3) {
+        // unordered schedule + stealing: leaf vote (bits 0-7) | trip from which a ray gives subtrees away
+        // (bits 8-19) | the same for split blocks (bits 20-31)
+        __shared__ int32_t leafq_lds[TR_LEAFQ * BS];
+        const tr_leafq lq = {leafq_lds + threadIdx.x, BS};
+        const bool mine = (((int)threadIdx.x ^ part) & ((1 << parts_lg) - 1)) == 0;
+        const uint32_t smin = parts_lg ? ((uint32_t)steal_min >> 20) & 0xfffu : ((uint32_t)steal_min >> 8) & 0xfffu;
+        process_ray_unordered<Q, STATS, COMPACT, DEEP, true>(b, rf, out, i, i < rf.n && mine, &cnt, ring, lq,
+                                                            steal_min & 0xff, smin);
     } else if (MODE == 1) {
         __shared__ alignas(8) int32_t steal_lds[(BS / 64) * 384];
         // A split block (one of the most expensive of the previous launch): this slot owns the rays
@@ -707,7 +833,7 @@ __global__ __launch_bounds__(1024) void k_sched_sort(uint32_t* __restrict__ cost
             const uint32_t x = k & 7u, e = k >> 3;
             const uint32_t sp = nsplit[x], q4 = sp >> 2;
             const uint32_t len = (uint32_t)((nblocks >> 3) + (((uint32_t)nblocks & 7u) > x ? 1 : 0));
-            if (e >= sp + 2u * q4) order[(len + e) * 8u + x] = 0x0fffffffu;
+            if (e >= sp + 2u * q4) order[(len + e) * 8u + x] = 0x07ffffffu;
         }
     }
     for (int i = tid; i < nblocks; i += 1024) {
@@ -1250,7 +1376,7 @@ void sched_acquire(const tr_bvh* bvh, const tr_options& opt, hipStream_t stream,
     if (!opt.adaptive || !mb->sched_mutex || nblocks < 64 || nblocks > TR_SCHED_MAX) return;
     // launches with split blocks (the stealing shapes) and launches without learn separate orders:
     // their costs differ, and a plain shape would only skip the extra slots of a split order
-    const int cls = split > 0;
+    const int cls = split != 0;
     std::lock_guard<std::mutex> lock(*mb->sched_mutex);
     tr_sched_slot* slot = sched_slot(mb, stream, cls);
     if (!slot) return;
@@ -1465,6 +1591,9 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
         // any where stealing is not in play).  Hierarchies only (a single triangle has none).
         const bool unord = opt.unordered && !steal && bvh->num_tris >= 2 &&
                            (Q == TR_Q_COUNT || Q == TR_Q_LOCATION || (Q == TR_Q_ANY && opt.unordered > 1));
+        // ... with hand-over of owed subtrees between the lanes of a wave and split launch slots (count;
+        // wave_count_unordered_steal).  usteal: 0 off, 1 on, >= 2 forced with that trip threshold.
+        const bool usteal = unord && Q == TR_Q_COUNT && !STATS && bs == 128 && opt.usteal > 0;
         // Block splitting: the nblocks >> N most expensive blocks of the previous launch get two launch
         // slots each.  A launch ends with its most expensive waves (scripts/exp_timeline.py: with 8x8
         // tiles everything but ~100 waves of the headline image is done after 215 us of 320), and those
@@ -1477,8 +1606,8 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
         const bool small_tris = rf.n >= 8 * bvh->num_tris;   // triangles of many pixels: flat tiles, balanced waves
         const bool can_tile8 = opt.tile && rf.s1 > 1 && rf.s2 % 8 == 0 && rf.s2 >= 8 && rf.s2 < (1 << 28) && rf.n % (8 * rf.s2) == 0;
         int split_shift = 0;
-        if (steal && opt.split > 1) split_shift = opt.split;
-        else if (steal && opt.split == 1 && rf.n <= ((int64_t)1 << 22) && Q != TR_Q_COUNT) {
+        if ((steal || usteal) && opt.split > 1) split_shift = opt.split;
+        else if ((usteal || (steal && Q != TR_Q_COUNT)) && opt.split == 1 && rf.n <= ((int64_t)1 << 22)) {
             // (the fewer waves a launch has, the more of them are worth splitting: at 262 k rays -- 2 048
             // blocks, 0.6 waves per slot of the chip -- a quarter of the blocks, 0.136 -> 0.115 ms; at
             // 410 k rays an eighth, 0.142 -> 0.125 ms: profiles/r03_sweep_small_split.jsonl)
@@ -1489,6 +1618,7 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
         if (split_shift > 0 && bs == 128 && nblocks_direct >= (opt.split > 1 ? 64 : 512)) split = (nblocks_direct >> split_shift) / 8;
         if (nblocks_direct + 12 * split > TR_SCHED_MAX || !opt.adaptive) split = 0;   // no learned order, no split
         const int64_t split4 = split >> 2;
+        const int64_t split_key = split;
         // ... of which the sort behind the launch really splits the blocks that stick out of the measured
         // cost distribution (k_sched_sort): at least outlier8 / 8 times the mean block cost.  A launch that
         // leaves wave slots of the chip empty can afford to split whatever is above the mean (262 k rays of
@@ -1505,10 +1635,10 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
         const uint32_t* order = nullptr;
         uint32_t* cost = nullptr;
         hipEvent_t gn_after = nullptr;      // node-flavour tuner: event to record behind this launch
-        if (!STATS) sched_acquire(bvh, opt, stream, nblocks_direct, split, &order, &cost);
-        const int64_t nslots = nblocks_direct + (order ? 8 * (split + 2 * split4) : 0);
+        if (!STATS) sched_acquire(bvh, opt, stream, nblocks_direct, split_key, &order, &cost);
         // ... and with split blocks the pruning queries take 8x8 tiles at any size
         if (split > 0 && can_tile8 && !small_tris && opt.tile_small == 4) tile_w = (int)rf.s2 | (3 << 28);
+        const int64_t nslots = nblocks_direct + (order ? 8 * (split + 2 * split4) : 0);
         int scramble = 0;
         if (xc > 0 && opt.scramble) {
             const int64_t cnt = nblocks_direct / (8 * (int64_t)xc) * xc;   // blocks per XCD in whole spans
@@ -1517,7 +1647,7 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
         }
 #define TR_LAUNCH_DIRECT(C, B, D)                                                                          \
     hipLaunchKernelGGL((k_query_direct<Q, STATS, C, B, 0, D>), dim3((unsigned)nslots), dim3(B), 0, stream, \
-                       view, rf, out, xc, scramble, tile_w, steal_min, order, (int)split, cost, d_stats, sel)
+                       view, rf, out, xc, scramble, tile_w, steal_min, order, (int)split_key, cost, d_stats, sel)
         bool qn_used = false;          // set by the stealing branch below
         static const bool debug_launch = getenv("TRIRO_DEBUG_LAUNCH") != nullptr;
         if (debug_launch)
@@ -1527,12 +1657,30 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
         if (unord) {
             if constexpr (Q == TR_Q_COUNT || Q == TR_Q_LOCATION || Q == TR_Q_ANY) {
                 const int leaf_min = opt.leaf_vote;
+                if constexpr (Q == TR_Q_COUNT && !STATS) {
+                    if (usteal) {
+                        // leaf vote | trip threshold of ordinary blocks | of split blocks
+                        const int us_min = opt.usteal > 1 ? opt.usteal : 16;
+                        const int uarg = (leaf_min & 0xff) | ((us_min & 0xfff) << 8) | ((opt.split_steal & 0xfff) << 20);
+                        if (compact)
+                            hipLaunchKernelGGL((k_query_direct<Q, false, true, 128, 3, false>), dim3((unsigned)nslots), dim3(128), 0, stream,
+                                               view, rf, out, xc, scramble, tile_w, uarg, order, (int)split_key, cost, d_stats, sel);
+                        else if (deep)
+                            hipLaunchKernelGGL((k_query_direct<Q, false, true, 128, 3, true>), dim3((unsigned)nslots), dim3(128), 0, stream,
+                                               view, rf, out, xc, scramble, tile_w, uarg, order, (int)split_key, cost, d_stats, sel);
+                        else
+                            hipLaunchKernelGGL((k_query_direct<Q, false, false, 128, 3, false>), dim3((unsigned)nslots), dim3(128), 0, stream,
+                                               view, rf, out, xc, scramble, tile_w, uarg, order, (int)split_key, cost, d_stats, sel);
+                    }
+                }
+                if (!usteal) {
 #define TR_LAUNCH_UNORD(C, B, D)                                                                            \
     hipLaunchKernelGGL((k_query_direct<Q, STATS, C, B, 2, D>), dim3((unsigned)nslots), dim3(B), 0, stream, \
-                       view, rf, out, xc, scramble, tile_w, leaf_min, order, (int)split, cost, d_stats, sel)
+                       view, rf, out, xc, scramble, tile_w, leaf_min, order, (int)split_key, cost, d_stats, sel)
                 if (bs == 64) { if (compact) TR_LAUNCH_UNORD(true, 64, false); else TR_LAUNCH_UNORD(false, 64, false); }
                 else if (bs == 128) { if (compact) TR_LAUNCH_UNORD(true, 128, false); else if (deep) TR_LAUNCH_UNORD(true, 128, true); else TR_LAUNCH_UNORD(false, 128, false); }
                 else { if (compact) TR_LAUNCH_UNORD(true, 256, false); else TR_LAUNCH_UNORD(false, 256, false); }
+                }
 #undef TR_LAUNCH_UNORD
             }
         } else
@@ -1552,24 +1700,24 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
             if constexpr (Q == TR_Q_CLOSEST || Q == TR_Q_FIRST) {
                 if (qn && compact) {
                     hipLaunchKernelGGL((k_query_direct<Q, false, true, 128, 1, false, true>), dim3((unsigned)nslots), dim3(128), 0, stream,
-                                       view, rf, out, xc, scramble, tile_w, steal_arg, order, (int)split, cost, d_stats, sel);
+                                       view, rf, out, xc, scramble, tile_w, steal_arg, order, (int)split_key, cost, d_stats, sel);
                     steal_launched = true;
                 } else if (qn && deep) {
                     hipLaunchKernelGGL((k_query_direct<Q, false, true, 128, 1, true, true>), dim3((unsigned)nslots), dim3(128), 0, stream,
-                                       view, rf, out, xc, scramble, tile_w, steal_arg, order, (int)split, cost, d_stats, sel);
+                                       view, rf, out, xc, scramble, tile_w, steal_arg, order, (int)split_key, cost, d_stats, sel);
                     steal_launched = true;
                 }
             }
             if (steal_launched) {
             } else if (compact)
                 hipLaunchKernelGGL((k_query_direct<Q, false, true, 128, 1>), dim3((unsigned)nslots), dim3(128), 0, stream,
-                                   view, rf, out, xc, scramble, tile_w, steal_arg, order, (int)split, cost, d_stats, sel);
+                                   view, rf, out, xc, scramble, tile_w, steal_arg, order, (int)split_key, cost, d_stats, sel);
             else if (deep)
                 hipLaunchKernelGGL((k_query_direct<Q, false, true, 128, 1, true>), dim3((unsigned)nslots), dim3(128), 0, stream,
-                                   view, rf, out, xc, scramble, tile_w, steal_arg, order, (int)split, cost, d_stats, sel);
+                                   view, rf, out, xc, scramble, tile_w, steal_arg, order, (int)split_key, cost, d_stats, sel);
             else
                 hipLaunchKernelGGL((k_query_direct<Q, false, false, 128, 1>), dim3((unsigned)nslots), dim3(128), 0, stream,
-                                   view, rf, out, xc, scramble, tile_w, steal_arg, order, (int)split, cost, d_stats, sel);
+                                   view, rf, out, xc, scramble, tile_w, steal_arg, order, (int)split_key, cost, d_stats, sel);
         } else
         if (bs == 64) { if (compact) TR_LAUNCH_DIRECT(true, 64, false); else TR_LAUNCH_DIRECT(false, 64, false); }
         else if (bs == 128) { if (compact) TR_LAUNCH_DIRECT(true, 128, false); else if (deep) TR_LAUNCH_DIRECT(true, 128, true); else TR_LAUNCH_DIRECT(false, 128, false); }
@@ -1584,13 +1732,13 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
             std::lock_guard<std::mutex> lock(*mb->sched_mutex);
             tr_launch_info& li = mb->last_launch;
             li.rays = rf.n; li.blocks = nblocks_direct; li.slots = nslots; li.query = Q;
-            li.shape = unord ? 2 : (steal ? 1 : 0);
+            li.shape = unord ? (usteal ? 3 : 2) : (steal ? 1 : 0);
             li.tile_rows_lg = tile_w ? (tile_w >> 28) & 3 : 0;
             li.split_blocks = order ? (int32_t)split : 0;
+            li.reserved = 0;
             li.learned_order = order != nullptr;
             li.grid_nodes = qn_used || unord;
             li.addressing = compact ? 1 : (deep ? 2 : 0);
-            li.reserved = 0;
             mb->have_last_launch = true;
         }
     }
@@ -1827,6 +1975,11 @@ int tr_trace_stats_closest(const tr_bvh* bvh, const tr_rays* rays, tr_trace_stat
 
 }  // extern "C"
 
+#ifdef TR_USTEAL_DEBUG
+extern "C" int tr_debug_usteal(unsigned* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_usteal_debug), 16);
+}
+#endif
 #ifdef TR_TIMELINE
 extern "C" int tr_debug_timeline(unsigned long long* host_out, long long n_waves) {
     if (n_waves > TR_TIMELINE) n_waves = TR_TIMELINE;
