@@ -15,5 +15,5 @@ rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_l2 -- p
 rocprofv3 --pmc TA_TA_BUSY_sum TD_TD_BUSY_sum GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_ta -- python3 $REPO/scripts/run_query.py $ARGS > $OUT/pmc_ta.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/scripts/run_query.py $ARGS > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $REPO/scripts/run_query.py $ARGS > $OUT/pmc_write.log 2>&1
-cd $REPO && PROFILE_CMD="scripts/run_query.py $ARGS" python3 scripts/summarize_profile.py $TAG k_query_direct > $OUT/summary.txt 2>&1
+cd $REPO && PROFILE_CMD="scripts/run_query.py $ARGS" python3 scripts/summarize_profile.py $TAG ${KERNEL_KEY:-k_query_direct} > $OUT/summary.txt 2>&1
 tail -25 $OUT/summary.txt

@@ -35,6 +35,7 @@ ap.add_argument("--subdiv", type=int, default=8, help="c5i / c5s: icosphere subd
 ap.add_argument("--flat", action="store_true", help="pass image-shaped rays as a flat [N, 3] batch")
 ap.add_argument("--stats", action="store_true", help="also run the instrumented kernel (traversal counters)")
 ap.add_argument("--each", action="store_true", help="also print the time of every step")
+ap.add_argument("--presort", type=int, default=0, help="c3 / c5s: sort the rays by (origin cell with this many bits per axis, direction octant) BEFORE the timed region")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)  # noqa: E731
@@ -74,6 +75,16 @@ else:
     if a.flat:
         o, d = o.reshape(-1, 3).contiguous(), d.reshape(-1, 3).contiguous()
     n = a.res * a.res
+if a.presort > 0:
+    lo_t = torch.as_tensor(v.min(0) * 1.5, device=dev)
+    ext_t = torch.as_tensor(v.max(0) * 1.5 - v.min(0) * 1.5, device=dev)
+    cell = ((o.reshape(-1, 3) - lo_t) / ext_t * (1 << a.presort)).clamp_(0, (1 << a.presort) - 1).to(torch.int32)
+    key = (((cell[:, 0] << a.presort) | cell[:, 1]) << a.presort) | cell[:, 2]
+    dd = d.reshape(-1, 3)
+    key = (key << 3) | ((dd[:, 0] < 0).to(torch.int32) << 2) | ((dd[:, 1] < 0).to(torch.int32) << 1) | (dd[:, 2] < 0).to(torch.int32)
+    perm = torch.sort(key)[1]
+    o, d = o.reshape(-1, 3)[perm].contiguous(), dd[perm].contiguous()
+    del cell, key, perm, dd
 fn = {"closest": lambda: r.intersects_closest(o, d), "any": lambda: r.intersects_any(o, d),
       "first": lambda: r.intersects_first(o, d), "count": lambda: r.intersects_count(o, d),
       "location": lambda: r.intersects_location(o, d),

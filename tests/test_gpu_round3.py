@@ -178,7 +178,7 @@ def test_unordered_count_with_stealing_matches_the_oracle(device, usteal, split)
     learned order -> split slots), interleaved with closest launches of the same batch."""
     import triro.backend.ops as hops
     from test_gpu_round2 import on_surface_rays
-    v, f = W.nested_shells(4)
+    v, f = W.nested_shells(4, radii=(1.0, 0.8, 0.6, 0.45, 0.3))    # up to 10 hits per ray: beyond the cap of 8
     r = make(v, f, device)
     R = OracleIntersector(v, f, 1)
     o_img, d_img = W.pinhole_grid(512, 384)                       # 196 608 rays = 1 536 blocks
@@ -193,12 +193,17 @@ def test_unordered_count_with_stealing_matches_the_oracle(device, usteal, split)
         for name, o, d in cases:
             cnt = R.intersects_count(o.reshape(-1, 3), d.reshape(-1, 3))
             tri = R.closest_raw(o.reshape(-1, 3), d.reshape(-1, 3))[2]
+            e_loc, e_ray, e_tri = R.intersects_location(o.reshape(-1, 3), d.reshape(-1, 3))
             ot, dt = T(o, device), T(d, device)
             for rep in range(7):
                 got = r.intersects_count(ot, dt).cpu().numpy().reshape(-1)
                 assert np.array_equal(got, cnt), f"{name} usteal={usteal} split={split} launch {rep}: {int((got != cnt).sum())} rays differ"
                 if rep % 3 == 2:
                     assert np.array_equal(r.intersects_first(ot, dt).cpu().numpy().reshape(-1), tri)
+                if rep % 2 == 1:       # the multi-hit list shared by the lanes that work on a ray
+                    loc, ray, tri_l = r.intersects_location(ot, dt)
+                    assert np.array_equal(ray.cpu().numpy(), e_ray) and np.array_equal(tri_l.cpu().numpy(), e_tri), f"{name} location launch {rep}"
+                    assert np.array_equal(loc.cpu().numpy(), e_loc)
             if name == "image" and usteal:
                 li = r.as_wrapper.last_launch()
                 assert li["shape"] == 3 and li["learned_order"] == 1, li

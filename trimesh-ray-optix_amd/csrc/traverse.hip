@@ -459,7 +459,11 @@ __device__ unsigned g_usteal_debug[4];
 // 230 k rays 0.254 -> 0.164 (profiles/r03_sweep_usteal.jsonl).  A launch of several rounds of EQUALLY
 // long waves (C4 at 1 M rays) gains nothing, also not from splitting the blocks of its last round
 // (tried: the ramp-down is half a wave's time whatever the last waves are, and split waves are not
-// 2-4x shorter; r03_sweep_usteal_uniform.jsonl).  Hand-over as in wave_traverse_steal, with two differences: (1) no LDS scratch --
+// 2-4x shorter; r03_sweep_usteal_uniform.jsonl).  The multi-hit list query stays on the plain unordered
+// schedule: a list that several lanes append to needs its fill count in one place and its overflow
+// path (a ray with more than `cap` hits replaces its farthest entry) serialised -- built and measured:
+// headline location -25 %, but C4 +5 % and the interior scene, where rays have up to 13 hits, 5x SLOWER
+// (profiles/r03_location_steal_experiment.jsonl).  Hand-over as in wave_traverse_steal, with two differences: (1) no LDS scratch --
 // the kernel sits exactly at the LDS budget of 7 waves per SIMD (ring + leaf queue), so donor lanes
 // are listed with ds_permute / ds_bpermute and counts are handed in through v_readlane loops; (2) the
 // merge is a sum, order-free.  Any partition of a tree among lanes visits the same leaves, so the
@@ -922,8 +926,16 @@ __global__ __launch_bounds__(256) void k_probe_coherence(RayFetch rf, float scen
     }
 }
 
+// The streaming launch is latency-bound (incoherent rays: 62 % of the wave cycles wait on memory,
+// profiles/r03_c5s_summary.md), and its closest-hit instantiation needs 65-67 registers -- one to three
+// more than the 64 that allow 8 instead of 7 waves per SIMD.  Ask the compiler for 8: the compact
+// instantiations fit without a spill (C3 first -7 %, count -5 %, closest / any -2.5 %, C5(ii) shard -2 %:
+// profiles/r03_ab_stream_8waves.jsonl).
+#ifndef TR_STREAM_OCC
+#define TR_STREAM_OCC __attribute__((amdgpu_waves_per_eu(8, 8)))
+#endif
 template <int Q, bool STATS, bool COMPACT, int BS, bool DEEP = false>
-__global__ __launch_bounds__(BS) void k_query_stream(tr_bvh_view b, RayFetch rf, QueryOut out,
+__global__ __launch_bounds__(BS) TR_STREAM_OCC void k_query_stream(tr_bvh_view b, RayFetch rf, QueryOut out,
                                                      int rays_per_wave, int refill_min, int xcd_map,
                                                      unsigned long long* stats,
                                                      const int* __restrict__ sel,
