@@ -241,7 +241,10 @@ int tr_trace_stats_query(const tr_bvh *bvh, const tr_rays *rays, int query, tr_t
  *    ones that cost at least "split_outlier" eighths of the mean block cost and at least "split_floor"
  *    microseconds per wave are really split -- decided on the device from the measured costs).
  *    "usteal" (0 off / 1 on / N >= 2 forced with that trip threshold: count launches of the unordered
- *    schedule hand owed subtrees over between the lanes of a wave and take split launch slots).
+ *    schedule hand owed subtrees over between the lanes of a wave and take split launch slots),
+ *    "lds_top" (0 off / 1 at 128-thread blocks / 2 at 256-thread blocks: closest and first launches that
+ *    steal read the grid nodes of the top 7 levels of the hierarchy from a 4-KiB table staged in LDS
+ *    while a wave descends them in lockstep -- the north_star's "LDS-staged node packets").
  *    "grid_nodes" (0 never / 1 measured on the first launches of a batch size / 2 always: closest and first launches that steal walk the
  *    32-byte grid nodes -- two 16-byte loads per visit -- instead of the exact 64-byte nodes).
  *    None of them changes results.  Returns TR_ERR_INVALID_ARG for unknown names or values out

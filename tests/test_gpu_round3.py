@@ -213,3 +213,56 @@ def test_unordered_count_with_stealing_matches_the_oracle(device, usteal, split)
     finally:
         for k, val in (("usteal", 1), ("split", 1), ("split_floor", 40)):
             hops.set_option(k, val)
+
+
+@pytest.mark.parametrize("lds_top", [1, 2])
+def test_lds_staged_node_packets_match_the_oracle(device, lds_top):
+    """north_star "LDS-staged node packets" (option lds_top): closest / first launches that steal read the
+    grid nodes of the top 7 levels from a table staged in LDS while a wave descends them in lockstep.
+    Image (tiles), flat, on-surface and hash batches, several launches each, a refit and a rebuild in
+    between (the table is derived data), a save / load round trip, and a mesh smaller than the table."""
+    import triro.backend.ops as hops
+    from test_gpu_round2 import on_surface_rays
+    from triro.ray.ray_optix import RayMeshIntersector
+    v, f = W.icosphere(5)
+    v = W.displaced(v, seed=4, amplitude=0.07)
+    r = make(v, f, device)
+    o_img, d_img = W.pinhole_grid(384, 256, distance=2.5)
+    try:
+        hops.set_option("lds_top", lds_top)
+        for step, (vv, how) in enumerate([(v, "build"), (W.displaced(v, seed=9, amplitude=0.03), "refit"), (v * np.float32(1.1), "update")]):
+            if how == "refit":
+                r.refit(T(vv, device))
+            elif how == "update":
+                r.update_raw(T(vv, device), T(f, device))
+            R = OracleIntersector(vv, f, 1)
+            o_on, d_on = on_surface_rays(vv, f, r, device, n_each=1200, seed=step)
+            o_h, d_h = W.hash_rays(70_000, 11 + step, vv.min(0) * 1.3, vv.max(0) * 1.3)
+            for name, o, d in (("image", o_img, d_img), ("flat", o_img.reshape(-1, 3), d_img.reshape(-1, 3)), ("on-surface", o_on, d_on), ("hash", o_h, d_h)):
+                exp = R.closest_raw(o.reshape(-1, 3), d.reshape(-1, 3))
+                ot, dt = T(o, device), T(d, device)
+                for rep in range(4):
+                    got = [g.reshape((-1,) + tuple(g.shape[o.ndim - 1:])) for g in r.intersects_closest(ot, dt)]
+                    for g, e in zip(got, exp[:5]):
+                        assert np.array_equal(g.cpu().numpy(), e), f"lds_top={lds_top} {how} {name} launch {rep}"
+                    assert np.array_equal(r.intersects_first(ot, dt).cpu().numpy().reshape(-1), exp[2])
+            li = r.as_wrapper.last_launch()
+            assert li["grid_nodes"] == 1 and li["shape"] == 1
+        import tempfile, os
+        with tempfile.TemporaryDirectory() as td:
+            r.save(os.path.join(td, "m"))
+            r2 = RayMeshIntersector.load(os.path.join(td, "m"), device=device)
+        a, b2 = r.intersects_closest(T(o_img, device), T(d_img, device)), r2.intersects_closest(T(o_img, device), T(d_img, device))
+        for x, y in zip(a, b2):
+            assert torch.equal(x, y)
+        # a mesh with fewer internal nodes than table slots
+        vs, fs = W.icosphere(1)
+        rs, Rs = make(vs, fs, device), OracleIntersector(vs, fs, 1)
+        os_, ds_ = W.pinhole_grid(128, 128, distance=3.0)
+        exp = Rs.closest_raw(os_.reshape(-1, 3), ds_.reshape(-1, 3))
+        for rep in range(3):
+            got = rs.intersects_closest(T(os_, device), T(ds_, device))
+            for g, e in zip(got, exp[:5]):
+                assert np.array_equal(g.cpu().numpy().reshape(e.shape), e)
+    finally:
+        hops.set_option("lds_top", 0)

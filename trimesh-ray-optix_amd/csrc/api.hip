@@ -44,6 +44,7 @@ const opt_desc OPTS[] = {
     {"split_steal", &tr_options::split_steal, 0, 4096, false},
     {"split_outlier", &tr_options::split_outlier, 0, 1024, false},
     {"usteal", &tr_options::usteal, 0, 4095, false},
+    {"lds_top", &tr_options::lds_top, 0, 2, false},
     {"split_floor", &tr_options::split_floor, 0, 100000, false},
 };
 constexpr int NUM_OPTS = (int)(sizeof(OPTS) / sizeof(OPTS[0]));
@@ -258,6 +259,7 @@ int tr_bvh_deserialize(const void* h_buffer, int64_t size, void* stream, tr_bvh*
             bvh->num_tris = h.num_tris; bvh->num_nodes = h.num_nodes; bvh->depth = h.depth; bvh->key_mode = h.key_mode;
             for (int k = 0; k < 3; k++) { bvh->aabb_min[k] = h.aabb_min[k]; bvh->aabb_max[k] = h.aabb_max[k]; }
             tr_qframe_make(bvh->aabb_min, bvh->aabb_max, &bvh->frame);   // the grid is a function of the bounds
+            s = tr_top_table_update(bvh, (hipStream_t)stream);            // derived data, not part of the blob
         }
     }
     if (s != TR_OK) {
@@ -278,6 +280,7 @@ int tr_bvh_destroy(tr_bvh* bvh) {
         if (g.enter(bvh->device) == TR_OK) {
             if (bvh->arena && hipFree(bvh->arena) != hipSuccess) status = tr_fail(TR_ERR_HIP, "hipFree(arena)");
             if (bvh->refit_temp && hipFree(bvh->refit_temp) != hipSuccess) status = tr_fail(TR_ERR_HIP, "hipFree(refit_temp)");
+            if (bvh->top_table && hipFree(bvh->top_table) != hipSuccess) status = tr_fail(TR_ERR_HIP, "hipFree(top_table)");
             for (int k = 0; k < TR_SCHED_SLOTS; k++) {
                 if (bvh->sched[k].buf && hipFree(bvh->sched[k].buf) != hipSuccess) status = tr_fail(TR_ERR_HIP, "hipFree(sched)");
                 for (int e = 0; e < 8; e++)

@@ -71,6 +71,7 @@ struct tr_bvh {
     tr_qframe frame = {{0, 0, 0}, {1, 1, 1}};   // their grid: a function of the bounds below
     float aabb_min[3] = {0, 0, 0};
     float aabb_max[3] = {0, 0, 0};
+    tr_qnode* top_table = nullptr;   // grid nodes of the top TR_TOP_LEVELS levels in heap order (own 4-KiB allocation; derived data)
     void* refit_temp = nullptr;   // boxes + flags of tr_bvh_refit, kept between calls (animation loops)
     size_t refit_temp_bytes = 0;
     // adaptive launch order (speed only, see traverse.hip).  One slot per stream that has
@@ -114,6 +115,8 @@ int64_t tr_arena_used_bytes(int64_t nf);
 void tr_bvh_reset(tr_bvh* bvh);
 int tr_refit_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_t* d_faces,
                   int64_t nf, hipStream_t stream);
+// (re)derive the heap-ordered table of the top levels from the grid nodes (after build, refit, upload)
+int tr_top_table_update(tr_bvh* bvh, hipStream_t stream);
 
 // Makes `device` current for the lifetime of the guard (every entry point that launches on or
 // copies from a handle's arena runs under one: a C caller may be on another current device).
@@ -160,6 +163,7 @@ struct tr_options {
     int split_outlier = 1;    // ... but only blocks that cost at least N eighths of the mean block cost (0: all of them, 1: N by how full the chip is)
     int split_floor = 40;     // ... and at least this many microseconds (device clock) per wave
     int leaf_vote = 32;   // unordered schedule: lanes with a queued leaf that fire a leaf phase
+    int lds_top = 0;      // LDS-staged node packets for closest / first launches that steal: 0 off, 1 at 128-thread blocks, 2 at 256-thread blocks
     int usteal = 1;       // unordered count launches hand owed subtrees over between lanes and use split launch slots: 0 off, 1 on, >= 2 forced trip threshold
 };
 tr_options tr_opts();   // snapshot by value

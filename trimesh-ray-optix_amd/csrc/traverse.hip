@@ -191,17 +191,54 @@ __device__ __forceinline__ int lane_rank(unsigned long long mask) {   // set bit
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
 
-template <int Q, bool STATS, bool COMPACT, bool DEEP = false, bool QN = false>
+// LT: LDS-staged node packets (north_star).  `toplds` holds the grid nodes of the top TR_TOP_LEVELS levels
+// in heap order (copied once per workgroup, k_query_direct).  A wave starts at the root with all of its
+// rays and walks the first levels in lockstep: as long as EVERY lane that visits a node this trip is still
+// on its first descent inside the table (hp != 0: its heap index), the records come from LDS
+// (two ds_read_b128) and the trip issues no node gather at all; the first trip on which a lane has
+// backtracked, taken stolen work or left the table ends it for the wave.  Same records, same arithmetic.
+template <int Q, bool STATS, bool COMPACT, bool DEEP = false, bool QN = false, bool LT = false>
 __device__ __forceinline__ bool wave_traverse_steal(const tr_bvh_view& b, tr_ray& r, bool go,
                                                     tr_result& res, tr_counters* cnt,
                                                     const tr_ring ring, int32_t* wl, int lane,
-                                                    uint32_t steal_min) {
+                                                    uint32_t steal_min, const tr_i4* toplds = nullptr) {
     typedef typename tr_word<COMPACT, DEEP>::T W;
     tr_result_init(res);
     tr_topk<1> top;
     tr_state_t<W, !QN> fs;
     tr_state_init(fs);
     if (!go) fs.node = -1;
+    uint32_t hp = (LT && go) ? 1u : 0u;      // heap index of the node this lane is at (0: not in the table)
+    bool table_live = LT;                    // wave-uniform: the lockstep descent through the table is still on
+    // one trip; with LT the record comes from the LDS table while the whole wave is inside it
+    auto trip_step = [&](auto test_tag) {
+        constexpr bool TEST = decltype(test_tag)::value;
+        if constexpr (LT && QN) {
+            if (table_live) {
+                const int32_t room = TEST ? fs.p2 : fs.p1;
+                const bool has_node = fs.node >= 0 && room < 0;
+                table_live = __ballot(has_node && hp == 0u) == 0ull && __ballot(has_node) != 0ull;
+                if (table_live) {
+                    typedef __attribute__((address_space(3))) const int32_t lds_ci32;
+                    lds_ci32* tp = (lds_ci32*)toplds + 8u * (has_node ? hp : 1u);
+                    tr_rec_q rec;
+                    rec.w0.x = tp[0]; rec.w0.y = tp[1]; rec.w0.z = tp[2]; rec.w0.w = tp[3];
+                    rec.w1.x = tp[4]; rec.w1.y = tp[5]; rec.w1.z = tp[6]; rec.w1.w = tp[7];
+                    if (!tr_done(fs)) {
+                        const uint32_t d0 = fs.depth;
+                        tr_fused_body<Q, 1, STATS, COMPACT, W, TEST>(b, r, fs, res, top, cnt, ring, has_node, rec);
+                        if (has_node) {
+                            // still descending?  c0 -> 2h, c1 -> 2h+1; anything else (backtrack, end) leaves the table
+                            const bool down = fs.depth == d0 + 1u && fs.depth < (uint32_t)TR_TOP_LEVELS;
+                            hp = !down ? 0u : (fs.node == rec.w1.z ? 2u * hp : (fs.node == rec.w1.w ? 2u * hp + 1u : 0u));
+                        }
+                    }
+                    return;
+                }
+            }
+        }
+        if (!tr_done(fs)) tr_fused_step<Q, 1, STATS, COMPACT, W, false, TEST, QN>(b, r, fs, res, top, cnt, ring);
+    };
     int owner = lane;          // lane whose ray this lane is working on
     bool split = false;        // wave-uniform: some ray is (or was) traversed by more than one lane
     uint32_t trip = 0;
@@ -247,11 +284,11 @@ __device__ __forceinline__ bool wave_traverse_steal(const tr_bvh_view& b, tr_ray
 #pragma unroll 1
 #if TR_ALTERNATE
         for (uint32_t k = 0; k <= TR_STEAL_EVERY; k += 1 + TR_ALTERNATE) {
-            if (!tr_done(fs)) tr_fused_step<Q, 1, STATS, COMPACT, W, false, true, QN>(b, r, fs, res, top, cnt, ring);
+            trip_step(std::true_type{});
             TR_CONVERGE();
 #pragma unroll
             for (int a = 0; a < TR_ALTERNATE; a++) {
-                if (!tr_done(fs)) tr_fused_step<Q, 1, STATS, COMPACT, W, false, false, QN>(b, r, fs, res, top, cnt, ring);
+                trip_step(std::false_type{});
                 TR_CONVERGE();
             }
         }
@@ -341,6 +378,7 @@ __device__ __forceinline__ bool wave_traverse_steal(const tr_bvh_view& b, tr_ray
                     fs.node = xnode[src];
                     fs.depth = (uint32_t)xdepth[src];
                     res.best_t = bt;
+                    hp = 0u;
                 }
                 __builtin_amdgcn_wave_barrier();
             }
@@ -402,18 +440,18 @@ __device__ __forceinline__ void process_ray(const tr_bvh_view& b, const RayFetch
     if (in_range) write_result<Q>(b, out, i, r, res);
 }
 
-template <int Q, bool STATS, bool COMPACT, bool DEEP = false, bool QN = false>
+template <int Q, bool STATS, bool COMPACT, bool DEEP = false, bool QN = false, bool LT = false>
 __device__ __forceinline__ void process_ray_steal(const tr_bvh_view& b, const RayFetch& rf,
                                                   const QueryOut& out, int64_t i, bool in_range,
                                                   tr_counters* cnt, const tr_ring ring, int32_t* wl,
-                                                  uint32_t steal_min) {
+                                                  uint32_t steal_min, const tr_i4* toplds = nullptr) {
     float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
     if (in_range) fetch_ray(rf, i, o, d);
     tr_ray r;
     const bool valid = tr_ray_setup(r, o[0], o[1], o[2], d[0], d[1], d[2]) && in_range;
     tr_result res;
     bool split = false;
-    if (b.num_tris >= 2) split = wave_traverse_steal<Q, STATS, COMPACT, DEEP, QN>(b, r, valid, res, cnt, ring, wl, (int)(threadIdx.x & 63), steal_min);
+    if (b.num_tris >= 2) split = wave_traverse_steal<Q, STATS, COMPACT, DEEP, QN, LT>(b, r, valid, res, cnt, ring, wl, (int)(threadIdx.x & 63), steal_min, toplds);
     else brute_one<Q>(b, r, valid, res);   // no hierarchy below two triangles
     if (split && in_range) {   // this lane may hold another lane's ray now: take its own again
         fetch_ray(rf, i, o, d);
@@ -611,7 +649,7 @@ __device__ unsigned long long g_timeline[4 * TR_TIMELINE];
 
 // MODE: 0 fused ordered trip, 1 fused trip + intra-wave work stealing, 2 unordered two-phase
 // schedule (any / count / location on hierarchies of at least two triangles)
-template <int Q, bool STATS, bool COMPACT, int BS, int MODE = 0, bool DEEP = false, bool QN = false>
+template <int Q, bool STATS, bool COMPACT, int BS, int MODE = 0, bool DEEP = false, bool QN = false, bool LT = false>
 __global__ __launch_bounds__(BS) void k_query_direct(tr_bvh_view b, RayFetch rf, QueryOut out,
                                                       int xcd_map, int scramble, int tile_w, int steal_min,
                                                       const uint32_t* __restrict__ order, int order_split,
@@ -633,6 +671,12 @@ __global__ __launch_bounds__(BS) void k_query_direct(tr_bvh_view b, RayFetch rf,
     const unsigned long long t_start = cost ? wall_clock64() : 0ull;
     __shared__ int32_t ring_lds[TR_RING * BS];
     const tr_ring ring = {ring_lds + threadIdx.x, BS};
+    // LDS-staged node packets: the top levels of the tree, once per workgroup (4 KiB, L2-resident source)
+    __shared__ tr_i4 top_lds[LT ? 2 * TR_TOP_SLOTS : 1];
+    if (LT) {
+        for (int k = threadIdx.x; k < 2 * TR_TOP_SLOTS; k += BS) top_lds[k] = reinterpret_cast<const tr_i4*>(b.top)[k];
+        __syncthreads();
+    }
     // XCD-aware block -> ray-tile map: workgroups are dealt round-robin over the 8 XCDs
     // (blocks b and b+8 share one).  The ray range is cut into chunks of `xcd_map` blocks and
     // chunk c goes to XCD c % 8, so each XCD's private L2 works on compact pieces of the image
@@ -715,8 +759,8 @@ __global__ __launch_bounds__(BS) void k_query_direct(tr_bvh_view b, RayFetch rf,
         // from the trip in the upper half of the argument on (the lower half: everybody else)
         const bool mine = (((int)threadIdx.x ^ part) & ((1 << parts_lg) - 1)) == 0;
         const uint32_t smin = parts_lg ? (uint32_t)steal_min >> 16 : (uint32_t)steal_min & 0xffffu;
-        process_ray_steal<Q, STATS, COMPACT, DEEP, QN>(b, rf, out, i, i < rf.n && mine, &cnt, ring,
-                                             steal_lds + (threadIdx.x >> 6) * 384, smin);
+        process_ray_steal<Q, STATS, COMPACT, DEEP, QN, LT>(b, rf, out, i, i < rf.n && mine, &cnt, ring,
+                                             steal_lds + (threadIdx.x >> 6) * 384, smin, top_lds);
 #ifdef TR_TIMELINE
         tl_extra = (unsigned)(steal_lds[(threadIdx.x >> 6) * 384] & 0xffff) |
                    ((unsigned long long)(steal_lds[(threadIdx.x >> 6) * 384 + 1] & 0xffff) << 16);
@@ -1322,6 +1366,7 @@ tr_bvh_view make_view(const tr_bvh* bvh) {
     tr_bvh_view v;
     v.nodes = bvh->nodes; v.links = bvh->links; v.tris = bvh->tris; v.num_tris = bvh->num_tris;
     v.qnodes = bvh->qnodes; v.frame = bvh->frame;
+    v.top = bvh->top_table;
     return v;
 }
 
@@ -1471,7 +1516,12 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
     TR_TRY(tr_get_device_state(bvh->device, &st));
     tr_bvh_view view = make_view(bvh);
     const tr_options opt = tr_opts();   // one snapshot per call
-    const int bs = opt.block_size;
+    // lds_top (LDS-staged node packets): 1 = at 128-thread blocks, 2 = at 256-thread blocks (where the table
+    // fits beside the far-child ring without costing a wave); closest / first launches that steal on the
+    // grid nodes only
+    const bool lt_query = (Q == TR_Q_CLOSEST || Q == TR_Q_FIRST) && !STATS && opt.lds_top > 0 && bvh->top_table != nullptr &&
+                          bvh->num_tris >= 2;
+    const int bs = (lt_query && opt.lds_top == 2) ? 256 : opt.block_size;
     const int64_t nblocks_direct = (rf.n + bs - 1) / bs;
     int64_t pgrid = (int64_t)st->num_cus * opt.blocks_per_cu;
     if (opt.persistent && Q != TR_Q_LOCATION) {   // the multi-hit list query has only the direct shape
@@ -1596,7 +1646,7 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
         // protect, but its waves are balanced enough).  steal >= 2 forces it on, with that trip
         // threshold, for closest / first / any / count at any size (tests).
         const int steal_min = opt.steal > 1 ? opt.steal : 64;
-        const bool steal = !STATS && bs == 128 &&
+        const bool steal = !STATS && (bs == 128 || (lt_query && bs == 256)) &&
                            ((opt.steal == 1 && rf.n <= ((int64_t)1 << 22) && (Q == TR_Q_CLOSEST || Q == TR_Q_FIRST || Q == TR_Q_ANY)) ||
                             (opt.steal > 1 && (Q == TR_Q_CLOSEST || Q == TR_Q_FIRST || Q == TR_Q_COUNT || Q == TR_Q_ANY)));
         // Unordered two-phase schedule for the queries that do not prune by distance (count, location;
@@ -1627,7 +1677,7 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
             else if (!can_tile8 && nblocks_direct <= 2048) split_shift = 4;
         }
         int64_t split = 0;
-        if (split_shift > 0 && bs == 128 && nblocks_direct >= (opt.split > 1 ? 64 : 512)) split = (nblocks_direct >> split_shift) / 8;
+        if (split_shift > 0 && (bs == 128 || lt_query) && nblocks_direct >= (opt.split > 1 ? 64 : 512)) split = (nblocks_direct >> split_shift) / 8;
         if (nblocks_direct + 12 * split > TR_SCHED_MAX || !opt.adaptive) split = 0;   // no learned order, no split
         const int64_t split4 = split >> 2;
         const int64_t split_key = split;
@@ -1709,8 +1759,21 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
                 qn = gn_pick(bvh, stream, split > 0, nblocks_direct * 8 + Q, &ev_before, &gn_after) != 0;
             if (ev_before) (void)hipEventRecord(ev_before, stream);
             qn_used = qn && (Q == TR_Q_CLOSEST || Q == TR_Q_FIRST) && (compact || deep);
+            if constexpr ((Q == TR_Q_CLOSEST || Q == TR_Q_FIRST) && !STATS) {
+                if (lt_query && compact) {       // the table holds grid nodes: this launch walks them
+                    qn_used = true;
+                    if (bs == 256)
+                        hipLaunchKernelGGL((k_query_direct<Q, false, true, 256, 1, false, true, true>), dim3((unsigned)nslots), dim3(256), 0, stream,
+                                           view, rf, out, xc, scramble, tile_w, steal_arg, order, (int)split_key, cost, d_stats, sel);
+                    else
+                        hipLaunchKernelGGL((k_query_direct<Q, false, true, 128, 1, false, true, true>), dim3((unsigned)nslots), dim3(128), 0, stream,
+                                           view, rf, out, xc, scramble, tile_w, steal_arg, order, (int)split_key, cost, d_stats, sel);
+                    steal_launched = true;
+                }
+            }
             if constexpr (Q == TR_Q_CLOSEST || Q == TR_Q_FIRST) {
-                if (qn && compact) {
+                if (steal_launched) {
+                } else if (qn && compact) {
                     hipLaunchKernelGGL((k_query_direct<Q, false, true, 128, 1, false, true>), dim3((unsigned)nslots), dim3(128), 0, stream,
                                        view, rf, out, xc, scramble, tile_w, steal_arg, order, (int)split_key, cost, d_stats, sel);
                     steal_launched = true;
