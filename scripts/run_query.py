@@ -44,7 +44,7 @@ for kv in a.opt:
     hops.set_option(k, int(v_))
 
 if a.config in ("c2", "c3"):
-    v, f = W.bunny_standin()
+    v, f, _bunny_label = W.bunny_mesh()
 elif a.config == "c4":
     v, f = W.nested_shells(7)
 elif a.config == "room":

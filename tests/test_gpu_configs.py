@@ -23,7 +23,7 @@ def make(v, f, dev):
 
 @pytest.fixture(scope="module")
 def bunny(device):
-    v, f = W.bunny_standin()                    # config 2/3 mesh (stand-in: no bunny file in the image)
+    v, f, _label = W.bunny_mesh()               # config 2/3 mesh: $TRIRO_BUNNY if supplied, else the labelled stand-in
     return v, f, make(v, f, device), OracleIntersector(v, f, 1)
 
 
@@ -32,7 +32,7 @@ def test_c2_bunny_standin_1024_pinhole_closest(bunny, device):
     o, d = W.pinhole_grid(1024, 1024, distance=2.5 * float(np.linalg.norm(v, axis=1).max()))
     hit, front, tri, loc, uv = [x.cpu().numpy() for x in r.intersects_closest(T(o, device), T(d, device))]
     eh, ef, et, el, eu, _ = R.closest_raw(o, d)
-    assert hit.shape == (1024, 1024) and 0.3 < hit.mean() < 0.9
+    assert hit.shape == (1024, 1024) and 0.05 < hit.mean() < 0.95
     assert np.array_equal(hit, eh) and np.array_equal(front, ef) and np.array_equal(tri, et)
     np.testing.assert_allclose(loc, el, rtol=RTOL, atol=ATOL)
     np.testing.assert_allclose(uv, eu, rtol=RTOL, atol=ATOL)

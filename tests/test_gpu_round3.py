@@ -101,7 +101,7 @@ def test_c5i_moving_camera_sequence_matches_the_oracle(headline, device):
 
 
 def test_c2_steady_state_launches_match_the_oracle(device):
-    v, f = W.bunny_standin()
+    v, f, _label = W.bunny_mesh()
     r, R = make(v, f, device), OracleIntersector(v, f, 1)
     o, d = W.pinhole_grid(1024, 1024, distance=2.5 * float(np.linalg.norm(v, axis=1).max()))
     infos = steady_state(r, R, o, d, device, "C2")

@@ -88,6 +88,100 @@ def bunny_standin():
     return displaced(v, seed=0, amplitude=0.12), f
 
 
+def load_mesh_file(path: str):
+    """Triangle mesh from a Stanford PLY (ascii or binary_little_endian; e.g. bun_zipper.ply) or a Wavefront
+    OBJ file -> (float32 [nv,3], int32 [nf,3]); polygons are fanned into triangles.  No trimesh needed."""
+    import os
+    ext = os.path.splitext(path)[1].lower()
+    if ext == ".obj":
+        vs, fs = [], []
+        for ln in open(path, errors="replace"):
+            t = ln.split()
+            if not t:
+                continue
+            if t[0] == "v":
+                vs.append([float(x) for x in t[1:4]])
+            elif t[0] == "f":
+                idx = [int(x.split("/")[0]) for x in t[1:]]
+                idx = [i - 1 if i > 0 else len(vs) + i for i in idx]
+                fs += [[idx[0], idx[k], idx[k + 1]] for k in range(1, len(idx) - 1)]
+        return np.asarray(vs, np.float32), np.asarray(fs, np.int32)
+    if ext != ".ply":
+        raise ValueError(f"unsupported mesh file type: {path}")
+    with open(path, "rb") as fh:
+        if fh.readline().strip() != b"ply":
+            raise ValueError("not a PLY file")
+        fmt, elems, cur = None, [], None
+        while True:
+            t = fh.readline().decode("ascii", "replace").split()
+            if not t:
+                continue
+            if t[0] == "format":
+                fmt = t[1]
+            elif t[0] == "element":
+                cur = {"name": t[1], "count": int(t[2]), "props": []}
+                elems.append(cur)
+            elif t[0] == "property":
+                cur["props"].append(t[1:])
+            elif t[0] == "end_header":
+                break
+        types = {"char": "i1", "uchar": "u1", "short": "i2", "ushort": "u2", "int": "i4", "uint": "u4", "float": "f4", "double": "f8",
+                 "int8": "i1", "uint8": "u1", "int16": "i2", "uint16": "u2", "int32": "i4", "uint32": "u4", "float32": "f4", "float64": "f8"}
+        v = f = None
+        if fmt == "ascii":
+            toks = fh.read().split()
+            pos = 0
+            for e in elems:
+                if e["name"] == "vertex":
+                    k = len(e["props"])
+                    names = [p[-1] for p in e["props"]]
+                    arr = np.array(toks[pos:pos + k * e["count"]], dtype=np.float64).reshape(e["count"], k)
+                    v = arr[:, [names.index("x"), names.index("y"), names.index("z")]]
+                    pos += k * e["count"]
+                elif e["name"] == "face":
+                    tris = []
+                    for _ in range(e["count"]):
+                        m = int(toks[pos])
+                        idx = [int(x) for x in toks[pos + 1:pos + 1 + m]]
+                        tris += [[idx[0], idx[j], idx[j + 1]] for j in range(1, m - 1)]
+                        pos += 1 + m
+                    f = np.asarray(tris)
+                else:
+                    raise ValueError("ascii PLY with extra elements is not supported")
+        elif fmt == "binary_little_endian":
+            for e in elems:
+                if e["name"] == "vertex":
+                    dt = np.dtype([(p[-1], "<" + types[p[0]]) for p in e["props"]])
+                    arr = np.frombuffer(fh.read(dt.itemsize * e["count"]), dt)
+                    v = np.stack([arr["x"], arr["y"], arr["z"]], 1)
+                elif e["name"] == "face":
+                    p = e["props"][0]            # list <count type> <index type> vertex_indices
+                    ct, it = np.dtype("<" + types[p[1]]), np.dtype("<" + types[p[2]])
+                    tris = []
+                    for _ in range(e["count"]):
+                        m = int(np.frombuffer(fh.read(ct.itemsize), ct)[0])
+                        idx = np.frombuffer(fh.read(it.itemsize * m), it)
+                        tris += [[idx[0], idx[j], idx[j + 1]] for j in range(1, m - 1)]
+                    f = np.asarray(tris)
+                else:
+                    raise ValueError("binary PLY with extra elements is not supported")
+        else:
+            raise ValueError(f"unsupported PLY format {fmt}")
+    return np.asarray(v, np.float32), np.asarray(f, np.int32)
+
+
+def bunny_mesh():
+    """BASELINE.md C2/C3 mesh: the file $TRIRO_BUNNY points to (canonical: bun_zipper.ply, 69 451 tris) if
+    set, else the labelled procedural stand-in.  Returns (vertices, faces, label)."""
+    import os
+    path = os.environ.get("TRIRO_BUNNY")
+    if path:
+        v, f = load_mesh_file(path)
+        return v, f, f"{os.path.basename(path)} ({len(f)} tris)"
+    v, f = bunny_standin()
+    return v, f, f"stand-in ({len(f)} tris; no Stanford bunny file in this image)"
+
+
 def headline_mesh(subdivisions: int = 8):
     """icosphere(8) = 1 310 720 tris + displacement, seed 0."""
     v, f = icosphere(subdivisions)
