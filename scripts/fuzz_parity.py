@@ -19,7 +19,7 @@ T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
 DEFAULTS = {"steal": 1, "tile": 1, "block_size": 128, "adaptive": 1, "xcd_chunk": 128, "compact": 1, "scramble": 1,
             "persistent": 0, "blocks_per_cu": 8,
             "tile_small": 4, "unordered": 1, "leaf_vote": 32, "stream": 1, "stream_rays": 256, "stream_refill": 32, "stream_dynamic": 1,
-            "split": 1, "split_steal": 8, "grid_nodes": 1}
+            "split": 1, "split_steal": 8, "grid_nodes": 1, "split_outlier": 1, "split_floor": 40, "usteal": 1, "lds_top": 0}
 bad = 0
 for it in range(a.iters):
     kind = rng.integers(0, 5)
@@ -64,7 +64,10 @@ for it in range(a.iters):
             "stream_refill": int(rng.choice([1, 8, 16, 40, 64])), "stream_dynamic": int(rng.choice([0, 1, 1])),
             # block splitting of the stealing launch shapes (from the second launch of a batch on)
             "split": int(rng.choice([0, 1, 1, 2, 3, 4])), "split_steal": int(rng.choice([0, 2, 8, 64])),
-            "grid_nodes": int(rng.choice([0, 1, 2, 2]))}
+            "grid_nodes": int(rng.choice([0, 1, 2, 2])),
+            # round 3: device-side split criterion, stealing in the unordered count launch, LDS-staged node packets
+            "split_outlier": int(rng.choice([0, 1, 1, 4, 8, 30])), "split_floor": int(rng.choice([0, 0, 0, 40])),
+            "usteal": int(rng.choice([0, 1, 1, 2, 8, 64])), "lds_top": int(rng.choice([0, 0, 1, 2]))}
     for k, val in opts.items(): hops.set_option(k, val)
     try:
         r = RayMeshIntersector(vertices=T(v), faces=T(f)); R = OracleIntersector(v, f, 1)
@@ -81,6 +84,9 @@ for it in range(a.iters):
             lo3, ra, tr_ = [x.cpu().numpy() for x in r.intersects_location(ot, dt)]
             el2, er2, et2 = R.intersects_location(of, df)
             ok &= np.array_equal(ra, er2) and np.array_equal(tr_, et2) and np.array_equal(lo3, el2)
+            # round 3: 12-byte packed closest records expand to the dense outputs bit for bit
+            exp5 = r.closest_expand(r.intersects_closest_packed(ot, dt), batch_shape=ot.shape[:-1])
+            ok &= all(np.array_equal(x.cpu().numpy().reshape(e.shape), e) for x, e in zip(exp5, (hit, front, tri, loc, uv)))
             if not ok: break
     finally:
         for k, val in DEFAULTS.items(): hops.set_option(k, val)

@@ -283,7 +283,7 @@ int tr_bvh_destroy(tr_bvh* bvh) {
             if (bvh->top_table && hipFree(bvh->top_table) != hipSuccess) status = tr_fail(TR_ERR_HIP, "hipFree(top_table)");
             for (int k = 0; k < TR_SCHED_SLOTS; k++) {
                 if (bvh->sched[k].buf && hipFree(bvh->sched[k].buf) != hipSuccess) status = tr_fail(TR_ERR_HIP, "hipFree(sched)");
-                for (int e = 0; e < 8; e++)
+                for (int e = 0; e < 16; e++)
                     if (bvh->sched[k].gn_ev[e]) (void)hipEventDestroy(bvh->sched[k].gn_ev[e]);
             }
         }

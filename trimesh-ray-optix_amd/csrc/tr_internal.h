@@ -50,7 +50,7 @@ struct tr_sched_slot {
     int gn_since = 0;       // launches since the last decision
     bool gn_final = false;
     bool gn_events = false;
-    hipEvent_t gn_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t gn_ev[16] = {};
     void gn_reset() { gn_key = 0; gn_count = 0; gn_choice = -1; gn_rounds = 0; gn_prev = -1; gn_since = 0; gn_final = false; }
 };
 

@@ -1452,16 +1452,17 @@ void sched_acquire(const tr_bvh* bvh, const tr_options& opt, hipStream_t stream,
 
 // Node flavour of a stealing closest / first launch under grid_nodes = 1.  Whether the 32-byte grid
 // nodes beat the exact ones depends on how many distinct nodes the lanes of a wave are on (headline
-// image -2...-5 %, 21 M triangles -8 %, the shell scene +1.5...+4 %), which the host cannot know -- so
-// it is measured: launches 0-4 of a (batch size, query) run on the exact nodes, 5-8 on the grid nodes;
-// the QUERY KERNELS of launches 3, 4, 7 and 8 are bracketed by events (the re-sort of the launch order
-// that may follow a launch is outside the bracket), and as soon as all four have completed the faster
-// flavour stays (the grid nodes have to win by 2 %).  One noisy sample must not pin a workload to the
-// slower flavour: the measurement is repeated 64 launches later and the decision is final once two
-// measurements agree (a third one, 128 launches on, breaks a tie).  A rebuild / refit starts over
-// (tr_build_impl, tr_bvh_reset).  Never blocks: until the events are done, and while a stream is being
-// captured, launches use the exact nodes.  Speed only.  *ev_before / *ev_after: events to record
-// immediately before / after this launch's query kernel.
+// image -3...-5 %, 21 M triangles -8 %, the shell scene +1.5...+4 %, the interior scene +20 %), which the
+// host cannot know -- so it is measured.  The two flavours differ by a few percent, so the measurement
+// has to be better than that: launches 4 ... 17 of a (batch size, query) ALTERNATE between the flavours
+// (even: exact, odd: grid -- clock ramps and the learning of the launch order hit both alike), the QUERY
+// KERNELS of four launches of each flavour are bracketed by events (4, 6, 8, 10 and 5, 9, 13, 17: never a
+// launch that also records block costs, every 4th), and when all eight have completed the grid nodes
+// stay if their four took less than 98.5 % of the exact nodes' four.  The measurement is repeated 64
+// launches later and is final once two agree (a third, 128 launches on, breaks a tie); a rebuild or refit
+// starts over.  Never blocks: until the events are done, and while a stream is being captured, launches
+// use the previous decision (exact nodes the first time).  Speed only.  *ev_before / *ev_after: events
+// to record immediately before / after this launch's query kernel.
 int gn_pick(const tr_bvh* bvh, hipStream_t stream, int cls, int64_t key, hipEvent_t* ev_before, hipEvent_t* ev_after) {
     *ev_before = nullptr; *ev_after = nullptr;
     tr_bvh* mb = const_cast<tr_bvh*>(bvh);
@@ -1478,20 +1479,26 @@ int gn_pick(const tr_bvh* bvh, hipStream_t stream, int cls, int64_t key, hipEven
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return t->gn_prev > 0; }
     if (!t->gn_events) {
-        for (int k = 0; k < 8; k++)
+        for (int k = 0; k < 16; k++)
             if (hipEventCreate(&t->gn_ev[k]) != hipSuccess) { (void)hipGetLastError(); t->gn_choice = 0; t->gn_final = true; return 0; }
         t->gn_events = true;
     }
     const int c = t->gn_count++;
-    const int sample = c == 3 ? 0 : (c == 4 ? 1 : (c == 7 ? 2 : (c == 8 ? 3 : -1)));
-    if (sample >= 0) { *ev_before = t->gn_ev[2 * sample]; *ev_after = t->gn_ev[2 * sample + 1]; }
-    if (c <= 4) return 0;
-    if (c <= 8) return 1;
-    if (hipEventQuery(t->gn_ev[3]) == hipSuccess && hipEventQuery(t->gn_ev[7]) == hipSuccess) {
-        float ms[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < 4) return t->gn_prev > 0;
+    if (c <= 17) {
+        const int flavour = c & 1;
+        int sample = -1;
+        if (!flavour && c <= 10) sample = (c - 4) >> 1;                    // exact: 4, 6, 8, 10
+        if (flavour && (c & 3) == 1) sample = 4 + ((c - 5) >> 2);          // grid: 5, 9, 13, 17
+        if (sample >= 0) { *ev_before = t->gn_ev[2 * sample]; *ev_after = t->gn_ev[2 * sample + 1]; }
+        return flavour;
+    }
+    if (hipEventQuery(t->gn_ev[7]) == hipSuccess && hipEventQuery(t->gn_ev[15]) == hipSuccess) {
+        float ms[8];
         bool ok = true;
-        for (int k = 0; k < 4; k++) ok = ok && hipEventElapsedTime(&ms[k], t->gn_ev[2 * k], t->gn_ev[2 * k + 1]) == hipSuccess && ms[k] > 0.f;
-        const int measured = ok && (ms[2] + ms[3]) < 0.98f * (ms[0] + ms[1]) ? 1 : 0;
+        for (int k = 0; k < 8; k++) { ms[k] = 0.f; ok = ok && hipEventElapsedTime(&ms[k], t->gn_ev[2 * k], t->gn_ev[2 * k + 1]) == hipSuccess && ms[k] > 0.f; }
+        const float exact = ms[0] + ms[1] + ms[2] + ms[3], grid = ms[4] + ms[5] + ms[6] + ms[7];
+        const int measured = ok && grid < 0.985f * exact ? 1 : 0;
         if (!ok) (void)hipGetLastError();
         t->gn_rounds++;
         t->gn_final = !ok || t->gn_rounds >= 3 || (t->gn_rounds == 2 && measured == t->gn_prev);
