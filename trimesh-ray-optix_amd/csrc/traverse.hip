@@ -1526,8 +1526,12 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
     // lds_top (LDS-staged node packets): 1 = at 128-thread blocks, 2 = at 256-thread blocks (where the table
     // fits beside the far-child ring without costing a wave); closest / first launches that steal on the
     // grid nodes only
+    // (only the compact instantiation exists: 32-bit offsets and trail words, i.e. arrays below 4 GiB and at
+    // most 32 levels; everything else keeps the ordinary launch and the caller's block size)
+    const bool lt_compact = opt.compact && bvh->depth <= 32 && bvh->num_nodes * (int64_t)sizeof(tr_node) < ((int64_t)1 << 32) &&
+                            bvh->num_tris * (int64_t)sizeof(tr_tri) < ((int64_t)1 << 32);
     const bool lt_query = (Q == TR_Q_CLOSEST || Q == TR_Q_FIRST) && !STATS && opt.lds_top > 0 && bvh->top_table != nullptr &&
-                          bvh->num_tris >= 2;
+                          bvh->num_tris >= 2 && lt_compact && !opt.persistent && (opt.block_size == 128 || opt.lds_top == 2);
     const int bs = (lt_query && opt.lds_top == 2) ? 256 : opt.block_size;
     const int64_t nblocks_direct = (rf.n + bs - 1) / bs;
     int64_t pgrid = (int64_t)st->num_cus * opt.blocks_per_cu;
