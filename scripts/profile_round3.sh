@@ -20,7 +20,7 @@ prof r03_roomcount k_query_direct --config room --query count
 prof r03_c5s k_query_stream --config c5s --query closest
 # the headline: kernel trace of the literal default command, then the PMC passes of the same kernel
 timeout 600 bash scripts/profile_default.sh r03m > /dev/null 2>&1
-PROFILE_STEPS=1000 python3 scripts/summarize_profile.py r03m k_query_direct > /dev/null 2>&1; cp profiles/r03m_summary.* gpurun_out/r03/
+PROFILE_CMD="bench.py (default flags: 1000 timed steps)" PROFILE_STEPS=1000 python3 scripts/summarize_profile.py r03m k_query_direct > /dev/null 2>&1; cp profiles/r03m_summary.* gpurun_out/r03/
 timeout 900 bash scripts/profile_bench.sh r03n --no-companions > /dev/null 2>&1
 python3 scripts/summarize_profile.py r03n k_query_direct > /dev/null 2>&1; cp profiles/r03n_summary.* gpurun_out/r03/
 cp profiles/r03n_summary.json profiles/r03_c5i_summary.json 2>/dev/null
