@@ -57,6 +57,9 @@ def parse(argv=None):
     ap.add_argument("--gather", action="store_true", help="(default for N > 1) results are gathered to rank 0 inside the timed region")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: leave every rank's results on its own GPU (no exchange)")
     ap.add_argument("--chunks", type=int, default=0, help="N > 1: chunks per shard of the trace / gather pipeline (0 = auto)")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="test aid: run the N > 1 result pipeline (packed trace, RCCL exchange, expansion on a side stream, "
+                         "double buffering) in a communicator of ONE rank -- what a single-GPU box can check of it; the line is labelled")
     ap.add_argument("--min-warmup-ms", type=float, default=50.0, help="keep warming up until this much time has passed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-companions", action="store_true", help="skip the cold / moving-camera / gather-ceiling companions")
@@ -274,8 +277,8 @@ def run_rank(args):
     build_ms = (time.perf_counter() - t0) * 1e3
     info = r.bvh_info()
 
-    gather_on = dist_on and world > 1 and not args.no_gather
-    S = ShardedRayMeshIntersector(r) if dist_on else None
+    gather_on = dist_on and (world > 1 or args.force_gather) and not args.no_gather
+    S = ShardedRayMeshIntersector(r, force_collectives=args.force_gather) if dist_on else None
     lead = origins.dim() - 1
     packed_ok = gather_on and S._can_pack()       # the real tracer; stand-ins take the per-output exchange
     pending = []
@@ -426,6 +429,8 @@ def run_rank(args):
         gather_txt = ""
         if gather_on:
             gather_txt = ", results gathered to rank 0 inside the timed region"
+            if args.force_gather and world == 1:
+                gather_txt += " [--force-gather: the exchange is a self-gather in a one-rank communicator]"
             if packed_ok:
                 gather_txt += " (12 B/ray packed records over RCCL, expanded on rank 0, exchange of step k overlaps trace of step k+1)"
         metric = "Mrays/s closest-hit, 1M-tri mesh, 1024^2 ray batch"

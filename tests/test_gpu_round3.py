@@ -266,3 +266,28 @@ def test_lds_staged_node_packets_match_the_oracle(device, lds_top):
                 assert np.array_equal(g.cpu().numpy().reshape(e.shape), e)
     finally:
         hops.set_option("lds_top", 0)
+
+
+@pytest.mark.timeout(900)
+def test_bench_result_pipeline_on_rccl_one_rank():
+    """bench.py's N > 1 step -- packed trace in chunks, asynchronous RCCL exchange, expansion on a side stream,
+    double buffering, `verified` against the cold first call -- under torch.distributed.run with ONE rank
+    (`--force-gather`): the multi-GPU code path on the real backend, as far as a single-GPU box can take it."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for extra in (["--workload", "c5i"], ["--workload", "c5i", "--scaling", "strong"],
+                  ["--workload", "c5ii", "--total-rays", "7000001", "--chunks", "3"]):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+               "--master-port", str(29700 + os.getpid() % 200), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "6",
+               "--warmup", "2", "--min-warmup-ms", "0", "--no-cpu-baseline", "--no-companions", "--force-gather"] + extra
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        assert p.returncode == 0, (p.stdout[-800:], p.stderr[-2500:])
+        line = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')][-1]
+        r = json.loads(line)
+        assert r["verified"] is True and r["n_gpus"] == 1 and r["value"] > 100
+        assert "12 B/ray packed" in r["config"]["parallelism"] and "--force-gather" in r["config"]["parallelism"]
