@@ -228,7 +228,8 @@ int tr_trace_stats_query(const tr_bvh *bvh, const tr_rays *rays, int query, tr_t
  *    image-shaped batches [..., H, W, 3] with W % 8 == 0 are traced in 8x8 pixel tiles per wave),
  *    "scramble" (0/1: launches without a measured order visit each
  *    XCD's blocks in a scrambled order), "build_cache" (0/1: keep the builder's temporaries, about 130 B/triangle per
- *    device, between builds so a rebuild costs no allocation; default 1),
+ *    device, between builds so a rebuild costs no allocation; default 1), "node_layout" (0/1, read at BUILD time: the
+ *    traversal nodes are stored in Karras numbering / in treelets of three levels, depth first; default 1),
  *    "unordered" (0/1/2: count and location -- with 2 also any -- queue box-hit leaves and test
  *    them in separate wave-level leaf phases instead of on every trip; default 1), "leaf_vote"
  *    (1..64 lanes with a queued leaf that trigger such a phase), "tile_small" (0..4: pixel

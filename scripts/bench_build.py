@@ -9,7 +9,10 @@ import workloads as W
 from triro.ray.ray_optix import RayMeshIntersector
 from triro.backend import ops as hops
 
-ap = argparse.ArgumentParser(); ap.add_argument("--reps", type=int, default=10); a = ap.parse_args()
+ap = argparse.ArgumentParser(); ap.add_argument("--reps", type=int, default=10)
+ap.add_argument("--opt", action="append", default=[], help="library option name=value (e.g. node_layout=0)"); a = ap.parse_args()
+for kv in a.opt:
+    k, val = kv.split("=", 1); hops.set_option(k, int(val))
 dev = torch.device("cuda:0")
 def wall(fn, reps):
     ts = []
@@ -27,7 +30,7 @@ for name, (v, f) in (("bunny stand-in", W.bunny_standin()), ("headline", W.headl
     reb0 = wall(lambda: r.update_raw(v, f), a.reps)
     hops.set_option("build_cache", 1)
     ref = wall(lambda: r.refit(v), a.reps)
-    print(json.dumps({"mesh": name, "tris": int(f.shape[0]), "first_build_ms": round(first, 3),
+    print(json.dumps({"mesh": name, "opts": a.opt, "tris": int(f.shape[0]), "first_build_ms": round(first, 3),
                       "rebuild_ms_median_min": [round(x, 3) for x in reb],
                       "rebuild_nocache_ms_median_min": [round(x, 3) for x in reb0],
                       "refit_ms_median_min": [round(x, 3) for x in ref],

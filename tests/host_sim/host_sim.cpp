@@ -22,12 +22,27 @@ struct SimBvh {
     int key_mode = 0;
 };
 
+static int g_node_layout = 1;      // as the product's option node_layout: 1 = treelet order
+
 template <int MODE>
 static int build_hierarchy(SimBvh& b, const std::vector<uint64_t>& keys, const std::vector<float>& sbox) {
     const int64_t n = (int64_t)keys.size(), ni = n - 1;
-    std::vector<int32_t> cl(ni), cr(ni), par(ni, -1);
+    std::vector<int32_t> cl(ni), cr(ni), par(ni, -1), span(ni, 0);
     for (int64_t i = 0; i < ni; i++) {
-        tr_karras_node<MODE>(keys.data(), n, i, &cl[i], &cr[i]);
+        tr_karras_node<MODE>(keys.data(), n, i, &cl[i], &cr[i], &span[i]);
+    }
+    // node layout (tr_lbvh.h): treelet order, level by level from the root, as the GPU builder does it
+    std::vector<int32_t> pos(ni), bases(ni, 0), flag(ni, 0);
+    for (int64_t i = 0; i < ni; i++) pos[i] = (int32_t)i;
+    if (g_node_layout) {
+        std::fill(pos.begin(), pos.end(), -1);
+        flag[0] = 1;
+        for (int32_t round = 1; round <= 80; round++) {
+            bool any = false;
+            for (int64_t i = 0; i < ni; i++)
+                if (flag[i] == round) { tr_treelet_assign(cl.data(), cr.data(), span.data(), (int32_t)i, bases[i], round + 1, pos.data(), bases.data(), flag.data()); any = true; }
+            if (!any) break;
+        }
     }
     for (int64_t i = 0; i < ni; i++) {
         if (cl[i] >= 0) par[cl[i]] = (int32_t)i;
@@ -57,23 +72,25 @@ static int build_hierarchy(SimBvh& b, const std::vector<uint64_t>& keys, const s
     b.nodes.resize(ni);
     b.links.resize(ni);
     b.qnodes.resize(ni);
+    auto at = [&](int32_t c) { return c >= 0 ? pos[c] : c; };      // ids in layout order
     for (int64_t i = 0; i < ni; i++) {
         const float* a = cl[i] < 0 ? &sbox[6 * (int64_t)(~cl[i])] : &ibox[6 * (int64_t)cl[i]];
         const float* c = cr[i] < 0 ? &sbox[6 * (int64_t)(~cr[i])] : &ibox[6 * (int64_t)cr[i]];
         tr_node nd;
         tr_node_set_box(nd.box0, a, a + 3);
         tr_node_set_box(nd.box1, c, c + 3);
-        nd.c0 = cl[i]; nd.c1 = cr[i];
+        nd.c0 = at(cl[i]); nd.c1 = at(cr[i]);
         int32_t p = par[i], sib = 0;
-        if (p >= 0) sib = (cl[p] == (int32_t)i) ? cr[p] : cl[p];
-        nd.parent = p; nd.sibling = sib;
-        b.nodes[i] = nd;
-        b.links[i].parent = p; b.links[i].sibling = sib;
+        if (p >= 0) sib = at((cl[p] == (int32_t)i) ? cr[p] : cl[p]);
+        nd.parent = p >= 0 ? pos[p] : -1; nd.sibling = sib;
+        const int64_t w = pos[i];
+        b.nodes[w] = nd;
+        b.links[w].parent = nd.parent; b.links[w].sibling = sib;
         tr_qnode qn;
         tr_qnode_set_box(qn.q, a, a + 3, b.frame);
         tr_qnode_set_box(qn.q + 3, c, c + 3, b.frame);
-        qn.c0 = cl[i]; qn.c1 = cr[i];
-        b.qnodes[i] = qn;
+        qn.c0 = nd.c0; qn.c1 = nd.c1;
+        b.qnodes[w] = qn;
     }
     return round;
 }

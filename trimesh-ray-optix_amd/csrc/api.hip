@@ -33,6 +33,7 @@ const opt_desc OPTS[] = {
     {"tile_small", &tr_options::tile_small, 0, 4, false},
     {"scramble", &tr_options::scramble, 0, 1, true},
     {"build_cache", &tr_options::build_cache, 0, 1, true},
+    {"node_layout", &tr_options::node_layout, 0, 1, true},
     {"unordered", &tr_options::unordered, 0, 2, false},
     {"stream", &tr_options::stream, 0, 2, false},
     {"stream_rays", &tr_options::stream_rays, 64, 1 << 20, false},
@@ -87,6 +88,9 @@ int tr_get_device_state(int device, tr_device_state** out) {
         st.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         TR_HIP_TRY(hipMalloc((void**)&st.counters, sizeof(unsigned long long) * TR_NUM_COUNTERS));
         TR_HIP_TRY(hipMemset(st.counters, 0, sizeof(unsigned long long) * TR_NUM_COUNTERS));
+        TR_HIP_TRY(hipStreamCreateWithFlags(&st.build_side, hipStreamNonBlocking));
+        TR_HIP_TRY(hipEventCreateWithFlags(&st.build_fork, hipEventDisableTiming));
+        TR_HIP_TRY(hipEventCreateWithFlags(&st.build_join, hipEventDisableTiming));
         st.ready = true;
     }
     *out = &st;

@@ -274,16 +274,31 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_karras(const uint64_t* __restrict__ keys, int64_t n,
                                                 int32_t* __restrict__ childL,
                                                 int32_t* __restrict__ childR,
-                                                int32_t* __restrict__ parent) {
+                                                int32_t* __restrict__ parent,
+                                                int32_t* __restrict__ span) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;
-    int32_t cl, cr;
-    tr_karras_node<MODE>(keys, n, i, &cl, &cr);
+    int32_t cl, cr, sp;
+    tr_karras_node<MODE>(keys, n, i, &cl, &cr, &sp);
     childL[i] = cl;
     childR[i] = cr;
+    span[i] = sp;
     if (cl >= 0) parent[cl] = (int32_t)i;
     if (cr >= 0) parent[cr] = (int32_t)i;
     if (i == 0) parent[0] = -1;
+}
+
+// ---- 5b. node layout: positions of the nodes in treelet order, one launch per treelet level (top-down)
+__global__ void k_layout_init(int32_t* __restrict__ bases, int32_t* __restrict__ flag) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { bases[0] = 0; flag[0] = 1; }
+}
+__global__ __launch_bounds__(256) void k_layout_round(const int32_t* __restrict__ childL, const int32_t* __restrict__ childR,
+                                                      const int32_t* __restrict__ span, int32_t* __restrict__ pos,
+                                                      int32_t* __restrict__ bases, int32_t* __restrict__ flag,
+                                                      int64_t ninternal, int32_t round) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ninternal || flag[i] != round) return;
+    tr_treelet_assign(childL, childR, span, (int32_t)i, bases[i], round + 1, pos, bases, flag);
 }
 
 // ---- 6. refit, one launch per level ----------------------------------------------------------
@@ -335,6 +350,7 @@ __global__ __launch_bounds__(256) void k_emit(const int32_t* __restrict__ childL
                                               const float* __restrict__ sbox,
                                               const float* __restrict__ ibox, int64_t ninternal,
                                               const tr_qframe* __restrict__ frame,
+                                              const int32_t* __restrict__ pos,
                                               tr_node* __restrict__ nodes,
                                               tr_link* __restrict__ links,
                                               tr_qnode* __restrict__ qnodes) {
@@ -346,10 +362,20 @@ __global__ __launch_bounds__(256) void k_emit(const int32_t* __restrict__ childL
     tr_node nd;
     tr_node_set_box(nd.box0, a, a + 3);
     tr_node_set_box(nd.box1, b, b + 3);
-    nd.c0 = cl; nd.c1 = cr;
     int32_t p = parent[i];
     int32_t sib = 0;
     if (p >= 0) sib = (childL[p] == (int32_t)i) ? childR[p] : childL[p];
+    // the arrays are written in layout order (tr_lbvh.h, treelets): node i lives at pos[i], ids follow
+    // (a node the layout has not reached yet -- a speculative emit of a tree that is higher than guessed
+    // -- is skipped: the emit is repeated once the tree is complete)
+    if (pos && pos[i] < 0) return;
+    if (pos) {
+        if (cl >= 0) cl = pos[cl];
+        if (cr >= 0) cr = pos[cr];
+        if (p >= 0) { if (sib >= 0) sib = pos[sib]; p = pos[p]; }
+        i = pos[i];
+    }
+    nd.c0 = cl; nd.c1 = cr;
     nd.parent = p; nd.sibling = sib;
     nodes[i] = nd;
     tr_link l; l.parent = p; l.sibling = sib;
@@ -545,7 +571,8 @@ int tr_build_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_
     Carver tc{nullptr};
     auto plan = [&](Carver& c, float*& tribox, float*& sbox, float*& ibox, uint64_t*& k0,
                     uint64_t*& k1, uint32_t*& v0, uint32_t*& v1, uint32_t*& hist,
-                    uint32_t*& gtot, uint32_t*& bounds, int32_t*& cl, int32_t*& cr, int32_t*& par, int32_t*& ready) {
+                    uint32_t*& gtot, uint32_t*& bounds, int32_t*& cl, int32_t*& cr, int32_t*& par, int32_t*& ready,
+                    int32_t*& lay) {
         tribox = c.take<float>(6 * (size_t)nf);
         sbox = c.take<float>(6 * (size_t)nf);
         ibox = c.take<float>(6 * (size_t)nf);
@@ -560,16 +587,19 @@ int tr_build_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_
         cr = c.take<int32_t>((size_t)nf);
         par = c.take<int32_t>((size_t)nf);
         ready = c.take<int32_t>((size_t)nf);
+        lay = c.take<int32_t>(4 * (size_t)nf);      // node layout: span | pos | bases | flag
     };
     float *tribox, *sbox, *ibox; uint64_t *k0, *k1; uint32_t *v0, *v1, *hist, *gtot, *bounds;
-    int32_t *cl, *cr, *par, *ready;
-    plan(tc, tribox, sbox, ibox, k0, k1, v0, v1, hist, gtot, bounds, cl, cr, par, ready);
+    int32_t *cl, *cr, *par, *ready, *lay;
+    plan(tc, tribox, sbox, ibox, k0, k1, v0, v1, hist, gtot, bounds, cl, cr, par, ready, lay);
     tr_device_state* st;
     TR_TRY(tr_get_device_state(bvh->device, &st));
     void* temp = nullptr;
     TR_TRY(tr_build_temp_acquire(st, align_up(tc.off, 256), &temp));   // holds st->build_mutex
     Carver tc2{(char*)temp};
-    plan(tc2, tribox, sbox, ibox, k0, k1, v0, v1, hist, gtot, bounds, cl, cr, par, ready);
+    plan(tc2, tribox, sbox, ibox, k0, k1, v0, v1, hist, gtot, bounds, cl, cr, par, ready, lay);
+    int32_t* span = lay; int32_t* lpos = lay + nf; int32_t* lbase = lay + 2 * nf; int32_t* lflag = lay + 3 * nf;
+    const bool treelets = tr_opts().node_layout != 0;
 
     int status = TR_OK;
     auto check = [&](hipError_t e, const char* what) {
@@ -625,11 +655,31 @@ int tr_build_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_
         bvh->depth = 0;
         for (int mode = 0; mode < 2 && status == TR_OK; mode++) {
             if (mode == 0)
-                hipLaunchKernelGGL(k_karras<0>, dim3(gI), dim3(TB), 0, stream, kin, nf, cl, cr, par);
+                hipLaunchKernelGGL(k_karras<0>, dim3(gI), dim3(TB), 0, stream, kin, nf, cl, cr, par, span);
             else
-                hipLaunchKernelGGL(k_karras<1>, dim3(gI), dim3(TB), 0, stream, kin, nf, cl, cr, par);
+                hipLaunchKernelGGL(k_karras<1>, dim3(gI), dim3(TB), 0, stream, kin, nf, cl, cr, par, span);
             check(hipGetLastError(), "k_karras");
             check(hipMemsetAsync(ready, 0, sizeof(int32_t) * (size_t)ni, stream), "memset ready");
+            // Node layout (top-down, one launch per treelet level) on the builder's side stream, beside
+            // the refit rounds (bottom-up) on the caller's: both need only the Karras hierarchy; the first
+            // emit waits for both.  As many levels as the guessed height needs; a higher tree gets the
+            // rest on the caller's stream further down.
+            int32_t lround = 0;              // treelet levels laid out so far
+            bool lay_joined = true;
+            if (treelets) {
+                check(hipEventRecord(st->build_fork, stream), "record fork");
+                check(hipStreamWaitEvent(st->build_side, st->build_fork, 0), "side waits");
+                check(hipMemsetAsync(lflag, 0, sizeof(int32_t) * (size_t)ni, st->build_side), "memset layout flags");
+                check(hipMemsetAsync(lpos, 0xff, sizeof(int32_t) * (size_t)ni, st->build_side), "memset layout positions");
+                hipLaunchKernelGGL(k_layout_init, dim3(1), dim3(64), 0, st->build_side, lbase, lflag);
+                while (lround * TR_TREELET_LEVELS < guess + TR_TREELET_LEVELS) {
+                    ++lround;
+                    hipLaunchKernelGGL(k_layout_round, dim3(gI), dim3(TB), 0, st->build_side, cl, cr, span, lpos, lbase, lflag, ni, lround);
+                }
+                check(hipGetLastError(), "k_layout_round");
+                check(hipEventRecord(st->build_join, st->build_side), "record join");
+                lay_joined = false;
+            }
             int32_t root_ready = 0;
             int32_t round = 0;
             const int32_t max_rounds = 160;   // > 64 + 32 + slack
@@ -640,8 +690,16 @@ int tr_build_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_
                     hipLaunchKernelGGL(k_refit_round, dim3(gI), dim3(TB), 0, stream, cl, cr, sbox, ibox, ready, ni, round);
                 }
                 check(hipGetLastError(), "k_refit_round");
+                // the layout needs one round per TR_TREELET_LEVELS levels; the tree is at most `round` high
+                // if its root has been reached (if not, both loops continue below)
+                if (!lay_joined) { check(hipStreamWaitEvent(stream, st->build_join, 0), "join layout"); lay_joined = true; }
+                while (treelets && lround * TR_TREELET_LEVELS < round + TR_TREELET_LEVELS) {
+                    ++lround;
+                    hipLaunchKernelGGL(k_layout_round, dim3(gI), dim3(TB), 0, stream, cl, cr, span, lpos, lbase, lflag, ni, lround);
+                }
                 // harmless if the root is not final yet: it is launched again below
-                hipLaunchKernelGGL(k_emit, dim3(gI), dim3(TB), 0, stream, cl, cr, par, sbox, ibox, ni, d_frame, bvh->nodes, bvh->links, bvh->qnodes);
+                hipLaunchKernelGGL(k_emit, dim3(gI), dim3(TB), 0, stream, cl, cr, par, sbox, ibox, ni, d_frame,
+                                   treelets ? lpos : nullptr, bvh->nodes, bvh->links, bvh->qnodes);
                 check(hipGetLastError(), "k_emit");
                 check(hipMemcpyAsync(&root_ready, ready, sizeof(int32_t), hipMemcpyDeviceToHost, stream), "memcpy root");
                 check(hipStreamSynchronize(stream), "sync refit");
@@ -657,8 +715,10 @@ int tr_build_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_
             if (mode == 1) { status = tr_fail(TR_ERR_INTERNAL, "tree height > 64 with bounded keys"); break; }
         }
     }
-    // drain the stream before the temporaries are handed back
+    // drain the streams before the temporaries are handed back (the side stream too: an error path may
+    // have left its layout rounds unjoined)
     check(hipStreamSynchronize(stream), "sync build");
+    if (treelets) check(hipStreamSynchronize(st->build_side), "sync build side stream");
     if (status == TR_OK && hb[6] != 0xffffffffu)
         status = tr_fail(TR_ERR_INVALID_ARG, "face " + std::to_string(hb[6]) + " has a vertex index outside [0, " +
                                                  std::to_string(nv) + ")");

@@ -94,6 +94,10 @@ struct tr_device_state {
     void* build_temp = nullptr;
     size_t build_temp_bytes = 0;
     std::mutex build_mutex;
+    // side stream of the builder (under build_mutex): the node-layout rounds (top-down) run beside the
+    // refit rounds (bottom-up) -- both depend only on the Karras hierarchy, the emit joins them
+    hipStream_t build_side = nullptr;
+    hipEvent_t build_fork = nullptr, build_join = nullptr;
 };
 constexpr int TR_NUM_COUNTERS = 4096;
 
@@ -151,6 +155,7 @@ struct tr_options {
     int tile = 1;         // image-shaped batches: waves take 8x8 pixel tiles (0 never, 1 from 4 M rays on, 2 always)
     int tile_small = 4;   // image-shaped batches below the `tile` threshold: 0 rows of 64 pixels, 1 = 2x32, 2 = 4x16, 3 = 8x8 tiles, 4 = by triangles per ray
     int scramble = 1;     // launches without a measured order visit each XCD's blocks in a scrambled order
+    int node_layout = 1;  // order of the traversal nodes in memory (build time): 0 Karras numbering, 1 treelets of 3 levels, depth first
     int build_cache = 1;  // keep the builder's temporaries (about 130 B/triangle) per device between builds
     int stream = 1;       // streaming launch with wave-level ray refill: 0 never, 1 large non-image batches, 2 always
     int stream_rays = 256;    // rays per range of the streaming launch (512 was the optimum of the static map)

@@ -48,9 +48,10 @@ TR_HD int tr_delta(const uint64_t* keys, int64_t n, int64_t i, uint64_t ki, int6
 
 // Karras 2012, one internal node: children of node i over n sorted keys.
 // child encoding: >= 0 internal node index, < 0 leaf with slot ~c.
+// *span (optional) = internal nodes of the subtree of node i, itself included (= its leaves - 1).
 template <int MODE>
 TR_HD void tr_karras_node(const uint64_t* keys, int64_t n, int64_t i, int32_t* child_l,
-                          int32_t* child_r) {
+                          int32_t* child_r, int32_t* span = nullptr) {
     const uint64_t ki = tr_key<MODE>(keys, i);
     const int dp = tr_delta<MODE>(keys, n, i, ki, i + 1), dm = tr_delta<MODE>(keys, n, i, ki, i - 1);
     const int64_t d = dp > dm ? 1 : -1;
@@ -71,4 +72,43 @@ TR_HD void tr_karras_node(const uint64_t* keys, int64_t n, int64_t i, int32_t* c
     const int64_t lo = i < j ? i : j, hi = i < j ? j : i;
     *child_l = (lo == gamma) ? ~(int32_t)gamma : (int32_t)gamma;
     *child_r = (hi == gamma + 1) ? ~(int32_t)(gamma + 1) : (int32_t)(gamma + 1);
+    if (span) *span = (int32_t)(hi - lo);
+}
+
+// ---- node layout in memory: treelets -------------------------------------------------------------
+// Karras numbers a node by one end of its key range: siblings are adjacent, but a parent is up to half
+// its subtree away from its children.  The traversal arrays are therefore emitted in TREELET order:
+// the hierarchy is cut into treelets of TR_TREELET_LEVELS levels (root, children, grandchildren: up to
+// 7 nodes = 224 B of grid nodes, two 128-byte lines), a treelet's nodes are stored in level order, and
+// the subtrees below it follow one after the other, depth first.  A descent touches a new line every
+// ~3 levels instead of every level (measured on the host-permuted arena, scripts/exp_node_layout.py,
+// profiles/r03_node_layout.jsonl: headline -4 %, incoherent shards -4 %; a random order costs +6...11 %).
+// Positions are a pure function of the topology: the GPU builder and tests/host_sim derive the same
+// permutation, replicas on other GPUs stay bit-identical, and every consumer of the arrays only follows
+// child / parent ids (node 0 stays the root).
+//
+// One treelet: root r at position `base`.  Writes pos[] of its members and, for the roots of the
+// treelets below it (the internal children of its last level), their bases and the round in which
+// they are due.  span[c] = internal nodes of the subtree of c (tr_karras_node).
+#define TR_TREELET_LEVELS 3
+TR_HD void tr_treelet_assign(const int32_t* cl, const int32_t* cr, const int32_t* span, int32_t r, int32_t base,
+                             int32_t next_round, int32_t* pos, int32_t* bases, int32_t* flag) {
+    int32_t m[(1 << TR_TREELET_LEVELS) - 1];
+    int nm = 0, lo = 0, hi = 1;
+    m[nm++] = r;
+    for (int lv = 1; lv < TR_TREELET_LEVELS; lv++) {
+        for (int k = lo; k < hi; k++) {
+            const int32_t a = cl[m[k]], b = cr[m[k]];
+            if (a >= 0) m[nm++] = a;
+            if (b >= 0) m[nm++] = b;
+        }
+        lo = hi; hi = nm;
+    }
+    for (int k = 0; k < nm; k++) pos[m[k]] = base + k;
+    int32_t next = base + nm;
+    for (int k = lo; k < hi; k++) {          // the last level's internal children: roots of the next treelets
+        const int32_t ch[2] = {cl[m[k]], cr[m[k]]};
+        for (int e = 0; e < 2; e++)
+            if (ch[e] >= 0) { bases[ch[e]] = next; flag[ch[e]] = next_round; next += span[ch[e]]; }
+    }
 }
