@@ -129,12 +129,19 @@ TR_HD void tr_qnode_set_box(uint32_t* q, const float* lo, const float* hi, const
     q[0] = lx | (ly << 16); q[1] = lz | (hz << 16); q[2] = hx | (hy << 16);
 }
 
+// TR_TRI_BYTES: 48 (packed: half of the records straddle a 64-byte line) or 64 (one line per record)
+#ifndef TR_TRI_BYTES
+#define TR_TRI_BYTES 48
+#endif
 struct alignas(16) tr_tri {
     float ax, ay, az, bx, by, bz, cx, cy, cz;
     int32_t face;  // original triangle index
     int32_t pad0, pad1;
+#if TR_TRI_BYTES == 64
+    int32_t pad2[4];
+#endif
 };
-static_assert(sizeof(tr_tri) == 48, "tri record must be 48 B");
+static_assert(sizeof(tr_tri) == TR_TRI_BYTES, "tri record must be 48 (or, experiment, 64) B");
 
 struct tr_bvh_view {
     const tr_node* nodes;
@@ -242,7 +249,7 @@ TR_HD const tr_i4* tr_qnode_ptr(const tr_bvh_view& b, int32_t node) {
 template <bool COMPACT>
 TR_HD const tr_f4* tr_tri_ptr(const tr_bvh_view& b, int32_t slot) {
     if (COMPACT)
-        return reinterpret_cast<const tr_f4*>(reinterpret_cast<const char*>(b.tris) + (uint32_t)slot * 48u);
+        return reinterpret_cast<const tr_f4*>(reinterpret_cast<const char*>(b.tris) + (uint32_t)slot * (uint32_t)sizeof(tr_tri));
     return reinterpret_cast<const tr_f4*>(b.tris + slot);
 }
 
