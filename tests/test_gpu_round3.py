@@ -291,3 +291,39 @@ def test_bench_result_pipeline_on_rccl_one_rank():
         r = json.loads(line)
         assert r["verified"] is True and r["n_gpus"] == 1 and r["value"] > 100
         assert "12 B/ray packed" in r["config"]["parallelism"] and "--force-gather" in r["config"]["parallelism"]
+
+
+def test_packed_closest_edge_cases(device):
+    """12-byte packed records on the inputs the dense path is tested with: a single-triangle mesh (no
+    hierarchy), zero rays, NaN / Inf rays (miss), broadcast and strided ray tensors, three batch dims."""
+    from triro.ray.ray_optix import RayMeshIntersector
+    v1 = np.array([[0.5, -0.5, 0], [0, 0.5, 0], [-0.5, -0.5, 0]], np.float32)
+    f1 = np.array([[0, 1, 2]], np.int32)
+    r1 = RayMeshIntersector(vertices=T(v1, device), faces=T(f1, device))
+    o = torch.tensor([[0, 0, 4.0], [10, 10, 10], [float("nan"), 0, 1], [0, 0, -4.0]], device=device)
+    d = torch.tensor([[0, 0, -1.0], [0, 1, 0], [0, 0, -1], [0, 0, float("inf")]], device=device)
+    dense = r1.intersects_closest(o, d)
+    got = r1.closest_expand(r1.intersects_closest_packed(o, d))
+    for a, e in zip(got, dense):
+        assert torch.equal(a, e)
+    assert dense[0].tolist() == [True, False, False, False] and got[2].tolist() == [0, -1, -1, -1]
+    empty = r1.intersects_closest_packed(torch.zeros(0, 3, device=device), torch.zeros(0, 3, device=device))
+    assert empty.shape == (0, 3)
+    assert [tuple(x.shape) for x in r1.closest_expand(empty)] == [(0,), (0,), (0,), (0, 3), (0, 2)]
+    v, f = W.icosphere(4)
+    r = make(v, f, device)
+    # stride-0 origin, three batch dims, non-contiguous directions
+    dn = W.pinhole_grid(40, 24)[1].reshape(2, 12, 40, 3)
+    big = torch.zeros(2, 12, 40, 6, device=device)
+    big[..., ::2] = T(dn, device)
+    dirs = big[..., ::2]
+    assert not dirs.is_contiguous()
+    org = torch.tensor([0.0, 0.0, 2.5], device=device).expand(2, 12, 40, 3)
+    dense = r.intersects_closest(org, dirs)
+    got = r.closest_expand(r.intersects_closest_packed(org, dirs), batch_shape=(2, 12, 40))
+    for a, e in zip(got, dense):
+        assert a.shape == e.shape and torch.equal(a, e)
+    with pytest.raises(ValueError):
+        r.closest_expand(torch.zeros(5, 3, device=device))                      # not int32
+    with pytest.raises(ValueError):
+        r.intersects_closest_packed(org, dirs, out=torch.zeros(7, 3, dtype=torch.int32, device=device))
