@@ -67,6 +67,17 @@ class PendingClosest:
         self._keep = ()
         return self._outputs
 
+    def __del__(self):
+        # The buffers were allocated on the caller's stream and are written on the side stream: they
+        # must not return to the allocator before that work is done.  wait() orders the caller's stream
+        # behind it; a handle that is dropped without wait() blocks here instead (rare, and correct).
+        ev = getattr(self, "_event", None)
+        if ev is not None:
+            try:
+                ev.synchronize()
+            except Exception:
+                pass
+
 
 class ShardedRayMeshIntersector:
     def __init__(self, local, group: Optional[dist.ProcessGroup] = None, gather_mode: Optional[str] = None,
@@ -244,14 +255,19 @@ class ShardedRayMeshIntersector:
         # the destination traces straight into its slice of the full packed buffer
         packed_all = self._alloc((n_total, 3), torch.int32, dev) if want else None
         mine = packed_all[lo:hi] if want else (self._alloc((m, 3), torch.int32, dev) if m > 0 else None)
-        outs = None
+        outs = flat_outs = None
         if want:
-            outs = (self._alloc(b, torch.bool, dev), self._alloc(b, torch.bool, dev), self._alloc(b, torch.int32, dev),
-                    self._alloc((*b, 3), torch.float32, dev), self._alloc((*b, 2), torch.float32, dev))
-        flat_outs = None
-        if want:
-            flat_outs = (outs[0].view(n_total), outs[1].view(n_total), outs[2].view(n_total),
-                         outs[3].view(n_total, 3), outs[4].view(n_total, 2))
+            # the five dense outputs out of ONE allocation (26 B per ray: loc | uv | tri | hit | front, each
+            # part aligned to 16 B): an allocator call costs as much as a small kernel launch
+            n16 = (n_total + 15) // 16 * 16
+            pool = self._alloc((26 * n16,), torch.uint8, dev)
+            loc = pool[:12 * n16].view(torch.float32)[:3 * n_total].view(n_total, 3)
+            uv = pool[12 * n16:20 * n16].view(torch.float32)[:2 * n_total].view(n_total, 2)
+            tri = pool[20 * n16:24 * n16].view(torch.int32)[:n_total]
+            hit = pool[24 * n16:25 * n16].view(torch.bool)[:n_total]
+            front = pool[25 * n16:26 * n16].view(torch.bool)[:n_total]
+            flat_outs = (hit, front, tri, loc, uv)
+            outs = (hit.view(b), front.view(b), tri.view(b), loc.view(*b, 3), uv.view(*b, 2))
         cuda = dev.type == "cuda"
         side = None
         if cuda and want:
@@ -259,8 +275,6 @@ class ShardedRayMeshIntersector:
                 self._side = torch.cuda.Stream(device=dev)
             side = self._side
             side.wait_stream(torch.cuda.current_stream(dev))     # the allocations above are ready
-            for t in (packed_all, *outs):
-                t.record_stream(side)       # allocated on the caller's stream, used on the side stream
         works_all = []
         for k in range(K):
             # chunk k of every rank (every rank can compute everybody's bounds)
@@ -287,10 +301,11 @@ class ShardedRayMeshIntersector:
                 works = []
             if want:
                 def expand_chunk():
-                    for r in range(world):
-                        ra, rz = cb[r]
-                        if rz > ra:
-                            self.local.closest_expand(packed_all[ra:rz], outs=tuple(x[ra:rz] for x in flat_outs))
+                    spans = [(ra, rz) for ra, rz in cb if rz > ra]
+                    if spans and all(spans[j][1] == spans[j + 1][0] for j in range(len(spans) - 1)):
+                        spans = [(spans[0][0], spans[-1][1])]          # one chunk per rank: one contiguous range
+                    for ra, rz in spans:
+                        self.local.closest_expand(packed_all[ra:rz], outs=tuple(x[ra:rz] for x in flat_outs))
                 if side is not None:
                     with torch.cuda.stream(side):
                         for w in works:
