@@ -196,6 +196,13 @@ def _worker(rank, world, port, q):
             for a, e in zip(g3, e3):
                 ok &= torch.equal(a, e)
         ok &= torch.equal(P.intersects_count(o3, d3, dst=None), ref.intersects_count(o3, d3))
+        # fewer rays than chunks: every rank must still cut its shard into the same number of chunks
+        for n_small in (5, 2, 1):
+            g_s = P.intersects_closest(fo[:n_small], fd[:n_small], dst=0, chunks=4)
+            e_s = ref.intersects_closest(fo[:n_small], fd[:n_small])
+            if rank == 0:
+                for a, e in zip(g_s, e_s):
+                    ok &= torch.equal(a, e)
         # a rank that holds ONLY its shard (bench.py c5ii): closest_of_shard_async
         h = P.closest_of_shard_async(fo[lo_:hi_], fd[lo_:hi_], 851, dst=0, chunks=2)
         g4 = h.wait()

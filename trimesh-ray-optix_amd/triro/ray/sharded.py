@@ -249,9 +249,15 @@ class ShardedRayMeshIntersector:
         b = tuple(batch_shape) if batch_shape is not None else (n_total,)
         K = chunks if chunks else default_chunks(max(1, n_total // world))
         image = o.dim() == 3           # image-shaped shard: chunk by whole rows
-        rows = o.shape[0] if image else m
         per_row = o.shape[1] if image else 1
-        K = max(1, min(K, rows)) if rows > 0 else 1
+        sizes = [shard_bounds(n_total, world, r) for r in range(world)]
+        if image and any((z - a) % per_row for a, z in sizes):
+            # (cannot happen through intersects_closest; a caller that hands in an image-shaped shard of a
+            # batch whose other shards are not whole rows gets the flat path)
+            o, d, image, per_row = o.reshape(-1, 3), d.expand(*o.shape).reshape(-1, 3), False, 1
+        # every rank must cut its shard into the SAME number of chunks (one exchange per chunk): bound K by
+        # the smallest shard, which every rank can compute
+        K = max(1, min(K, min((z - a) // per_row for a, z in sizes)))
         # the destination traces straight into its slice of the full packed buffer
         packed_all = self._alloc((n_total, 3), torch.int32, dev) if want else None
         mine = packed_all[lo:hi] if want else (self._alloc((m, 3), torch.int32, dev) if m > 0 else None)
