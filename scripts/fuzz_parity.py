@@ -19,7 +19,7 @@ T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
 DEFAULTS = {"steal": 1, "tile": 1, "block_size": 128, "adaptive": 1, "xcd_chunk": 128, "compact": 1, "scramble": 1,
             "persistent": 0, "blocks_per_cu": 8,
             "tile_small": 4, "unordered": 1, "leaf_vote": 32, "stream": 1, "stream_rays": 256, "stream_refill": 32, "stream_dynamic": 1,
-            "split": 1, "split_steal": 8, "grid_nodes": 1, "split_outlier": 1, "split_floor": 40, "usteal": 1, "lds_top": 0}
+            "split": 1, "split_steal": 8, "grid_nodes": 1, "split_outlier": 1, "split_floor": 40, "usteal": 1, "lds_top": 0, "occ8": 1}
 bad = 0
 for it in range(a.iters):
     kind = rng.integers(0, 5)
@@ -67,7 +67,7 @@ for it in range(a.iters):
             "grid_nodes": int(rng.choice([0, 1, 2, 2])),
             # round 3: device-side split criterion, stealing in the unordered count launch, LDS-staged node packets
             "split_outlier": int(rng.choice([0, 1, 1, 4, 8, 30])), "split_floor": int(rng.choice([0, 0, 0, 40])),
-            "usteal": int(rng.choice([0, 1, 1, 2, 8, 64])), "lds_top": int(rng.choice([0, 0, 1, 2]))}
+            "usteal": int(rng.choice([0, 1, 1, 2, 8, 64])), "lds_top": int(rng.choice([0, 0, 1, 2])), "occ8": int(rng.choice([0, 1, 2, 2]))}
     for k, val in opts.items(): hops.set_option(k, val)
     try:
         r = RayMeshIntersector(vertices=T(v), faces=T(f)); R = OracleIntersector(v, f, 1)

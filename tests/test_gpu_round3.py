@@ -14,6 +14,7 @@ from oracle.oracle import OracleIntersector
 
 pytestmark = pytest.mark.gpu
 LAUNCHES = 14
+OCC8_DEFAULT = 1       # the library's default of option occ8 (tests that flip it restore this)
 
 
 def T(x, dev):
@@ -215,7 +216,7 @@ def test_unordered_count_with_stealing_matches_the_oracle(device, usteal, split)
             hops.set_option(k, val)
 
 
-@pytest.mark.parametrize("lds_top", [1, 2])
+@pytest.mark.parametrize("lds_top", [1, 2, -8])
 def test_lds_staged_node_packets_match_the_oracle(device, lds_top):
     """north_star "LDS-staged node packets" (option lds_top): closest / first launches that steal read the
     grid nodes of the top 7 levels from a table staged in LDS while a wave descends them in lockstep.
@@ -228,8 +229,17 @@ def test_lds_staged_node_packets_match_the_oracle(device, lds_top):
     v = W.displaced(v, seed=4, amplitude=0.07)
     r = make(v, f, device)
     o_img, d_img = W.pinhole_grid(384, 256, distance=2.5)
+    # (lds_top = -8 stands for the OTHER variant of the stealing grid-node kernel this test covers: option
+    # occ8, 8 waves per SIMD with the slim ds_permute hand-over -- same batches, same launch sequence)
+    occ8 = lds_top < 0
+    lds_top = max(lds_top, 0)
     try:
         hops.set_option("lds_top", lds_top)
+        hops.set_option("occ8", 2 if occ8 else 0)
+        if occ8:
+            hops.set_option("grid_nodes", 2)
+            hops.set_option("steal", 4)
+            hops.set_option("split_floor", 0)
         for step, (vv, how) in enumerate([(v, "build"), (W.displaced(v, seed=9, amplitude=0.03), "refit"), (v * np.float32(1.1), "update")]):
             if how == "refit":
                 r.refit(T(vv, device))
@@ -265,7 +275,8 @@ def test_lds_staged_node_packets_match_the_oracle(device, lds_top):
             for g, e in zip(got, exp[:5]):
                 assert np.array_equal(g.cpu().numpy().reshape(e.shape), e)
     finally:
-        hops.set_option("lds_top", 0)
+        for k_, v_ in (("lds_top", 0), ("occ8", OCC8_DEFAULT), ("grid_nodes", 1), ("steal", 1), ("split_floor", 40)):
+            hops.set_option(k_, v_)
 
 
 @pytest.mark.timeout(900)

@@ -46,6 +46,7 @@ const opt_desc OPTS[] = {
     {"split_outlier", &tr_options::split_outlier, 0, 1024, false},
     {"usteal", &tr_options::usteal, 0, 4095, false},
     {"lds_top", &tr_options::lds_top, 0, 2, false},
+    {"occ8", &tr_options::occ8, 0, 2, false},
     {"split_floor", &tr_options::split_floor, 0, 100000, false},
 };
 constexpr int NUM_OPTS = (int)(sizeof(OPTS) / sizeof(OPTS[0]));

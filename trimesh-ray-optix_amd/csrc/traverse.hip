@@ -197,7 +197,11 @@ __device__ __forceinline__ int lane_rank(unsigned long long mask) {   // set bit
 // on its first descent inside the table (hp != 0: its heap index), the records come from LDS
 // (two ds_read_b128) and the trip issues no node gather at all; the first trip on which a lane has
 // backtracked, taken stolen work or left the table ends it for the wave.  Same records, same arithmetic.
-template <int Q, bool STATS, bool COMPACT, bool DEEP = false, bool QN = false, bool LT = false>
+// SLIM: 192 instead of 384 ints of LDS scratch per wave -- the hand-over lists its donors with
+// ds_permute / ds_bpermute and moves node and depth through registers (as wave_count_unordered_steal
+// does), so that only the per-ray merge keys and winner slots stay in LDS: ring + scratch = 9.5 KiB per
+// 128-thread workgroup, 16 workgroups = 8 waves per SIMD (k_query_direct_occ8).
+template <int Q, bool STATS, bool COMPACT, bool DEEP = false, bool QN = false, bool LT = false, bool SLIM = false>
 __device__ __forceinline__ bool wave_traverse_steal(const tr_bvh_view& b, tr_ray& r, bool go,
                                                     tr_result& res, tr_counters* cnt,
                                                     const tr_ring ring, int32_t* wl, int lane,
@@ -250,16 +254,17 @@ __device__ __forceinline__ bool wave_traverse_steal(const tr_bvh_view& b, tr_ray
     typedef __attribute__((address_space(3))) volatile int32_t lds_i32;
     typedef __attribute__((address_space(3))) volatile unsigned long long lds_u64;
     lds_i32* const lw = (lds_i32*)wl;
-    lds_i32* const list = lw;                    // [64] donor lane of pair k
+    lds_i32* const list = lw;                    // [64] donor lane of pair k          (not with SLIM)
     lds_i32* const xnode = lw + 64;              // [64] node handed over by donor lane
     lds_i32* const xdepth = lw + 128;            // [64] its depth
     // per-ray accumulators at the owner's index: partial results are deposited whenever a lane
     // finishes a piece of work (before it takes the next one) and once more at the end
-    int32_t* sum = wl + 192;                                                        // count
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(wl + 192);   // closest / first
-    lds_i32* const vsum = lw + 192;
-    lds_u64* const vkeys = (lds_u64*)(lw + 192);
-    lds_i32* const vslots = lw + 320;
+    constexpr int ACC = SLIM ? 0 : 192;          // SLIM: the accumulators are all the scratch there is
+    int32_t* sum = wl + ACC;                                                        // count
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(wl + ACC);   // closest / first
+    lds_i32* const vsum = lw + ACC;
+    lds_u64* const vkeys = (lds_u64*)(lw + ACC);
+    lds_i32* const vslots = lw + ACC + 128;
     auto deposit = [&]() {
         if (Q == TR_Q_COUNT) {
             if (res.count) atomicAdd(&sum[owner], res.count);
@@ -350,17 +355,30 @@ __device__ __forceinline__ bool wave_traverse_steal(const tr_bvh_view& b, tr_ray
                     __builtin_amdgcn_wave_barrier();
                 }
                 const int drank = lane_rank(donors), irank = lane_rank(idle);
-                if (can_give && drank < np) {
+                const bool give = can_give && drank < np;
+                int gnode = 0, gdepth = 0;
+                if (give) {
                     const uint32_t j = (uint32_t)__builtin_ctzll((unsigned long long)cand);
-                    list[drank] = lane;
-                    xnode[lane] = ring.base[(j & (TR_RING - 1)) * ring.stride];
-                    xdepth[lane] = (int32_t)(j + 1);
+                    gnode = ring.base[(j & (TR_RING - 1)) * ring.stride];
+                    gdepth = (int32_t)(j + 1);
+                    if (!SLIM) { list[drank] = lane; xnode[lane] = gnode; xdepth[lane] = gdepth; }
                     fs.trail &= ~(W(1) << j);
                     fs.owned &= ~(W(1) << j);
                 }
                 __builtin_amdgcn_wave_barrier();
                 const bool take = done && irank < np;
-                const int src = take ? list[irank] : lane;
+                int src;
+                if (SLIM) {
+                    // giver g sends its lane id to lane g (everybody else to distinct lanes from the top); the
+                    // read-back is issued by EVERY lane: ds_bpermute returns 0 for a masked-off source lane
+                    const unsigned long long givers = __ballot(give);
+                    const int tgt = give ? drank : 63 - lane_rank(~givers);
+                    const int lst = __builtin_amdgcn_ds_permute(tgt << 2, lane);
+                    const int pick = __shfl(lst, irank & 63);
+                    src = take ? pick : lane;
+                } else {
+                    src = take ? list[irank] : lane;
+                }
                 // a lane that takes new work first hands in what it has found so far
                 if (take) {
                     deposit();
@@ -372,11 +390,12 @@ __device__ __forceinline__ bool wave_traverse_steal(const tr_bvh_view& b, tr_ray
                 r.ix = __shfl(r.ix, src); r.iy = __shfl(r.iy, src); r.iz = __shfl(r.iz, src);
                 const int own2 = __shfl(owner, src);
                 const float bt = __shfl(res.best_t, src);
+                const int n2 = SLIM ? __shfl(gnode, src) : 0, d2 = SLIM ? __shfl(gdepth, src) : 0;
                 if (take) {
                     owner = own2;
                     tr_state_init(fs);
-                    fs.node = xnode[src];
-                    fs.depth = (uint32_t)xdepth[src];
+                    fs.node = SLIM ? n2 : xnode[src];
+                    fs.depth = (uint32_t)(SLIM ? d2 : xdepth[src]);
                     res.best_t = bt;
                     hp = 0u;
                 }
@@ -440,7 +459,7 @@ __device__ __forceinline__ void process_ray(const tr_bvh_view& b, const RayFetch
     if (in_range) write_result<Q>(b, out, i, r, res);
 }
 
-template <int Q, bool STATS, bool COMPACT, bool DEEP = false, bool QN = false, bool LT = false>
+template <int Q, bool STATS, bool COMPACT, bool DEEP = false, bool QN = false, bool LT = false, bool SLIM = false>
 __device__ __forceinline__ void process_ray_steal(const tr_bvh_view& b, const RayFetch& rf,
                                                   const QueryOut& out, int64_t i, bool in_range,
                                                   tr_counters* cnt, const tr_ring ring, int32_t* wl,
@@ -451,7 +470,7 @@ __device__ __forceinline__ void process_ray_steal(const tr_bvh_view& b, const Ra
     const bool valid = tr_ray_setup(r, o[0], o[1], o[2], d[0], d[1], d[2]) && in_range;
     tr_result res;
     bool split = false;
-    if (b.num_tris >= 2) split = wave_traverse_steal<Q, STATS, COMPACT, DEEP, QN, LT>(b, r, valid, res, cnt, ring, wl, (int)(threadIdx.x & 63), steal_min, toplds);
+    if (b.num_tris >= 2) split = wave_traverse_steal<Q, STATS, COMPACT, DEEP, QN, LT, SLIM>(b, r, valid, res, cnt, ring, wl, (int)(threadIdx.x & 63), steal_min, toplds);
     else brute_one<Q>(b, r, valid, res);   // no hierarchy below two triangles
     if (split && in_range) {   // this lane may hold another lane's ray now: take its own again
         fetch_ray(rf, i, o, d);
@@ -649,13 +668,13 @@ __device__ unsigned long long g_timeline[4 * TR_TIMELINE];
 
 // MODE: 0 fused ordered trip, 1 fused trip + intra-wave work stealing, 2 unordered two-phase
 // schedule (any / count / location on hierarchies of at least two triangles)
-template <int Q, bool STATS, bool COMPACT, int BS, int MODE = 0, bool DEEP = false, bool QN = false, bool LT = false>
-__global__ __launch_bounds__(BS) void k_query_direct(tr_bvh_view b, RayFetch rf, QueryOut out,
-                                                      int xcd_map, int scramble, int tile_w, int steal_min,
-                                                      const uint32_t* __restrict__ order, int order_split,
-                                                      uint32_t* __restrict__ cost,
-                                                      unsigned long long* stats,
-                                                      const int* __restrict__ sel) {
+template <int Q, bool STATS, bool COMPACT, int BS, int MODE, bool DEEP, bool QN, bool LT, bool SLIM>
+__device__ __forceinline__ void query_direct_body(const tr_bvh_view& b, const RayFetch& rf, const QueryOut& out,
+                                                  int xcd_map, int scramble, int tile_w, int steal_min,
+                                                  const uint32_t* __restrict__ order, int order_split,
+                                                  uint32_t* __restrict__ cost,
+                                                  unsigned long long* stats,
+                                                  const int* __restrict__ sel) {
     // dual launch (k_probe_coherence): this launch shape is the one for coherent batches (id 0)
     if (sel && *sel != 0) return;
 #ifdef TR_LDS_PAD
@@ -753,17 +772,18 @@ __global__ __launch_bounds__(BS) void k_query_direct(tr_bvh_view b, RayFetch rf,
         process_ray_unordered<Q, STATS, COMPACT, DEEP, true>(b, rf, out, i, i < rf.n && mine, &cnt, ring, lq,
                                                             steal_min & 0xff, smin);
     } else if (MODE == 1) {
-        __shared__ alignas(8) int32_t steal_lds[(BS / 64) * 384];
+        constexpr int SCR = SLIM ? 192 : 384;          // ints of stealing scratch per wave
+        __shared__ alignas(8) int32_t steal_lds[(BS / 64) * SCR];
         // A split block (one of the most expensive of the previous launch): this slot owns the rays
         // of every 2^parts_lg-th lane; the other lanes start idle and take subtrees of those rays
         // from the trip in the upper half of the argument on (the lower half: everybody else)
         const bool mine = (((int)threadIdx.x ^ part) & ((1 << parts_lg) - 1)) == 0;
         const uint32_t smin = parts_lg ? (uint32_t)steal_min >> 16 : (uint32_t)steal_min & 0xffffu;
-        process_ray_steal<Q, STATS, COMPACT, DEEP, QN, LT>(b, rf, out, i, i < rf.n && mine, &cnt, ring,
-                                             steal_lds + (threadIdx.x >> 6) * 384, smin, top_lds);
+        process_ray_steal<Q, STATS, COMPACT, DEEP, QN, LT, SLIM>(b, rf, out, i, i < rf.n && mine, &cnt, ring,
+                                             steal_lds + (threadIdx.x >> 6) * SCR, smin, top_lds);
 #ifdef TR_TIMELINE
-        tl_extra = (unsigned)(steal_lds[(threadIdx.x >> 6) * 384] & 0xffff) |
-                   ((unsigned long long)(steal_lds[(threadIdx.x >> 6) * 384 + 1] & 0xffff) << 16);
+        tl_extra = (unsigned)(steal_lds[(threadIdx.x >> 6) * SCR] & 0xffff) |
+                   ((unsigned long long)(steal_lds[(threadIdx.x >> 6) * SCR + 1] & 0xffff) << 16);
 #endif
     } else {
         // the plain shape is what large coherent batches get (small ones steal, incoherent ones
@@ -794,6 +814,32 @@ __global__ __launch_bounds__(BS) void k_query_direct(tr_bvh_view b, RayFetch rf,
     }
 #endif
     flush_stats<STATS>(cnt, stats);
+}
+
+// MODE: 0 fused ordered trip, 1 fused trip + intra-wave work stealing, 2 unordered two-phase schedule,
+// 3 unordered + stealing (query_direct_body)
+template <int Q, bool STATS, bool COMPACT, int BS, int MODE = 0, bool DEEP = false, bool QN = false, bool LT = false>
+__global__ __launch_bounds__(BS) void k_query_direct(tr_bvh_view b, RayFetch rf, QueryOut out,
+                                                      int xcd_map, int scramble, int tile_w, int steal_min,
+                                                      const uint32_t* __restrict__ order, int order_split,
+                                                      uint32_t* __restrict__ cost,
+                                                      unsigned long long* stats,
+                                                      const int* __restrict__ sel) {
+    query_direct_body<Q, STATS, COMPACT, BS, MODE, DEEP, QN, LT, false>(b, rf, out, xcd_map, scramble, tile_w, steal_min, order,
+                                                                        order_split, cost, stats, sel);
+}
+// The stealing closest / first launch on the grid nodes at EIGHT waves per SIMD: 64 registers (the
+// compiler is asked for them; the kernel needs 67 unconstrained) and 9.5 KiB of LDS per workgroup (the
+// slim hand-over, wave_traverse_steal<..., SLIM>).  Pays where the launch is large -- 4 M rays -3.8 % --
+// and costs where it is small or the waves share lines (262 k ... 590 k rays +1...+8 %, C2 / C4 / interior on
+// forced grid nodes +4...+6 %: profiles/r03_ab_occ8.txt).  Option occ8: 0 never, 1 from 2 M rays on, 2 always.
+template <int Q, bool DEEP>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void k_query_direct_occ8(tr_bvh_view b, RayFetch rf, QueryOut out, int xcd_map, int scramble, int tile_w, int steal_min,
+                         const uint32_t* __restrict__ order, int order_split, uint32_t* __restrict__ cost,
+                         unsigned long long* stats, const int* __restrict__ sel) {
+    query_direct_body<Q, false, true, 128, 1, DEEP, true, false, true>(b, rf, out, xcd_map, scramble, tile_w, steal_min, order,
+                                                                       order_split, cost, stats, sel);
 }
 
 // Order the blocks of the last launch by measured cost, most expensive first: one workgroup,
@@ -1783,6 +1829,15 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
                 }
             }
             if constexpr (Q == TR_Q_CLOSEST || Q == TR_Q_FIRST) {
+                if (!steal_launched && qn && (opt.occ8 == 2 || (opt.occ8 == 1 && rf.n >= ((int64_t)1 << 21))) && (compact || deep) && bs == 128) {
+                    if (compact)
+                        hipLaunchKernelGGL((k_query_direct_occ8<Q, false>), dim3((unsigned)nslots), dim3(128), 0, stream,
+                                           view, rf, out, xc, scramble, tile_w, steal_arg, order, (int)split_key, cost, d_stats, sel);
+                    else
+                        hipLaunchKernelGGL((k_query_direct_occ8<Q, true>), dim3((unsigned)nslots), dim3(128), 0, stream,
+                                           view, rf, out, xc, scramble, tile_w, steal_arg, order, (int)split_key, cost, d_stats, sel);
+                    steal_launched = true;
+                }
                 if (steal_launched) {
                 } else if (qn && compact) {
                     hipLaunchKernelGGL((k_query_direct<Q, false, true, 128, 1, false, true>), dim3((unsigned)nslots), dim3(128), 0, stream,
