@@ -102,7 +102,8 @@ def test_c5_headline_1M_tris_1024_closest(headline, device):
 def test_c5_100M_rays_in_8_shards(headline, device):
     """config 5(ii): 100 M hash rays as 8 contiguous shards of 12.5 M (the per-GPU chunks of an
     8-GPU run, traced here one after the other against the same BVH): per-shard properties at
-    full size, every 16th ray against the oracle, and sharded == unsharded on the seams."""
+    full size, every 4th ray against the oracle (25 M rays, bit for bit incl. loc / uv), and sharded ==
+    unsharded on the seams."""
     from triro.ray.sharded import shard_bounds
     v, f, r, R = headline
     n, world = 100_000_000, 8
@@ -114,12 +115,12 @@ def test_c5_100M_rays_in_8_shards(headline, device):
         hit, front, tri, loc, uv = r.intersects_closest(o, d)
         assert torch.equal(hit, tri >= 0) and not front[~hit].any() and torch.all(loc[~hit] == 0)
         total_hits += int(hit.sum())
-        sub = slice(0, b - a, 16)
+        sub = slice(rank % 4, b - a, 4)
         on, dn = o[sub].cpu().numpy(), d[sub].cpu().numpy()
         eh, ef, et, el, eu, _ = R.closest_raw(on, dn)
         assert np.array_equal(hit[sub].cpu().numpy(), eh) and np.array_equal(tri[sub].cpu().numpy(), et)
         assert np.array_equal(front[sub].cpu().numpy(), ef)
-        np.testing.assert_allclose(loc[sub].cpu().numpy(), el, rtol=RTOL, atol=ATOL)
+        assert np.array_equal(loc[sub].cpu().numpy(), el) and np.array_equal(uv[sub].cpu().numpy(), eu)
         if rank > 0:   # rays around the seam, traced as one unsharded batch
             os_, ds_ = W.hash_rays_torch(2048, 99, lo, hi, start=a - 1024, device=device)
             t2 = r.intersects_first(os_, ds_)

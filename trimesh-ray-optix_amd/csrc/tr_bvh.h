@@ -315,6 +315,27 @@ struct tr_ring {
     int32_t* base;   // nullptr = no ring (always climb)
     int32_t stride;
 };
+// Ring accesses go through an explicit LDS pointer on the device.  With the generic pointer the compiler
+// merged "pop the ring slot (LDS)" and "read the sibling from links[] (global)" -- two 4-byte loads that
+// feed the same variable -- into ONE flat_load_dword with a selected address: every backtracking trip
+// then sent a 64-lane flat load through the texture addresser (the busiest unit of the kernels) and
+// waited for vmcnt AND lgkmcnt, where a ds_read_b32 would do.
+TR_HD int32_t tr_ring_get(const tr_ring& ring, uint32_t slot) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(TR_RING_GENERIC)      // (-DTR_RING_GENERIC: the old code path, for A/B runs)
+    typedef __attribute__((address_space(3))) int32_t tr_lds_i32;
+    return ((tr_lds_i32*)ring.base)[slot * ring.stride];
+#else
+    return ring.base[slot * ring.stride];
+#endif
+}
+TR_HD void tr_ring_put(const tr_ring& ring, uint32_t slot, int32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(TR_RING_GENERIC)
+    typedef __attribute__((address_space(3))) int32_t tr_lds_i32;
+    ((tr_lds_i32*)ring.base)[slot * ring.stride] = v;
+#else
+    ring.base[slot * ring.stride] = v;
+#endif
+}
 
 // Per-lane traversal state between two iterations.  W = uint64_t in general; uint32_t when
 // the hierarchy is at most 32 levels high (halves the 64-bit shift/clz work per trip).
@@ -421,7 +442,7 @@ TR_HD void tr_node_step(const tr_bvh_view& b, const tr_ray& r, tr_state& st, con
             st.trail |= (1ull << st.depth);
             if (ring.base) {
                 const uint32_t slot = st.depth & (TR_RING - 1);
-                ring.base[slot * ring.stride] = swap ? c0 : c1;
+                tr_ring_put(ring, slot, swap ? c0 : c1);
                 st.owned = (st.owned & ~(TR_RING_MASK << slot)) | (1ull << st.depth);
             }
         }
@@ -434,7 +455,7 @@ TR_HD void tr_node_step(const tr_bvh_view& b, const tr_ray& r, tr_state& st, con
         const uint32_t j = 63u - (uint32_t)__builtin_clzll(st.trail);
         st.trail &= ~(1ull << j);
         if (ring.base && ((st.owned >> j) & 1ull)) {
-            st.node = ring.base[(j & (TR_RING - 1)) * ring.stride];
+            st.node = tr_ring_get(ring, j & (TR_RING - 1));
         } else {
             int32_t node = st.node;
             uint32_t depth = st.depth;
@@ -649,7 +670,7 @@ TR_HD void tr_fused_body(const tr_bvh_view& b, const tr_ray& r,
                 st.trail |= (W(1) << st.depth);
                 if (ring.base) {
                     const uint32_t slot = st.depth & (TR_RING - 1);
-                    ring.base[slot * ring.stride] = swap ? c0 : c1;
+                    tr_ring_put(ring, slot, swap ? c0 : c1);
                     st.owned = (st.owned & ~(tr_ring_mask(W(0)) << slot)) | (W(1) << st.depth);
                 }
             }
@@ -661,7 +682,7 @@ TR_HD void tr_fused_body(const tr_bvh_view& b, const tr_ray& r,
             const uint32_t j = tr_top_bit(st.trail);
             st.trail &= ~(W(1) << j);
             if (ring.base && ((st.owned >> j) & W(1))) {
-                st.node = ring.base[(j & (TR_RING - 1)) * ring.stride];
+                st.node = tr_ring_get(ring, j & (TR_RING - 1));
             } else if constexpr (std::is_same<REC, tr_rec_f>::value) {
                 int32_t node = st.node;
                 uint32_t depth = st.depth;
@@ -833,7 +854,7 @@ TR_HD void tr_unord_step(const tr_bvh_view& b, const tr_ray& r, bool go_node, bo
                 st.trail |= (W(1) << st.depth);
                 if (ring.base) {
                     const uint32_t slot = st.depth & (TR_RING - 1);
-                    ring.base[slot * ring.stride] = swap ? c0 : c1;
+                    tr_ring_put(ring, slot, swap ? c0 : c1);
                     st.owned = (st.owned & ~(tr_ring_mask(W(0)) << slot)) | (W(1) << st.depth);
                 }
             }
@@ -844,7 +865,7 @@ TR_HD void tr_unord_step(const tr_bvh_view& b, const tr_ray& r, bool go_node, bo
         } else {
             const uint32_t j = tr_top_bit(st.trail);
             st.trail &= ~(W(1) << j);
-            if (ring.base && ((st.owned >> j) & W(1))) st.node = ring.base[(j & (TR_RING - 1)) * ring.stride];
+            if (ring.base && ((st.owned >> j) & W(1))) st.node = tr_ring_get(ring, j & (TR_RING - 1));
             else st.node = tr_climb<STATS>(b, st.node, st.depth, j, cnt);
             st.depth = j + 1;
         }

@@ -359,7 +359,7 @@ __device__ __forceinline__ bool wave_traverse_steal(const tr_bvh_view& b, tr_ray
                 int gnode = 0, gdepth = 0;
                 if (give) {
                     const uint32_t j = (uint32_t)__builtin_ctzll((unsigned long long)cand);
-                    gnode = ring.base[(j & (TR_RING - 1)) * ring.stride];
+                    gnode = tr_ring_get(ring, j & (TR_RING - 1));
                     gdepth = (int32_t)(j + 1);
                     if (!SLIM) { list[drank] = lane; xnode[lane] = gnode; xdepth[lane] = gdepth; }
                     fs.trail &= ~(W(1) << j);
@@ -596,7 +596,7 @@ __device__ __forceinline__ int wave_count_unordered_steal(const tr_bvh_view& b, 
         int gnode = 0, gdepth = 0;
         if (give) {
             const uint32_t j = (uint32_t)__builtin_ctzll((unsigned long long)cand);     // the shallowest: the biggest subtree
-            gnode = ring.base[(j & (TR_RING - 1)) * ring.stride];
+            gnode = tr_ring_get(ring, j & (TR_RING - 1));
             gdepth = (int)(j + 1);
             st.trail &= ~(W(1) << j);
             st.owned &= ~(W(1) << j);
