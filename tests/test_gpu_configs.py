@@ -102,8 +102,8 @@ def test_c5_headline_1M_tris_1024_closest(headline, device):
 def test_c5_100M_rays_in_8_shards(headline, device):
     """config 5(ii): 100 M hash rays as 8 contiguous shards of 12.5 M (the per-GPU chunks of an
     8-GPU run, traced here one after the other against the same BVH): per-shard properties at
-    full size, every 4th ray against the oracle (25 M rays, bit for bit incl. loc / uv), and sharded ==
-    unsharded on the seams."""
+    full size, EVERY ray against the oracle (100 M rays, bit for bit incl. loc / uv: the oracle runs
+    at ~12 Mrays/s on the GPU box's 128 host threads), and sharded == unsharded on the seams."""
     from triro.ray.sharded import shard_bounds
     v, f, r, R = headline
     n, world = 100_000_000, 8
@@ -115,7 +115,7 @@ def test_c5_100M_rays_in_8_shards(headline, device):
         hit, front, tri, loc, uv = r.intersects_closest(o, d)
         assert torch.equal(hit, tri >= 0) and not front[~hit].any() and torch.all(loc[~hit] == 0)
         total_hits += int(hit.sum())
-        sub = slice(rank % 4, b - a, 4)
+        sub = slice(0, b - a)
         on, dn = o[sub].cpu().numpy(), d[sub].cpu().numpy()
         eh, ef, et, el, eu, _ = R.closest_raw(on, dn)
         assert np.array_equal(hit[sub].cpu().numpy(), eh) and np.array_equal(tri[sub].cpu().numpy(), et)
