@@ -3,7 +3,8 @@
 Only tests/, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
 import this module.  It loads ``oracle/libtriro_oracle.so`` (built from
 ``oracle/triro_oracle.c`` -- see that file's header for the parity status:
-*parity unpinned* against the real OptiX path) and restates, in numpy, the
+*parity unpinned* against the real OptiX path at the bit level; pinned at image precision on
+the reference's published README rendering) and restates, in numpy, the
 Python-level conventions of the reference's public class:
 
 * return orders / dtypes / shapes      triro/ray/ray_optix.py:117-146,157-164,191-223

@@ -338,3 +338,26 @@ def test_packed_closest_edge_cases(device):
         r.closest_expand(torch.zeros(5, 3, device=device))                      # not int32
     with pytest.raises(ValueError):
         r.intersects_closest_packed(org, dirs, out=torch.zeros(7, 3, dtype=torch.int32, device=device))
+
+
+def test_hip_path_reproduces_the_reference_s_published_readme_image(device):
+    """README.md:31-53 run through the HIP path, statement for statement, against the reference's own
+    published rendering of it (assets/location.png -> tests/golden/reference_readme_location_axes.npz):
+    the one comparison with reference-PRODUCED data that exists (8-bit image precision)."""
+    pytest.importorskip("PIL")
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from readme_image import assert_matches_reference_image, compare_with_reference_image
+    from triro.ray.ray_optix import RayMeshIntersector
+
+    class Mesh:                                   # any object with .vertices / .faces (trimesh is not installed)
+        vertices, faces = W.icosphere(3)
+    intersector = RayMeshIntersector(mesh=Mesh)
+    y, x = torch.meshgrid([torch.linspace(1, -1, 800), torch.linspace(-1, 1, 800)], indexing='ij')
+    z = -torch.ones_like(x)
+    ray_directions = torch.stack([x, y, z], dim=-1).to(device)
+    ray_origins = torch.Tensor([0, 0, 3]).to(device).broadcast_to(ray_directions.shape)
+    hit, front, ray_idx, tri_idx, location, uv = intersector.intersects_closest(ray_origins, ray_directions, stream_compaction=True)
+    locs = torch.zeros((800, 800, 3), device=device)
+    locs[hit] = location
+    assert_matches_reference_image(compare_with_reference_image(locs.cpu().numpy()))
