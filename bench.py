@@ -561,6 +561,31 @@ def run_rank(args):
                                         "on an RTX 3090, its own bedroom scene); kernel_ms = HIP events around the call, call_ms = "
                                         "wall per Python call in a loop of 500 (asynchronous launches), call_sync_ms = with a device "
                                         "synchronisation in every call as the reference's loop has"}
+            # Two batches in flight: the same launches dealt round-robin to two streams, each with its own outputs
+            # (and its own learned launch order: the order is kept per (handle, stream)).  The second launch fills
+            # the ramp-down of the first -- a launch ends with a few long waves.  NOT the headline (`value` is one
+            # stream, one launch at a time, as the reference's loop runs): what a caller that pipelines batches gets.
+            side = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+            for s_ in side:
+                s_.wait_stream(torch.cuda.current_stream(dev))
+            outs2 = [None, None]
+            for k in range(80):
+                with torch.cuda.stream(side[k & 1]):
+                    outs2[k & 1] = r.intersects_closest(origins, dirs)
+            sync()
+            t1 = time.perf_counter()
+            for k in range(600):
+                with torch.cuda.stream(side[k & 1]):
+                    outs2[k & 1] = r.intersects_closest(origins, dirs)
+            sync()
+            pip_ms = (time.perf_counter() - t1) / 600 * 1e3
+            first_out = r.intersects_closest(origins, dirs)
+            sync()
+            res["pipelined"] = {"streams": 2, "ms_per_step": round(pip_ms, 4), "mrays_per_s": round(n / pip_ms / 1e3, 1),
+                                "results_identical": bool(all(torch.equal(a, b) for o2 in outs2 for a, b in zip(o2, first_out))),
+                                "note": "600 launches of the same batch dealt round-robin to two streams (own outputs per stream): "
+                                        "the next launch fills the ramp-down of the previous one; informational, not `value`"}
+            del outs2, first_out
             st = hops.trace_stats_closest(r.as_wrapper, origins, dirs)
             gbytes = st["node_visits"] * 64 + st["tri_tests"] * 48
             gach = gbytes / (kernel_avg_ms * 1e-3) / 1e9
