@@ -552,15 +552,46 @@ def run_rank(args):
                     out_rs = rr.intersects_closest(o_rs, d_rs)
                     sync()               # the reference's loop synchronises in every call (cudaFree, ray.cpp:287)
                 sync_ms = (time.perf_counter() - t1) / 200 * 1e3
+                # the same call captured in a HIP graph (torch.cuda.graph on a side stream that has been queried
+                # before: the library allocates nothing and never synchronises in a warmed-up query) and replayed
+                # with a synchronisation per replay: what is left of the host side of a small synchronous call
+                graph_ms = None
+                try:
+                    gs = torch.cuda.Stream(dev)
+                    gs.wait_stream(torch.cuda.current_stream(dev))
+                    with torch.cuda.stream(gs):
+                        for _ in range(12):
+                            rr.intersects_closest(o_rs, d_rs)
+                    torch.cuda.current_stream(dev).wait_stream(gs)
+                    sync()
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph, stream=gs):
+                        out_g = rr.intersects_closest(o_rs, d_rs)
+                    for _ in range(20):
+                        graph.replay()
+                    sync()
+                    t1 = time.perf_counter()
+                    for _ in range(200):
+                        graph.replay()
+                        sync()
+                    graph_ms = (time.perf_counter() - t1) / 200 * 1e3
+                    if not all(torch.equal(a, b) for a, b in zip(out_g, out_rs)):
+                        graph_ms = None
+                    del graph, out_g
+                except Exception as exc:      # a companion must never cost the bench line
+                    print(f"bench.py: graph replay companion skipped ({exc})", file=sys.stderr)
                 rs[name] = {"kernel_ms": round(float(np.mean(kms)), 4), "call_ms": round(call_ms, 4),
-                            "call_sync_ms": round(sync_ms, 4), "hit_fraction": round(float(out_rs[0].float().mean().item()), 4),
+                            "call_sync_ms": round(sync_ms, 4),
+                            "graph_replay_sync_ms": None if graph_ms is None else round(graph_ms, 4),
+                            "hit_fraction": round(float(out_rs[0].float().mean().item()), 4),
                             "triangles": int(rr.bvh_info()["num_tris"])}
             res["ref_shape"] = {"rays": 640 * 360, "scenes": rs,
                                 "ref_shape_kernel_ms": rs["interior"]["kernel_ms"], "ref_shape_call_ms": rs["interior"]["call_ms"],
                                 "note": "640x360 pinhole, f=444 px, stride-0 origin (the reference's published call: 83.62 us wall "
                                         "on an RTX 3090, its own bedroom scene); kernel_ms = HIP events around the call, call_ms = "
                                         "wall per Python call in a loop of 500 (asynchronous launches), call_sync_ms = with a device "
-                                        "synchronisation in every call as the reference's loop has"}
+                                        "synchronisation in every call as the reference's loop has, graph_replay_sync_ms = the call captured in a HIP "
+                                        "graph and replayed, one synchronisation per replay"}
             # Two batches in flight: the same launches dealt round-robin to two streams, each with its own outputs
             # (and its own learned launch order: the order is kept per (handle, stream)).  The second launch fills
             # the ramp-down of the first -- a launch ends with a few long waves.  NOT the headline (`value` is one
