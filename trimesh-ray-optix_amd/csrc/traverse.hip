@@ -498,7 +498,7 @@ __device__ __forceinline__ void wave_traverse_unordered(const tr_bvh_view& b, co
         const unsigned long long mn = __ballot(can_node), ml = __ballot(st.nq > 0);
         if ((mn | ml) == 0ull) break;
         const bool parked = st.node >= 0 && !can_node;
-        const bool leaf_phase = mn == 0ull || __ballot(parked) != 0ull || __popcll(ml) >= leaf_min;
+        const bool leaf_phase = mn == 0ull || __ballot(parked) != 0ull || (int)__popcll(ml) >= (int)leaf_min;
         tr_unord_step<Q, K, STATS, COMPACT, W>(b, r, can_node, leaf_phase, st, res, top, cnt, ring, lq);
         TR_CONVERGE();
     }
@@ -559,7 +559,7 @@ __device__ __forceinline__ int wave_count_unordered_steal(const tr_bvh_view& b, 
             live = (mn | ml) != 0ull;
             if (live) {
                 const bool parked = st.node >= 0 && !can_node;
-                const bool leaf_phase = mn == 0ull || __ballot(parked) != 0ull || __popcll(ml) >= leaf_min;
+                const bool leaf_phase = mn == 0ull || __ballot(parked) != 0ull || (int)__popcll(ml) >= (int)leaf_min;
                 tr_unord_step<Q, 1, STATS, COMPACT, W>(b, r, can_node, leaf_phase, st, res, top, cnt, ring, lq);
             }
             TR_CONVERGE();
