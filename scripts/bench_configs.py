@@ -131,6 +131,16 @@ query("ROOM closest, interior scene, camera inside, 640x360 reference-shaped ray
 query("ROOM count, same rays", r, 640 * 360, "count", lambda: r.intersects_count(ot, dt), tag="roomcount", reps=30, warm=12)
 nh = r.intersects_location(ot, dt)[0].shape[0]
 query("ROOM location, same rays", r, 640 * 360, "location", lambda: r.intersects_location(ot, dt), reps=20, warm=8, hits=nh)
+v, f = W.terrain()
+r = RayMeshIntersector(vertices=T(v), faces=T(f))
+_, d = W.ref_shape_rays(W.TERRAIN_EYE, W.TERRAIN_TARGET, 1024, 576, 444.0 * 1024 / 640)
+ot = torch.from_numpy(np.array(W.TERRAIN_EYE, np.float32)).to(dev).expand(576, 1024, 3)
+dt = T(d)
+query("TERRAIN closest, open height field, grazing camera, 1024x576 reference-shaped rays", r, 1024 * 576, "closest",
+      lambda: r.intersects_closest(ot, dt), reps=50, warm=20)
+query("TERRAIN count, same rays", r, 1024 * 576, "count", lambda: r.intersects_count(ot, dt), reps=30, warm=12)
+nh = r.intersects_location(ot, dt)[0].shape[0]
+query("TERRAIN location, same rays", r, 1024 * 576, "location", lambda: r.intersects_location(ot, dt), reps=20, warm=8, hits=nh)
 v, f = W.headline_mesh(8)
 t0 = time.perf_counter()
 r = RayMeshIntersector(vertices=T(v), faces=T(f))

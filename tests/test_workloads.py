@@ -64,3 +64,19 @@ def test_interior_room_is_closed_and_deep():
     cnt = R.intersects_count(np.ascontiguousarray(o.reshape(-1, 3)), d.reshape(-1, 3))
     assert cnt.mean() > 4.5 and cnt.max() > 8
     assert np.all(np.abs(loc) <= np.array([4.001, 3.001, 3.001]))
+
+
+def test_terrain_is_deterministic_and_open():
+    v, f = W.terrain(64)
+    v2, f2 = W.terrain(64)
+    assert np.array_equal(v, v2) and np.array_equal(f, f2)
+    assert v.dtype == np.float32 and f.dtype == np.int32 and len(f) == 2 * 64 * 64 and len(v) == 65 * 65
+    # upward-facing: every triangle normal has a positive y component
+    a, b, c = v[f[:, 0]].astype(np.float64), v[f[:, 1]].astype(np.float64), v[f[:, 2]].astype(np.float64)
+    assert (np.cross(b - a, c - a)[:, 1] > 0).all()
+    assert len(W.terrain()[1]) == 1048352
+    # the default camera sees both ground and sky
+    from oracle.oracle import OracleIntersector
+    o, d = W.ref_shape_rays(W.TERRAIN_EYE, W.TERRAIN_TARGET, w=160, h=90, f=111.0)
+    hit = OracleIntersector(*W.terrain(128), 1).closest_raw(np.ascontiguousarray(o.reshape(-1, 3)), d.reshape(-1, 3))[0]
+    assert 0.3 < hit.mean() < 0.8 and not hit.reshape(90, 160)[:20].any() and hit.reshape(90, 160)[-20:].all()

@@ -348,6 +348,29 @@ def pinhole_grid(width: int = 1024, height: int = 1024, vfov_deg: float = 40.0,
     return o, d.astype(np.float32)
 
 
+def terrain(n: int = 724, seed: int = 0, size: float = 40.0, relief: float = 2.5):
+    """An open height field seen from just above the ground: n x n cells (2 n^2 triangles; n = 724 ->
+    1 048 352) over a size x size square in the xz plane, heights = five octaves of sines (ridges up to
+    `relief`).  With TERRAIN_EYE / TERRAIN_TARGET most rays GRAZE the surface for a long way before they hit
+    (long traversals near the horizon), and the upper part of the image misses everything (sky) -- the
+    opposite of the closed blobs and of the interior scene: skewed block costs, rays that leave the mesh."""
+    rng = np.random.default_rng(seed)
+    ph = rng.random((5, 4)) * 2 * np.pi
+    fr = np.array([[1.0, 1.3], [2.1, 1.7], [4.3, 3.9], [8.9, 7.7], [17.0, 19.0]])
+
+    def h(s, t):
+        out = np.zeros_like(s)
+        for k in range(5):
+            out += (0.5 ** k) * (np.sin(2 * np.pi * fr[k, 0] * s + ph[k, 0]) * np.sin(2 * np.pi * fr[k, 1] * t + ph[k, 1]) +
+                                 0.5 * np.sin(2 * np.pi * (fr[k, 0] * s + fr[k, 1] * t) + ph[k, 2]))
+        return relief * out / 3.0
+    v, f = _grid_patch((-size / 2, 0.0, -size / 2), (0, 0, size), (size, 0, 0), n, n, h)      # normal +y
+    return v.astype(np.float32), f.astype(np.int32)
+
+
+TERRAIN_EYE, TERRAIN_TARGET = (-17.0, 3.2, -15.0), (12.0, -1.0, 11.0)
+
+
 def ref_shape_rays(eye, target, w: int = 640, h: int = 360, f: float = 444.0, up=(0.0, 1.0, 0.0)):
     """The reference's published benchmark shape (test/performance_test.py:10-20, 29-31, 39-44): w x h
     pinhole rays, focal length f pixels, unit directions x = col - (w-1)/2, y = row - (h-1)/2, z = -f
