@@ -1,0 +1,54 @@
+"""A "cloud" at full size: 1 000 000 small triangles of arbitrary winding scattered in a cube (unstructured:
+no surfaces, no coherence between neighbouring triangles), a camera outside.  A ray meets 14 triangles on
+average and up to 60 -- far beyond the multi-hit cap of 8, so the list query replaces entries at scale --
+and front / back faces alternate at random.  All queries against the oracle, bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+import workloads as W
+from oracle.oracle import OracleIntersector
+
+pytestmark = pytest.mark.gpu
+EYE, TARGET = (-2.2, 0.6, -1.8), (0.2, -0.1, 0.1)
+
+
+def T(x, dev):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def test_camera_through_a_million_triangle_cloud(device):
+    from triro.ray.ray_optix import RayMeshIntersector
+    v, f = W.random_soup(1_000_000, seed=5, extent=1.0, size=0.02)
+    r = RayMeshIntersector(vertices=T(v, device), faces=T(f, device))
+    R = OracleIntersector(v, f, 1)
+    o, d = W.ref_shape_rays(EYE, TARGET)
+    ot = torch.from_numpy(np.array(EYE, np.float32)).to(device).expand(360, 640, 3)
+    dt = T(d, device)
+    of, df = np.ascontiguousarray(o.reshape(-1, 3)), d.reshape(-1, 3)
+    eh, ef, et, el, eu, _ = R.closest_raw(of, df)
+    cnt = R.intersects_count(of, df)
+    assert 0.4 < eh.mean() < 0.9 and cnt.max() > 30 and 0.3 < ef[eh].mean() < 0.7
+    for k in range(10):
+        hit, front, tri, loc, uv = [x.cpu().numpy() for x in r.intersects_closest(ot, dt)]
+        assert np.array_equal(hit.reshape(-1), eh) and np.array_equal(tri.reshape(-1), et), f"launch {k}"
+        assert np.array_equal(front.reshape(-1), ef) and np.array_equal(loc.reshape(-1, 3), el), f"launch {k}"
+        assert np.array_equal(uv.reshape(-1, 2), eu), f"launch {k}"
+        if k % 3 == 0:
+            assert np.array_equal(r.intersects_count(ot, dt).cpu().numpy().reshape(-1), cnt), f"launch {k}"
+            assert np.array_equal(r.intersects_any(ot, dt).cpu().numpy().reshape(-1), eh)
+            assert np.array_equal(r.intersects_first(ot, dt).cpu().numpy().reshape(-1), et)
+    e_loc, e_ray, e_tri = R.intersects_location(of, df)        # the 8 nearest of up to 60 hits per ray
+    loc, ray, tri = r.intersects_location(ot, dt)
+    assert loc.shape[0] == int(np.minimum(cnt, 8).sum())
+    assert np.array_equal(ray.cpu().numpy(), e_ray) and np.array_equal(tri.cpu().numpy(), e_tri)
+    assert np.array_equal(loc.cpu().numpy(), e_loc)
+    # incoherent rays through the cloud (the streaming launch)
+    n = 2_100_000
+    o2, d2 = W.hash_rays_torch(n, 21, [-1.5] * 3, [1.5] * 3, device=device)
+    got = r.intersects_closest(o2, d2)
+    sub = slice(0, n, 7)
+    exp = R.closest_raw(o2[sub].cpu().numpy(), d2[sub].cpu().numpy())
+    for g, e in zip(got, exp[:5]):
+        assert np.array_equal(g[sub].cpu().numpy(), e)
+    assert np.array_equal(r.intersects_count(o2, d2)[sub].cpu().numpy(), R.intersects_count(o2[sub].cpu().numpy(), d2[sub].cpu().numpy()))
