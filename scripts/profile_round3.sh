@@ -18,6 +18,8 @@ prof r03_c4location k_query_direct --config c4 --query location
 prof r03_roomclosest k_query_direct --config room --query closest
 prof r03_roomcount k_query_direct --config room --query count
 prof r03_c5s k_query_stream --config c5s --query closest
+prof r03_terrainclosest k_query_direct --config terrain --query closest --res 1024
+prof r03_terraincount k_query_direct --config terrain --query count --res 1024
 # the headline: kernel trace of the literal default command, then the PMC passes of the same kernel
 timeout 600 bash scripts/profile_default.sh r03m > /dev/null 2>&1
 PROFILE_CMD="bench.py (default flags: 1000 timed steps)" PROFILE_STEPS=1000 python3 scripts/summarize_profile.py r03m k_query_direct > /dev/null 2>&1; cp profiles/r03m_summary.* gpurun_out/r03/
