@@ -1731,6 +1731,14 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
             // blocks, 0.6 waves per slot of the chip -- a quarter of the blocks, 0.136 -> 0.115 ms; at
             // 410 k rays an eighth, 0.142 -> 0.125 ms: profiles/r03_sweep_small_split.jsonl)
             if (can_tile8 && !small_tris) split_shift = nblocks_direct <= 2048 ? 2 : (nblocks_direct <= 4096 ? 3 : (nblocks_direct <= 8192 ? 4 : (nblocks_direct < 32768 ? 5 : 0)));
+            // ... and HALF of them while the launch then still leaves three tenths of the chip's wave slots
+            // free (147 k rays of the headline image 0.099 -> 0.091 ms, of the terrain 0.098 -> 0.084, headline
+            // count 0.154 -> 0.134; at 200 k rays -- 76 % of the slots -- already +4 %, at 262 k rays half the
+            // blocks would fill every slot: +3...+17 %; profiles/r03_ab_split_half.txt)
+            if (split_shift == 2) {
+                const int64_t s1 = (nblocks_direct >> 1) / 8;
+                if (2 * (nblocks_direct + 8 * (s1 + 2 * (s1 >> 2))) <= (int64_t)st->num_cus * 28 * 7 / 10) split_shift = 1;
+            }
             else if (!can_tile8 && nblocks_direct <= 2048) split_shift = 4;
         }
         int64_t split = 0;
