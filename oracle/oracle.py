@@ -141,6 +141,29 @@ class OracleIntersector:
         return (hit.astype(bool).reshape(b), front.astype(bool).reshape(b), tri.reshape(b),
                 loc.reshape(*b, 3), uv.reshape(*b, 2), t.reshape(b))
 
+    def closest_timed(self, o, d, threads: int, passes: int = 1):
+        """seconds of `passes` calls of the C entry point ALONE (oracle_closest on dense [n, 3] rays with
+        `threads` OpenMP threads, dynamic schedule over rays) -- bench.py's cpu_baseline; nothing of numpy
+        is inside the clock.  The output arrays are allocated and touched once, before the clock: a fresh
+        np.empty per pass puts ~8 000 page faults per million rays into the timed call, and in a VM those
+        (16 us each, serialised on the address-space lock) cost more than the tracing on 8 threads."""
+        import time
+        o = np.ascontiguousarray(o, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)
+        n = len(o)
+        # (np.full writes every page; np.zeros would hand out untouched copy-on-write zero pages)
+        hit, front = np.full(n, 1, np.uint8), np.full(n, 1, np.uint8)
+        tri, t = np.full(n, 1, np.int32), np.full(n, 1, np.float32)
+        loc, uv = np.full((n, 3), 1, np.float32), np.full((n, 2), 1, np.float32)
+        args = (self._h, _p(o, C.c_float), _p(d, C.c_float), n, self.mode, int(threads), _p(hit, C.c_uint8),
+                _p(front, C.c_uint8), _p(tri, C.c_int32), _p(loc, C.c_float), _p(uv, C.c_float), _p(t, C.c_float))
+        el = 0.0
+        for _ in range(passes):
+            t0 = time.perf_counter()
+            lib().oracle_closest(*args)
+            el += time.perf_counter() - t0
+        return el
+
     def intersects_closest(self, origins, directions, stream_compaction=False):
         hit, front, tri, loc, uv, _ = self.closest_raw(origins, directions)
         if stream_compaction:  # ray_optix.py:142-144
@@ -219,3 +242,25 @@ class OracleIntersector:
 
 def num_threads() -> int:
     return int(lib().oracle_num_threads())
+
+
+def usable_cpus() -> int:
+    """CPUs this process can really run on: the affinity mask cut by the cgroup's CPU quota (a
+    container that shows 128 cores may be allowed 8: OpenMP's default would oversubscribe them)."""
+    import math
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, math.ceil(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, math.ceil(q / per)))
+            break
+        except Exception:
+            continue
+    return max(1, n)

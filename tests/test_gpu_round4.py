@@ -1,0 +1,167 @@
+"""Round 4 GPU tests: the multi-GPU path with more than one rank on ONE device (gloo, host-staged), the
+destination rank's emulation, the vectorised record expansion, the public async call without collectives."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import workloads as W
+from oracle.oracle import OracleIntersector
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _port(base):
+    return str(base + os.getpid() % 1000)
+
+
+def _bench(extra, timeout=900):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + extra
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert p.returncode == 0, (p.returncode, p.stdout[-2000:], p.stderr[-4000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_share_one_gpu_real_tracer():
+    """tests/gloo_world2_gpu.py: two processes, both on cuda:0, real tracer, every query family, every
+    destination, ragged / weighted / image shards -- all torch.equal to the unsharded call"""
+    script = os.path.join(ROOT, "tests", "gloo_world2_gpu.py")
+    port = _port(29700)
+    procs = [subprocess.Popen([sys.executable, script, str(r), "2", port], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=840) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0 and so.strip().endswith("OK"), (p.returncode, so[-1000:], se[-4000:])
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("extra", [
+    [],                                                            # c5i weak: one 256^2 batch per rank
+    ["--scaling", "strong"],                                       # ONE batch in two row bands
+    ["--scaling", "strong", "--dst-share", "0.5"],                 # ... rank 0 takes a smaller band
+    ["--workload", "c5ii", "--total-rays", "300001"],              # ragged shards of one flat batch
+    ["--workload", "c5ii", "--total-rays", "300001", "--dst-share", "auto", "--chunks", "3"],
+], ids=["weak", "strong", "strong-weighted", "c5ii-ragged", "c5ii-weighted-chunks"])
+def test_bench_two_ranks_on_one_gpu_over_gloo(extra):
+    """bench.py --gpus 2 --backend gloo with the REAL tracer (both ranks on cuda:0): the launcher, the pipeline and
+    the self-verification (last timed step == cold first call) with two ranks and device tensors"""
+    r = _bench(["--gpus", "2", "--backend", "gloo", "--subdiv", "5", "--res", "256", "--steps", "4", "--warmup", "2",
+                "--min-warmup-ms", "0", "--no-cpu-baseline", "--no-companions"] + extra)
+    assert r["n_gpus"] == 2 and r["verified"] is True
+    assert "NOT a measurement" in r["data"]
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("extra", [
+    ["--emulate-world", "8"],
+    ["--emulate-world", "4", "--scaling", "strong", "--dst-share", "auto"],
+    ["--emulate-world", "8", "--workload", "c5ii", "--total-rays", "2000003", "--dst-share", "auto", "--chunks", "2"],
+    ["--emulate-world", "3", "--workload", "c5ii", "--total-rays", "500000", "--arrival-priority"],
+], ids=["weak8", "strong4-weighted", "c5ii8-weighted", "c5ii3-priority"])
+def test_emulated_destination_rank_is_bit_exact(extra):
+    """bench.py --emulate-world: rank 0's step with N-1 chunks of records arriving as device copies and expanded on
+    the side stream; every row of the gathered outputs == a dense trace of that rank's rays"""
+    r = _bench(["--subdiv", "5", "--res", "256", "--steps", "6", "--warmup", "3"] + extra)
+    assert r["verified"] is True and r["emulated_world"] >= 3
+    e = r["emulation"]
+    assert e["rank0_ms_per_step"] > 0 and e["plain_1gpu_ms_per_step"] > 0 and e["implied_scaling_vs_1gpu"] > 0
+
+
+def test_vectorised_expansion_matches_the_scalar_kernel_and_the_dense_trace(device):
+    """tr_closest_expand: four rays per thread with 16-byte accesses (aligned rows) + the one-ray kernel for the
+    rest; both == intersects_closest bit for bit, at every alignment of the row range"""
+    import triro.backend.ops as hops
+    from triro.ray.ray_optix import RayMeshIntersector
+    v, f = W.headline_mesh(5)
+    r = RayMeshIntersector(vertices=torch.from_numpy(v).to(device), faces=torch.from_numpy(f).to(device))
+    rad = float(np.linalg.norm(v, axis=1).max())
+    o_np, d_np = W.pinhole_grid(203, 101, distance=2.5 * rad)          # 20 503 rays: not a multiple of 4
+    o = torch.from_numpy(np.ascontiguousarray(o_np)).to(device).reshape(-1, 3)
+    d = torch.from_numpy(d_np).to(device).reshape(-1, 3)
+    n = o.shape[0]
+    exp = r.intersects_closest(o, d)
+    packed = r.intersects_closest_packed(o, d)
+    assert 0.2 < float(exp[0].float().mean()) < 0.95
+    try:
+        for opt in (1, 0):
+            hops.set_option("expand4", opt)
+            got = r.closest_expand(packed)
+            for a, e in zip(got, exp):
+                assert torch.equal(a, e), opt
+            # row ranges at every alignment, into slices of full-size outputs (what the destination rank does)
+            for lo in (0, 1, 2, 3, 4, 1001):
+                for hi in (n, n - 1, n - 2, n - 3, lo + 5, lo + 4):
+                    outs = (torch.zeros(n, dtype=torch.bool, device=device), torch.zeros(n, dtype=torch.bool, device=device),
+                            torch.full((n,), -7, dtype=torch.int32, device=device), torch.full((n, 3), 9.0, device=device),
+                            torch.full((n, 2), 9.0, device=device))
+                    r.closest_expand(packed[lo:hi], outs=tuple(x[lo:hi] for x in outs))
+                    for a, e in zip(outs, exp):
+                        assert torch.equal(a[lo:hi], e[lo:hi]), (opt, lo, hi)
+                    # nothing outside the range was written
+                    assert int((outs[2][:lo] != -7).sum()) == 0 and int((outs[2][hi:] != -7).sum()) == 0
+                    assert float((outs[3][:lo] != 9.0).sum()) == 0 and float((outs[3][hi:] != 9.0).sum()) == 0
+    finally:
+        hops.set_option("expand4", 1)
+    # records that point outside the mesh (corrupt input) are misses, never out-of-bounds reads
+    bad = packed.clone()
+    bad[::7, 0] = 0x3fffffff
+    hit = r.closest_expand(bad)[0]
+    assert not bool(hit[::7].any())
+
+
+def test_destination_traces_dense_in_place(device):
+    """intersects_closest_into: rows of preallocated full-size outputs == the ordinary call"""
+    from triro.ray.ray_optix import RayMeshIntersector
+    v, f = W.headline_mesh(4)
+    r = RayMeshIntersector(vertices=torch.from_numpy(v).to(device), faces=torch.from_numpy(f).to(device))
+    o_np, d_np = W.pinhole_grid(64, 48, distance=2.5 * float(np.linalg.norm(v, axis=1).max()))
+    o, d = torch.from_numpy(np.ascontiguousarray(o_np)).to(device), torch.from_numpy(d_np).to(device)
+    exp = [x.reshape(64 * 48, *x.shape[2:]) for x in r.intersects_closest(o, d)]
+    n = 64 * 48
+    outs = (torch.zeros(n, dtype=torch.bool, device=device), torch.zeros(n, dtype=torch.bool, device=device),
+            torch.zeros(n, dtype=torch.int32, device=device), torch.zeros((n, 3), device=device), torch.zeros((n, 2), device=device))
+    r.intersects_closest_into(o[:16], d[:16], tuple(x[:16 * 64] for x in outs))
+    r.intersects_closest_into(o[16:], d[16:], tuple(x[16 * 64:] for x in outs))
+    for a, e in zip(outs, exp):
+        assert torch.equal(a, e)
+    with pytest.raises(ValueError):
+        r.intersects_closest_into(o[:16], d[:16], tuple(x[:5] for x in outs))
+
+
+def test_async_closest_without_collectives_orders_the_side_stream(device):
+    """closest_of_shard_async called directly with world == 1 and no forced collectives -- the
+    expansion on the side stream must run behind the trace on the caller's stream (round 3 waited on itself)"""
+    from triro.ray.ray_optix import RayMeshIntersector
+    from triro.ray.sharded import ShardedRayMeshIntersector
+    v, f = W.headline_mesh(7)
+    r = RayMeshIntersector(vertices=torch.from_numpy(v).to(device), faces=torch.from_numpy(f).to(device))
+    o_np, d_np = W.pinhole_grid(1024, 512, distance=2.5 * float(np.linalg.norm(v, axis=1).max()))
+    o, d = torch.from_numpy(np.ascontiguousarray(o_np)).to(device), torch.from_numpy(d_np).to(device)
+    exp = r.intersects_closest(o, d)
+    S = ShardedRayMeshIntersector(r)
+    assert S.world == 1 and not S.force_collectives
+
+    class PackedOnly:      # a tracer without the dense in-place call: the destination packs and expands its own rows
+        def __init__(self, inner):
+            self.inner = inner
+            self.intersects_closest_packed = inner.intersects_closest_packed
+            self.closest_expand = inner.closest_expand
+            self.intersects_closest = inner.intersects_closest
+    for local in (r, PackedOnly(r)):
+        S.local = local
+        for k in range(6):
+            # a long kernel in front of the trace on the caller's stream: an expansion that does not wait starts early
+            junk = torch.randn(4096, 4096, device=device) @ torch.randn(4096, 4096, device=device)
+            got = S.closest_of_shard_async(o, d, o.shape[0] * o.shape[1], batch_shape=o.shape[:2], dst=0, chunks=1 + k % 3).wait()
+            torch.cuda.synchronize()
+            for a, e in zip(got, exp):
+                assert torch.equal(a, e), (type(local).__name__, k)
+            del junk

@@ -85,6 +85,22 @@ class CpuLocal:
         return self._t(*self.R.intersects_location(o.numpy(), d.numpy()))
 
 
+class CpuLocalInto(CpuLocal):
+    """... with the destination rank's dense in-place trace (RayMeshIntersector.intersects_closest_into)"""
+
+    def __init__(self, v, f):
+        super().__init__(v, f)
+        self.into_calls = []
+
+    def intersects_closest_into(self, o, d, outs):
+        self.into_calls.append((o.numel() // 3, tuple(o.shape)))
+        res = self.closest_expand(CpuLocal.intersects_closest_packed(self, o, d))
+        self.packed_calls.pop()
+        for dst_, src_ in zip(outs, res):
+            dst_.copy_(src_.reshape(dst_.shape))
+        return outs
+
+
 def _worker(rank, world, port, q):
     for p in (ROOT, os.path.join(ROOT, "trimesh-ray-optix_amd")):
         if p not in sys.path:
@@ -209,6 +225,45 @@ def _worker(rank, world, port, q):
         if rank == 0:
             for a, e in zip(g4, exp):
                 ok &= torch.equal(a.reshape(e.shape), e)
+        # ---- round 4: the destination traces dense in place, weighted shards, host staging ---------------
+        from triro.ray.sharded import weighted_bounds, auto_dst_share
+        for stage in (False, True):          # True: every exchange through the host-staging transport (gloo + device tensors)
+            for share in (None, 0.5, 0.0):
+                D = ShardedRayMeshIntersector(CpuLocalInto(v, f), dst_share=share, stage_through_host=stage or None)
+                for dst_, ch in ((0, 3), (1, 1), (None, 2)):
+                    D.local.into_calls.clear(); D.local.packed_calls.clear()
+                    g6 = D.intersects_closest(o, d, dst=dst_, chunks=ch)
+                    bb = D.bounds(851, dst_, 37, weighted=True)
+                    if share == 0.5 and dst_ is not None:
+                        ok &= bb == weighted_bounds(851, [0.5 if r == dst_ else 1.0 for r in range(world)], 37)
+                        ok &= (bb[dst_][1] - bb[dst_][0]) < (bb[1 - dst_][1] - bb[1 - dst_][0])
+                    if dst_ is None or dst_ == rank:
+                        for a, e in zip(g6, exp):
+                            ok &= torch.equal(a.reshape(e.shape), e)
+                    else:
+                        ok &= g6 is None
+                    mine_rays = bb[rank][1] - bb[rank][0]
+                    if dst_ == rank:       # dense in place, nothing packed on the destination
+                        ok &= sum(c[0] for c in D.local.into_calls) == mine_rays and not D.local.packed_calls
+                    else:
+                        ok &= sum(c[0] for c in D.local.packed_calls) == mine_rays and not D.local.into_calls
+                # image batch, weighted shards cut at row boundaries: both ranks keep the image shape
+                g7 = D.intersects_closest(o3, d3, dst=0, chunks=2)
+                if share == 0.5:
+                    ok &= all(lo_ % 37 == 0 and hi_ % 37 == 0 for lo_, hi_ in D.bounds(37 * 24, 0, 37, weighted=True))
+                if rank == 0:
+                    for a, e in zip(g7, e3):
+                        ok &= torch.equal(a, e)
+                # the other queries through the same transport
+                ok &= torch.equal(D.intersects_count(o, d, dst=None).reshape(-1), ref.intersects_count(fo, fd))
+                l8 = D.intersects_location(o, d, dst=1)
+                if rank == 1:
+                    for a, e in zip(l8, ref.intersects_location(fo, fd)):
+                        ok &= torch.equal(a, e)
+                c8 = D.intersects_closest(o, d, stream_compaction=True, dst=None)
+                for a, e in zip(c8, ref.intersects_closest(fo, fd, stream_compaction=True)):
+                    ok &= torch.equal(a.reshape(e.shape), e)
+        ok &= 0.0 < auto_dst_share(8) < 1.0 and auto_dst_share(1) == 1.0
         # round 1's padded exchange stays selectable (fallback until the in-place path has run on RCCL)
         Q = ShardedRayMeshIntersector(CpuLocal(v, f), gather_mode="padded")
         g5 = Q.intersects_closest(o, d, dst=0)
@@ -235,6 +290,20 @@ def test_sharded_world2_gloo():
     for p in procs:
         p.join(60)
     assert res == {0: True, 1: True}
+
+
+def test_weighted_bounds():
+    from triro.ray.sharded import weighted_bounds
+    for n in (0, 1, 7, 1000, 1024 * 1024, 100_000_000):
+        for w in ([1, 1], [0.5, 1, 1, 1], [0.0, 1, 1], [1, 1, 1, 1, 1, 1, 1, 0.52]):
+            for q in (1, 8, 1024):
+                ch = weighted_bounds(n, w, q)
+                assert ch[0][0] == 0 and ch[-1][1] == n and all(ch[i][1] == ch[i + 1][0] for i in range(len(w) - 1))
+                assert all(hi >= lo for lo, hi in ch)
+                if n % q == 0:
+                    assert all(lo % q == 0 for lo, _ in ch)
+    ch = weighted_bounds(800, [0.5, 1, 1, 1], 1)
+    assert abs((ch[0][1] - ch[0][0]) - 800 * 0.5 / 3.5) <= 1
 
 
 def test_shard_bounds():

@@ -48,6 +48,7 @@ const opt_desc OPTS[] = {
     {"lds_top", &tr_options::lds_top, 0, 2, false},
     {"occ8", &tr_options::occ8, 0, 2, false},
     {"split_floor", &tr_options::split_floor, 0, 100000, false},
+    {"expand4", &tr_options::expand4, 0, 1, true},
 };
 constexpr int NUM_OPTS = (int)(sizeof(OPTS) / sizeof(OPTS[0]));
 struct opt_store {

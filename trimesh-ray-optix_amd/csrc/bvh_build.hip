@@ -497,6 +497,9 @@ int tr_top_table_update(tr_bvh* bvh, hipStream_t stream) {
     if (!bvh->top_table) TR_HIP_TRY(hipMalloc((void**)&bvh->top_table, sizeof(tr_qnode) * TR_TOP_SLOTS));
     hipLaunchKernelGGL(k_top_table, dim3(1), dim3(TR_TOP_SLOTS), 0, stream, bvh->qnodes, bvh->num_nodes, bvh->top_table);
     TR_HIP_TRY(hipGetLastError());
+    // build / refit / load return with ALL data of the handle complete: a query on another stream may start at
+    // once, and with lds_top it copies this table (a 128-thread kernel behind an already drained stream)
+    TR_HIP_TRY(hipStreamSynchronize(stream));
     return TR_OK;
 }
 

@@ -101,16 +101,40 @@ TR_HD uint32_t tr_qestimate(float x, float scale, float base) {
     const float e = (x - base) / scale;          // scale is a power of two: the division is exact
     return !(e > 0.f) ? 0u : (e >= 65535.f ? 65535u : (uint32_t)e);
 }
+// (the walk is bounded: where ulp(base) >> scale -- a mesh far from the origin relative to its extent, a
+// degenerate axis -- thousands of consecutive q decode to the same float and a linear walk would take up to
+// 65535 steps per plane, 12 planes per node; after 4 steps the binary search of round 2 takes over.  Same
+// result: the largest q with decode(q) <= lo / the smallest with decode(q) >= hi, decode being monotone.)
 TR_HD uint32_t tr_qfloor(float lo, float scale, float base) {
     uint32_t q = tr_qestimate(lo, scale, base);
-    while (q > 0u && !(tr_qdecode(q, scale, base) <= lo)) q--;
-    while (q < 65535u && tr_qdecode(q + 1u, scale, base) <= lo) q++;
+    int steps = 0;
+    while (q > 0u && !(tr_qdecode(q, scale, base) <= lo) && steps < 4) { q--; steps++; }
+    while (q < 65535u && tr_qdecode(q + 1u, scale, base) <= lo && steps < 4) { q++; steps++; }
+    if (steps >= 4) {
+        // largest q in [0, 65535] with decode(q) <= lo (decode(0) = base <= lo by construction; NaN: 0)
+        uint32_t a = 0u, z = 65535u;
+        while (a < z) {
+            const uint32_t m = (a + z + 1u) >> 1;
+            if (tr_qdecode(m, scale, base) <= lo) a = m; else z = m - 1u;
+        }
+        q = a;
+    }
     return q;
 }
 TR_HD uint32_t tr_qceil(float hi, float scale, float base) {
     uint32_t q = tr_qestimate(hi, scale, base);
-    while (q < 65535u && !(tr_qdecode(q, scale, base) >= hi)) q++;
-    while (q > 0u && tr_qdecode(q - 1u, scale, base) >= hi) q--;
+    int steps = 0;
+    while (q < 65535u && !(tr_qdecode(q, scale, base) >= hi) && steps < 4) { q++; steps++; }
+    while (q > 0u && tr_qdecode(q - 1u, scale, base) >= hi && steps < 4) { q--; steps++; }
+    if (steps >= 4) {
+        // smallest q in [0, 65535] with decode(q) >= hi (decode(65535) >= hi by construction; NaN: 65535)
+        uint32_t a = 0u, z = 65535u;
+        while (a < z) {
+            const uint32_t m = (a + z) >> 1;
+            if (tr_qdecode(m, scale, base) >= hi) z = m; else a = m + 1u;
+        }
+        q = a;
+    }
     return q;
 }
 // Child boxes as 16-bit pairs {lo.x, lo.y | lo.z, hi.z | hi.x, hi.y} (low half first): every pair

@@ -170,6 +170,7 @@ struct tr_options {
     int leaf_vote = 32;   // unordered schedule: lanes with a queued leaf that fire a leaf phase
     int occ8 = 1;         // stealing closest / first launches on the grid nodes at 8 waves per SIMD (64 registers, slim hand-over scratch): 0 never, 1 from 2 M rays on, 2 always
     int lds_top = 0;      // LDS-staged node packets for closest / first launches that steal: 0 off, 1 at 128-thread blocks, 2 at 256-thread blocks
+    int expand4 = 1;      // tr_closest_expand: four rays per thread with 16-byte accesses where the rows are aligned (0: one ray per thread)
     int usteal = 1;       // unordered count launches hand owed subtrees over between lanes and use split launch slots: 0 off, 1 on, >= 2 forced trip threshold
 };
 tr_options tr_opts();   // snapshot by value

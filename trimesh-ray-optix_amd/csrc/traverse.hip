@@ -833,13 +833,13 @@ __global__ __launch_bounds__(BS) void k_query_direct(tr_bvh_view b, RayFetch rf,
 // slim hand-over, wave_traverse_steal<..., SLIM>).  Pays where the launch is large -- 4 M rays -3.8 % --
 // and costs where it is small or the waves share lines (262 k ... 590 k rays +1...+8 %, C2 / C4 / interior on
 // forced grid nodes +4...+6 %: profiles/r03_ab_occ8.txt).  Option occ8: 0 never, 1 from 2 M rays on, 2 always.
-template <int Q, bool DEEP>
+template <int Q>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void k_query_direct_occ8(tr_bvh_view b, RayFetch rf, QueryOut out, int xcd_map, int scramble, int tile_w, int steal_min,
                          const uint32_t* __restrict__ order, int order_split, uint32_t* __restrict__ cost,
                          unsigned long long* stats, const int* __restrict__ sel) {
-    query_direct_body<Q, false, true, 128, 1, DEEP, true, false, true>(b, rf, out, xcd_map, scramble, tile_w, steal_min, order,
-                                                                       order_split, cost, stats, sel);
+    query_direct_body<Q, false, true, 128, 1, false, true, false, true>(b, rf, out, xcd_map, scramble, tile_w, steal_min, order,
+                                                                        order_split, cost, stats, sel);
 }
 
 // Order the blocks of the last launch by measured cost, most expensive first: one workgroup,
@@ -849,7 +849,12 @@ void k_query_direct_occ8(tr_bvh_view b, RayFetch rf, QueryOut out, int xcd_map, 
 __global__ __launch_bounds__(1024) void k_sched_sort(uint32_t* __restrict__ cost,
                                                       uint32_t* __restrict__ order, int nblocks,
                                                       int xcd_map, int split, int split4,
-                                                      int outlier8, int floor_ticks) {
+                                                      int outlier8, int floor_ticks,
+                                                      const int* __restrict__ sel) {
+    // dual launch (k_probe_coherence): the direct launch whose costs this would sort returned at its first
+    // instruction -- nothing was measured, the order (if any) stays as it is (round 3 sorted an all-zero cost
+    // array of 97 656 blocks behind every streamed 12.5 M-ray launch: 215 us of serial work per call)
+    if (sel && *sel != 0) return;
     // list x: blocks whose home in the XCD-chunked map is XCD x (see k_query_direct; the blocks
     // past the last whole span are dealt round-robin there, so their home is i % 8).  Launch
     // slot j*8+x runs on XCD x, so list x fills the slots of XCD x in cost order: expensive
@@ -1024,12 +1029,12 @@ __global__ __launch_bounds__(256) void k_probe_coherence(RayFetch rf, float scen
 #ifndef TR_STREAM_OCC
 #define TR_STREAM_OCC __attribute__((amdgpu_waves_per_eu(8, 8)))
 #endif
-template <int Q, bool STATS, bool COMPACT, int BS, bool DEEP = false>
-__global__ __launch_bounds__(BS) TR_STREAM_OCC void k_query_stream(tr_bvh_view b, RayFetch rf, QueryOut out,
-                                                     int rays_per_wave, int refill_min, int xcd_map,
-                                                     unsigned long long* stats,
-                                                     const int* __restrict__ sel,
-                                                     unsigned long long* work) {
+template <int Q, bool STATS, bool COMPACT, int BS, bool DEEP>
+__device__ __forceinline__ void query_stream_body(const tr_bvh_view& b, const RayFetch& rf, const QueryOut& out,
+                                                  int rays_per_wave, int refill_min, int xcd_map,
+                                                  unsigned long long* stats,
+                                                  const int* __restrict__ sel,
+                                                  unsigned long long* work) {
     if (sel && *sel != 1) return;      // dual launch: this is the shape for incoherent batches (id 1)
 #ifdef TR_TIMELINE
     const unsigned long long tl_start = wall_clock64();
@@ -1144,6 +1149,24 @@ __global__ __launch_bounds__(BS) TR_STREAM_OCC void k_query_stream(tr_bvh_view b
     }
 #endif
     flush_stats<STATS>(cnt, stats);
+}
+// 8 waves per SIMD are asked for only where the kernel was measured to fit 64 registers without a spill: the
+// compact instantiations (32-bit offsets and trail words) without counters.  The deep / 64-bit / instrumented
+// ones keep the compiler's own register budget (round 3 forced 64 registers on all of them: 1-2 spilled
+// registers and scratch traffic in the inner loop for every mesh of more than 32 levels).
+template <int Q, bool STATS, bool COMPACT, int BS, bool DEEP = false>
+__global__ __launch_bounds__(BS) void k_query_stream(tr_bvh_view b, RayFetch rf, QueryOut out,
+                                                     int rays_per_wave, int refill_min, int xcd_map,
+                                                     unsigned long long* stats, const int* __restrict__ sel,
+                                                     unsigned long long* work) {
+    query_stream_body<Q, STATS, COMPACT, BS, DEEP>(b, rf, out, rays_per_wave, refill_min, xcd_map, stats, sel, work);
+}
+template <int Q>
+__global__ __launch_bounds__(128) TR_STREAM_OCC void k_query_stream_occ8(tr_bvh_view b, RayFetch rf, QueryOut out,
+                                                     int rays_per_wave, int refill_min, int xcd_map,
+                                                     unsigned long long* stats, const int* __restrict__ sel,
+                                                     unsigned long long* work) {
+    query_stream_body<Q, false, true, 128, false>(b, rf, out, rays_per_wave, refill_min, xcd_map, stats, sel, work);
 }
 
 // ---- multi-hit second pass (shaders.cu:196-246) ----------------------------------------------
@@ -1367,6 +1390,72 @@ __global__ __launch_bounds__(256) void k_closest_expand(const tr_packed_hit* __r
     if (tri) tri[i] = t;
     if (loc) { loc[3 * i] = l3[0]; loc[3 * i + 1] = l3[1]; loc[3 * i + 2] = l3[2]; }
     if (uv) { uv[2 * i] = u2[0]; uv[2 * i + 1] = u2[1]; }
+}
+
+// Four rays per thread, every global access 16 bytes wide (round 4).  The destination rank of a ray-sharded
+// run expands the records of ALL its peers (7 x the rays it traces itself at 8 GPUs) beside its own trace, so
+// this kernel has to run near the memory system's rate: 48 B of records in, 104 B of outputs per thread as
+// dword / dwordx4 stores (the scalar kernel above issues 1-byte and 12-byte-strided stores), streamed with
+// non-temporal hints (neither the records nor the outputs are touched again by this launch, and the trace
+// running next to it lives on what the L2s hold of the hierarchy); only the face / vertex gathers stay
+// scalar (12-byte rows).  Needs n % 4 == 0 and 16-byte aligned rows (the host launches the scalar kernel for
+// whatever does not fit); same arithmetic (tr_bary_outputs), same bits.
+typedef uint32_t tr_u4 __attribute__((ext_vector_type(4)));
+typedef float tr_fl4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_closest_expand4(const tr_u4* __restrict__ packed4, int64_t n4,
+                                                         const float* __restrict__ verts, int64_t nv,
+                                                         const int32_t* __restrict__ faces, int64_t nf,
+                                                         uint32_t* __restrict__ hit4, uint32_t* __restrict__ front4,
+                                                         tr_u4* __restrict__ tri4, tr_fl4* __restrict__ loc4,
+                                                         tr_fl4* __restrict__ uv4) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= n4) return;
+    const tr_u4 p0 = __builtin_nontemporal_load(packed4 + 3 * g);
+    const tr_u4 p1 = __builtin_nontemporal_load(packed4 + 3 * g + 1);
+    const tr_u4 p2 = __builtin_nontemporal_load(packed4 + 3 * g + 2);
+    const uint32_t w[12] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w};
+    float l[12], u[8];
+    uint32_t hm = 0, fm = 0;
+    int32_t t[4];
+    // the four face rows first, then the twelve vertex rows: the gathers of a thread are in flight together
+    int32_t vi[12];
+    bool ok[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t tri = w[3 * k], face = tri & 0x3fffffffu;
+        ok[k] = !(tri & 0x80000000u) && (int64_t)face < nf;
+        const int32_t* fp = faces + 3 * (int64_t)(ok[k] ? face : 0u);
+        vi[3 * k] = nf > 0 ? fp[0] : 0; vi[3 * k + 1] = nf > 0 ? fp[1] : 0; vi[3 * k + 2] = nf > 0 ? fp[2] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int32_t i0 = vi[3 * k], i1 = vi[3 * k + 1], i2 = vi[3 * k + 2];
+        ok[k] = ok[k] && (uint32_t)i0 < (uint64_t)nv && (uint32_t)i1 < (uint64_t)nv && (uint32_t)i2 < (uint64_t)nv;
+        float l3[3] = {0.f, 0.f, 0.f}, u2[2] = {0.f, 0.f};
+        t[k] = -1;
+        if (ok[k]) {
+            const float* a = verts + 3 * (int64_t)i0; const float* b = verts + 3 * (int64_t)i1; const float* c = verts + 3 * (int64_t)i2;
+            tr_bary_outputs(__uint_as_float(w[3 * k + 1]), __uint_as_float(w[3 * k + 2]), a[0], a[1], a[2], b[0], b[1], b[2],
+                            c[0], c[1], c[2], l3, u2);
+            hm |= 1u << (8 * k);
+            fm |= ((w[3 * k] >> 30) & 1u) << (8 * k);
+            t[k] = (int32_t)(w[3 * k] & 0x3fffffffu);
+        }
+        l[3 * k] = l3[0]; l[3 * k + 1] = l3[1]; l[3 * k + 2] = l3[2];
+        u[2 * k] = u2[0]; u[2 * k + 1] = u2[1];
+    }
+    if (hit4) __builtin_nontemporal_store(hm, hit4 + g);
+    if (front4) __builtin_nontemporal_store(fm, front4 + g);
+    if (tri4) __builtin_nontemporal_store(tr_u4{(uint32_t)t[0], (uint32_t)t[1], (uint32_t)t[2], (uint32_t)t[3]}, tri4 + g);
+    if (loc4) {
+        __builtin_nontemporal_store(tr_fl4{l[0], l[1], l[2], l[3]}, loc4 + 3 * g);
+        __builtin_nontemporal_store(tr_fl4{l[4], l[5], l[6], l[7]}, loc4 + 3 * g + 1);
+        __builtin_nontemporal_store(tr_fl4{l[8], l[9], l[10], l[11]}, loc4 + 3 * g + 2);
+    }
+    if (uv4) {
+        __builtin_nontemporal_store(tr_fl4{u[0], u[1], u[2], u[3]}, uv4 + 2 * g);
+        __builtin_nontemporal_store(tr_fl4{u[4], u[5], u[6], u[7]}, uv4 + 2 * g + 1);
+    }
 }
 
 // ---- host side ----------------------------------------------------------------------------------
@@ -1650,7 +1739,10 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
                     if (grid > resident) grid = resident;
                     sxc = 0;
                 }
-                if (compact)
+                if (compact && !STATS)
+                    hipLaunchKernelGGL((k_query_stream_occ8<Q>), dim3(grid), dim3(128), 0, stream,
+                                       view, rf, out, rpw, opt.stream_refill, sxc, d_stats, sel, work);
+                else if (compact)
                     hipLaunchKernelGGL((k_query_stream<Q, STATS, true, 128>), dim3(grid), dim3(128), 0, stream,
                                        view, rf, out, rpw, opt.stream_refill, sxc, d_stats, sel, work);
                 else if (addr32)
@@ -1837,13 +1929,11 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
                 }
             }
             if constexpr (Q == TR_Q_CLOSEST || Q == TR_Q_FIRST) {
-                if (!steal_launched && qn && (opt.occ8 == 2 || (opt.occ8 == 1 && rf.n >= ((int64_t)1 << 21))) && (compact || deep) && bs == 128) {
-                    if (compact)
-                        hipLaunchKernelGGL((k_query_direct_occ8<Q, false>), dim3((unsigned)nslots), dim3(128), 0, stream,
-                                           view, rf, out, xc, scramble, tile_w, steal_arg, order, (int)split_key, cost, d_stats, sel);
-                    else
-                        hipLaunchKernelGGL((k_query_direct_occ8<Q, true>), dim3((unsigned)nslots), dim3(128), 0, stream,
-                                           view, rf, out, xc, scramble, tile_w, steal_arg, order, (int)split_key, cost, d_stats, sel);
+                // (8 waves per SIMD only for the compact instantiation: with 64-bit trail words -- hierarchies deeper
+                // than 32 levels -- the kernel does not fit 64 registers without spilling; those run at 7 waves)
+                if (!steal_launched && qn && (opt.occ8 == 2 || (opt.occ8 == 1 && rf.n >= ((int64_t)1 << 21))) && compact && bs == 128) {
+                    hipLaunchKernelGGL((k_query_direct_occ8<Q>), dim3((unsigned)nslots), dim3(128), 0, stream,
+                                       view, rf, out, xc, scramble, tile_w, steal_arg, order, (int)split_key, cost, d_stats, sel);
                     steal_launched = true;
                 }
                 if (steal_launched) {
@@ -1875,7 +1965,7 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
         if (gn_after) (void)hipEventRecord(gn_after, stream);      // brackets the query kernel only
         if (cost)
             hipLaunchKernelGGL(k_sched_sort, dim3(1), dim3(1024), 0, stream, cost, cost + TR_SCHED_MAX,
-                               (int)nblocks_direct, xc, (int)split, (int)split4, outlier8, opt.split_floor * 100);
+                               (int)nblocks_direct, xc, (int)split, (int)split4, outlier8, opt.split_floor * 100, sel);
         if (!STATS && bvh->sched_mutex) {
             tr_bvh* mb = const_cast<tr_bvh*>(bvh);
             std::lock_guard<std::mutex> lock(*mb->sched_mutex);
@@ -1976,8 +2066,22 @@ int tr_closest_expand(const tr_packed_hit* d_packed, int64_t n, const float* d_v
     if (n == 0) return TR_OK;
     if (!d_packed) return tr_fail(TR_ERR_INVALID_ARG, "d_packed == NULL");
     if (nf > 0 && (!d_vertices || !d_faces)) return tr_fail(TR_ERR_INVALID_ARG, "null mesh pointer");
-    hipLaunchKernelGGL(k_closest_expand, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       d_packed, n, d_vertices, nv, d_faces, nf, d_hit, d_front, d_tri, d_loc, d_uv);
+    // the body in groups of four rays with 16-byte accesses (k_closest_expand4) when every row pointer is
+    // 16-byte aligned (rows of full-size outputs at multiples of four rays are); the rest one ray per thread
+    const uintptr_t align_bits = (uintptr_t)d_packed | (uintptr_t)d_tri | (uintptr_t)d_loc | (uintptr_t)d_uv |
+                                 (((uintptr_t)d_hit | (uintptr_t)d_front) << 2);
+    const int64_t n4 = (align_bits & 15) == 0 && tr_opts().expand4 ? n / 4 : 0;
+    if (n4 > 0)
+        hipLaunchKernelGGL(k_closest_expand4, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const tr_u4*>(d_packed), n4, d_vertices, nv, d_faces, nf,
+                           reinterpret_cast<uint32_t*>(d_hit), reinterpret_cast<uint32_t*>(d_front),
+                           reinterpret_cast<tr_u4*>(d_tri), reinterpret_cast<tr_fl4*>(d_loc), reinterpret_cast<tr_fl4*>(d_uv));
+    const int64_t done = 4 * n4, rest = n - done;
+    if (rest > 0)
+        hipLaunchKernelGGL(k_closest_expand, dim3((unsigned)((rest + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           d_packed + done, rest, d_vertices, nv, d_faces, nf, d_hit ? d_hit + done : nullptr,
+                           d_front ? d_front + done : nullptr, d_tri ? d_tri + done : nullptr,
+                           d_loc ? d_loc + 3 * done : nullptr, d_uv ? d_uv + 2 * done : nullptr);
     TR_HIP_TRY(hipGetLastError());
     return TR_OK;
 }

@@ -236,15 +236,25 @@ def intersects_first(accel_structure, origins, dirs) -> torch.Tensor:
     return out
 
 
-def intersects_closest(accel_structure, origins, dirs) -> Tuple[torch.Tensor, ...]:
-    """ops.py:122-149 / ray.cpp:231-289.  (hit, front, tri_idx, loc, uv)."""
+def intersects_closest(accel_structure, origins, dirs, outs=None) -> Tuple[torch.Tensor, ...]:
+    """ops.py:122-149 / ray.cpp:231-289.  (hit, front, tri_idx, loc, uv).  `outs`: optional preallocated
+    contiguous destinations (bool [n], bool [n], int32 [n], float32 [n, 3], float32 [n, 2] with n = the
+    number of rays -- e.g. this rank's rows of gathered full-size outputs, triro.ray.sharded)."""
     check_rays(origins, dirs)
     b, dev = origins.shape[:-1], origins.device
-    hit = torch.empty(b, dtype=torch.bool, device=dev)
-    front = torch.empty(b, dtype=torch.bool, device=dev)
-    tri = torch.empty(b, dtype=torch.int32, device=dev)
-    loc = torch.empty((*b, 3), dtype=torch.float32, device=dev)
-    uv = torch.empty((*b, 2), dtype=torch.float32, device=dev)
+    if outs is not None:
+        n = origins.numel() // 3
+        want = ((torch.bool, (n,)), (torch.bool, (n,)), (torch.int32, (n,)), (torch.float32, (n, 3)), (torch.float32, (n, 2)))
+        if len(outs) != 5 or any(t.dtype != dt or tuple(t.shape) != sh or not t.is_contiguous() or t.device != dev
+                                 for t, (dt, sh) in zip(outs, want)):
+            raise ValueError("outs must be contiguous (bool[n], bool[n], int32[n], float32[n,3], float32[n,2]) on the rays' device")
+        hit, front, tri, loc, uv = outs
+    else:
+        hit = torch.empty(b, dtype=torch.bool, device=dev)
+        front = torch.empty(b, dtype=torch.bool, device=dev)
+        tri = torch.empty(b, dtype=torch.int32, device=dev)
+        loc = torch.empty((*b, 3), dtype=torch.float32, device=dev)
+        uv = torch.empty((*b, 2), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _check(get_module().tr_intersects_closest(
             _handle(accel_structure, origins), C.byref(make_rays(origins, dirs)), hit.data_ptr(), front.data_ptr(),

@@ -110,6 +110,12 @@ class RayMeshIntersector:
             return hit, front_c, ray_idx, tri_c, loc_c, uv_c
         return hit, front, tri_idx, loc, uv
 
+    def intersects_closest_into(self, origins, directions, outs):
+        """intersects_closest (stream_compaction=False) into preallocated flat outputs (bool [n], bool [n],
+        int32 [n], float32 [n, 3], float32 [n, 2]): the destination rank of a ray-sharded gather traces
+        straight into its rows of the full-size results (triro.ray.sharded; not in the reference)."""
+        return hops.intersects_closest(self.as_wrapper, origins, directions, outs=outs)
+
     def intersects_closest_packed(self, origins, directions, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Closest hit as int32 [n, 3] rows {tri_idx | front << 30 (-1: miss), u bits, v bits}: 12 bytes
         per ray (not in the reference; what a ray-sharded run sends over xGMI, triro.ray.sharded)."""

@@ -26,6 +26,17 @@ stand-in so the sharding logic runs under gloo without a GPU).  The packed pipel
 TRIRO_SHARDED_GATHER=dense, closest hits take the per-output exchange of the other queries;
 TRIRO_SHARDED_GATHER=padded selects round 1's padded-buffer gather for every exchange (kept as a
 fallback until the receive-into-place path has run on a multi-GPU RCCL node).
+
+Round 4:
+  * the destination rank of a closest-hit gather traces its own shard straight into its rows of the
+    dense outputs (`intersects_closest_into`) and expands only the peers' records;
+  * `dst_share`: the destination rank takes a smaller shard (it also expands everybody else's
+    records): `weighted_bounds`, `auto_dst_share`;
+  * device tensors under the gloo backend travel through the host (`_exchange` stages them): two
+    ranks can share ONE GPU and run the real tracer through every branch of this module -- a
+    functional check, never a measurement;
+  * `EmulatedWorld`: the destination rank's side of an N-rank gather on one GPU (the peers' records
+    are traced beforehand and arrive as device copies on a copy stream), for bench.py --emulate-world.
 """
 from __future__ import annotations
 
@@ -43,6 +54,66 @@ def shard_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def weighted_bounds(n: int, weights: Sequence[float], quantum: int = 1) -> List[Tuple[int, int]]:
+    """Contiguous chunks of [0, n) in proportion to `weights`, cut at multiples of `quantum` rays
+    (an image batch: whole rows) when n is a multiple of it.  Pure function of its arguments: every
+    rank computes everybody's bounds."""
+    world = len(weights)
+    if quantum < 1 or n % quantum:
+        quantum = 1
+    units = n // quantum
+    tot = float(sum(weights))
+    edges, acc = [0], 0.0
+    for r in range(world):
+        acc += float(weights[r])
+        e = units if r == world - 1 else int(round(units * acc / tot)) if tot > 0 else 0
+        edges.append(max(edges[-1], min(units, e)))
+    return [(edges[r] * quantum, edges[r + 1] * quantum) for r in range(world)]
+
+
+def auto_dst_share(world: int, rho: float = 0.07) -> float:
+    """Share of an EVEN shard the destination rank of a packed closest-hit gather should trace so that
+    all ranks finish together: the destination spends rho x (a ray's trace time) on every ray somebody
+    else traced (receive + expansion), so with s = its fraction of the batch
+        s + rho (1 - s) = (1 - s) / (world - 1).
+    rho = 0.07: 10 us of expansion against 137 us of tracing per million incoherent rays on the headline
+    mesh.  Returns s x world (1.0 = an even shard)."""
+    if world < 2:
+        return 1.0
+    inv = 1.0 / (world - 1)
+    s = max(0.0, (inv - rho) / (1.0 + inv - rho))
+    return min(1.0, s * world)
+
+
+class _EventWork:
+    """work handle of an exchange that is stream work on ANOTHER stream: wait() orders the current
+    stream behind it (the contract of an asynchronous RCCL work handle)."""
+
+    def __init__(self, event, device):
+        self._event, self._device = event, device
+
+    def wait(self):
+        torch.cuda.current_stream(self._device).wait_event(self._event)
+        return True
+
+
+class _StagedWork:
+    """work handle of a host-staged exchange (device tensors under gloo): wait() completes the CPU
+    collective and enqueues the host -> device copies of the received rows on the CURRENT stream."""
+
+    def __init__(self, works, copies):
+        self._works, self._copies = list(works), list(copies)
+
+    def wait(self):
+        for w in self._works:
+            w.wait()
+        self._works = []
+        for dst_view, host in self._copies:
+            dst_view.copy_(host)
+        self._copies = []
+        return True
+
+
 def default_chunks(rays_per_rank: int) -> int:
     """Chunks per shard of the packed closest-hit pipeline: at least ~3 M rays each (smaller launches
     lose the streaming launch's efficiency), at most 8."""
@@ -54,15 +125,16 @@ class PendingClosest:
     wait(): makes the caller's current stream wait for the gather + expansion and returns
     (hit, front, tri, loc, uv) on the destination rank(s), None elsewhere."""
 
-    def __init__(self, outputs, event=None, works=(), keep=()):
+    def __init__(self, outputs, event=None, works=(), keep=(), device=None):
         self._outputs, self._event, self._works, self._keep = outputs, event, list(works), keep
+        self._device = device
 
     def wait(self):
         for w in self._works:      # CPU (gloo) path and non-destination ranks: plain completion
             w.wait()
         self._works = []
         if self._event is not None:
-            torch.cuda.current_stream().wait_event(self._event)
+            torch.cuda.current_stream(self._device).wait_event(self._event)
             self._event = None
         self._keep = ()
         return self._outputs
@@ -81,7 +153,7 @@ class PendingClosest:
 
 class ShardedRayMeshIntersector:
     def __init__(self, local, group: Optional[dist.ProcessGroup] = None, gather_mode: Optional[str] = None,
-                 force_collectives: bool = False):
+                 force_collectives: bool = False, dst_share=None, stage_through_host: Optional[bool] = None):
         # force_collectives: run the collectives even in a communicator of ONE rank (tests: the RCCL
         # calls of this module on a single-GPU box; a self-gather moves nothing but takes every code path
         # of the equal-chunk exchange)
@@ -93,16 +165,43 @@ class ShardedRayMeshIntersector:
         self.gather_mode = gather_mode or os.environ.get("TRIRO_SHARDED_GATHER", "packed")
         if self.gather_mode not in ("packed", "dense", "padded"):
             raise ValueError("gather_mode must be 'packed', 'dense' or 'padded'")
+        # dst_share: the destination rank of a packed closest-hit gather traces this fraction of an even
+        # shard (None / 1.0: even shards; "auto": auto_dst_share(world)).  Every rank must use the same value.
+        if dst_share is None:
+            dst_share = os.environ.get("TRIRO_DST_SHARE")
+        if isinstance(dst_share, str):
+            dst_share = auto_dst_share(self.world) if dst_share == "auto" else float(dst_share)
+        if dst_share is not None and not (0.0 <= dst_share <= 1.0):
+            raise ValueError("dst_share must lie in [0, 1]")
+        self.dst_share = dst_share
+        # gloo cannot move device memory: device tensors are staged through the host (functional runs of the
+        # real tracer with several ranks on one GPU).  None = decide from the backend; True forces it (CPU tests).
+        if stage_through_host is None:
+            stage_through_host = dist.is_initialized() and dist.get_backend(group) == "gloo"
+            self._stage_cpu_too = False
+        else:
+            self._stage_cpu_too = bool(stage_through_host)
+        self._stage = bool(stage_through_host)
         self._side = None      # side stream of the destination rank (wait for chunk, expand)
 
     # ---- helpers -------------------------------------------------------------------------
-    def _my_rays(self, origins: torch.Tensor, directions: torch.Tensor):
+    def bounds(self, n: int, dst: Optional[int] = None, quantum: int = 1, weighted: bool = False) -> List[Tuple[int, int]]:
+        """[lo, hi) of every rank's shard of an n-ray batch.  Even shards (shard_bounds) unless `weighted`
+        and a destination with dst_share < 1 exist: then the destination's shard is that fraction of an
+        even one, cut at multiples of `quantum`."""
+        if weighted and dst is not None and self.world > 1 and self.dst_share is not None and self.dst_share < 1.0:
+            w = [1.0] * self.world
+            w[dst] = float(self.dst_share)
+            return weighted_bounds(n, w, quantum)
+        return [shard_bounds(n, self.world, r) for r in range(self.world)]
+
+    def _my_rays(self, origins: torch.Tensor, directions: torch.Tensor, bounds=None):
         """this rank's chunk of the batch (the full batch is visible on every rank).  An image-shaped
         batch [H, W, 3] that is cut at row boundaries keeps its shape (and its stride-0 broadcast), so
         the shard is traced with the image launch shapes (tiles); everything else becomes flat [m, 3]."""
         b = origins.shape[:-1]
         n = origins.numel() // 3
-        lo, hi = shard_bounds(n, self.world, self.rank)
+        lo, hi = bounds[self.rank] if bounds is not None else shard_bounds(n, self.world, self.rank)
         if origins.dim() == 3 and b[1] > 0 and lo % b[1] == 0 and hi % b[1] == 0 and hi > lo:
             return b, n, lo, hi, origins[lo // b[1]:hi // b[1]], directions.expand(*b, 3)[lo // b[1]:hi // b[1]]
         # expand() keeps stride-0 origins cheap; reshape copies only the chunk that is traced
@@ -117,6 +216,9 @@ class ShardedRayMeshIntersector:
     def _alloc(shape, dtype, device):
         return torch.empty(shape, dtype=dtype, device=device)
 
+    def _staged(self, t: torch.Tensor) -> bool:
+        return self._stage and (t.is_cuda or self._stage_cpu_too)
+
     def _exchange(self, src: torch.Tensor, out: Optional[torch.Tensor], bounds, dst: Optional[int],
                   async_op: bool = False) -> List:
         """rows [bounds[r][0], bounds[r][1]) of `out` <- rank r's `src`, for every r; `out` exists
@@ -128,45 +230,72 @@ class ShardedRayMeshIntersector:
         sizes = [hi - lo for lo, hi in bounds]
         equal = len(set(sizes)) == 1
         want = dst is None or rank == dst
-        if self.gather_mode == "padded":
+        if self.gather_mode == "padded" and not self._staged(src):
             return self._exchange_padded(src, out, bounds, dst)
-        if equal and sizes[0] > 0:
-            src = src.contiguous()
+        src = src.contiguous()
+        staged = self._staged(src)
+        copies = []
+        if staged:
+            # host staging (gloo + device tensors): the collective runs on host copies; .cpu() waits for the
+            # stream that produced `src`, the received rows go back with copies enqueued by the handle's wait()
+            if want and sizes[rank] > 0 and out[bounds[rank][0]:bounds[rank][1]].data_ptr() != src.data_ptr():
+                out[bounds[rank][0]:bounds[rank][1]].copy_(src)
+            src_x = src.detach().cpu()
+            views = None
+            if want:
+                views = [src_x if r == rank else torch.empty((sizes[r], *src.shape[1:]), dtype=src.dtype) for r in range(world)]
+                copies = [(out[bounds[r][0]:bounds[r][1]], views[r]) for r in range(world) if r != rank and sizes[r] > 0]
+        else:
+            src_x = src
             views = [out[lo:hi] for lo, hi in bounds] if want else None
-            if want and views[rank].data_ptr() == src.data_ptr():
-                src = views[rank]           # traced in place: the collective's self-copy is a no-op
+            if want and sizes[rank] > 0 and views[rank].data_ptr() == src.data_ptr():
+                src_x = views[rank]           # traced in place: the collective's self-copy is a no-op
+        works = []
+        if equal and sizes[0] > 0:
             if dst is None:
-                whole = bounds[0][0] == 0 and all(bounds[r][1] == bounds[r + 1][0] for r in range(world - 1)) and \
+                whole = not staged and bounds[0][0] == 0 and all(bounds[r][1] == bounds[r + 1][0] for r in range(world - 1)) and \
                     bounds[-1][1] == out.shape[0]
                 if whole:
-                    w = dist.all_gather_into_tensor(out, src, group=self.group, async_op=async_op)
+                    w = dist.all_gather_into_tensor(out, src_x, group=self.group, async_op=async_op)
                 else:       # chunk k of every rank: the slices are not adjacent in `out`
-                    w = dist.all_gather(views, src, group=self.group, async_op=async_op)
+                    if staged:
+                        views = [torch.empty_like(src_x) if r == rank else v for r, v in enumerate(views)]
+                    w = dist.all_gather(views, src_x, group=self.group, async_op=async_op)
             else:
-                w = dist.gather(src, views, dst=dst, group=self.group, async_op=async_op)
-            return [w] if async_op and w is not None else []
-        ops = []
-        src = src.contiguous()
-        if want:
-            lo, hi = bounds[rank]
-            mine = out[lo:hi]
-            if mine.data_ptr() != src.data_ptr() and hi > lo:
-                mine.copy_(src)
-            for r in range(world):
-                if r != rank and sizes[r] > 0:
-                    ops.append(dist.P2POp(dist.irecv, out[bounds[r][0]:bounds[r][1]], r, group=self.group))
-        if sizes[rank] > 0:
-            targets = [r for r in range(world) if r != rank] if dst is None else ([dst] if rank != dst else [])
-            for r in targets:
-                ops.append(dist.P2POp(dist.isend, src, r, group=self.group))
-        if not ops:
+                if staged and want:
+                    views = [torch.empty_like(src_x) if r == rank else v for r, v in enumerate(views)]
+                w = dist.gather(src_x, views, dst=dst, group=self.group, async_op=async_op)
+            works = [w] if async_op and w is not None else []
+        else:
+            ops = []
+            if want:
+                lo, hi = bounds[rank]
+                if not staged and hi > lo and views[rank].data_ptr() != src_x.data_ptr():
+                    views[rank].copy_(src_x)
+                for r in range(world):
+                    if r != rank and sizes[r] > 0:
+                        ops.append(dist.P2POp(dist.irecv, views[r], self._global_rank(r), group=self.group))
+            if sizes[rank] > 0:
+                targets = [r for r in range(world) if r != rank] if dst is None else ([dst] if rank != dst else [])
+                for r in targets:
+                    ops.append(dist.P2POp(dist.isend, src_x, self._global_rank(r), group=self.group))
+            if ops:
+                reqs = dist.batch_isend_irecv(ops)
+                if async_op:
+                    works = list(reqs)
+                else:
+                    for req in reqs:
+                        req.wait()
+        if staged:
+            fin = _StagedWork(works, copies)
+            if async_op:
+                return [fin]
+            fin.wait()
             return []
-        reqs = dist.batch_isend_irecv(ops)
-        if async_op:
-            return list(reqs)
-        for req in reqs:
-            req.wait()
-        return []
+        return works
+
+    def _global_rank(self, r: int) -> int:
+        return r if self.group is None else dist.get_global_rank(self.group, r)
 
     def _exchange_padded(self, src, out, bounds, dst):
         """round 1's exchange: every rank pads its rows to the longest chunk, one (all_)gather of the
@@ -188,7 +317,7 @@ class ShardedRayMeshIntersector:
                 out[lo:hi].copy_(bufs[r][:hi - lo])
         return []
 
-    def _gather_fixed(self, x: torch.Tensor, n: int, dst: Optional[int]):
+    def _gather_fixed(self, x: torch.Tensor, n: int, dst: Optional[int], bounds=None):
         """x: this rank's [m, ...] rows -> [n, ...] on dst (None = all ranks)"""
         if self.world == 1 and not self.force_collectives:
             return x
@@ -196,7 +325,8 @@ class ShardedRayMeshIntersector:
         src = x.view(torch.uint8) if isbool else x
         want = dst is None or self.rank == dst
         out = self._alloc((n, *src.shape[1:]), src.dtype, src.device) if want else None
-        bounds = [shard_bounds(n, self.world, r) for r in range(self.world)]
+        if bounds is None:
+            bounds = [shard_bounds(n, self.world, r) for r in range(self.world)]
         self._exchange(src, out, bounds, dst)
         if not want:
             return None
@@ -207,9 +337,11 @@ class ShardedRayMeshIntersector:
         if self.world == 1 and not self.force_collectives:
             return list(xs)
         dev = xs[0].device
-        # the only extra exchange of the variable-size outputs: `world` row counts
-        cnt = torch.tensor([xs[0].shape[0]], dtype=torch.int64, device=dev)
-        cnts = self._alloc((self.world,), torch.int64, dev)
+        # the only extra exchange of the variable-size outputs: `world` row counts (on the host when the
+        # transport cannot move device memory)
+        cdev = torch.device("cpu") if self._staged(xs[0]) else dev
+        cnt = torch.tensor([xs[0].shape[0]], dtype=torch.int64, device=cdev)
+        cnts = self._alloc((self.world,), torch.int64, cdev)
         dist.all_gather_into_tensor(cnts, cnt, group=self.group)
         counts = [int(c) for c in cnts.tolist()]
         bounds, acc = [], 0
@@ -232,15 +364,23 @@ class ShardedRayMeshIntersector:
                 and hasattr(self.local, "closest_expand"))
 
     def closest_of_shard_async(self, o: torch.Tensor, d: torch.Tensor, n_total: int, batch_shape=None,
-                               dst: Optional[int] = 0, chunks: Optional[int] = None) -> PendingClosest:
+                               dst: Optional[int] = 0, chunks: Optional[int] = None, bounds=None,
+                               row_quantum: Optional[int] = None) -> PendingClosest:
         """Closest hit of ONE batch of `n_total` rays of which this rank holds (only) its shard `o`, `d`
-        = rows shard_bounds(n_total, world, rank) of the batch; results for all n_total rays on rank
-        `dst` (None: on every rank), shaped `batch_shape` (default [n_total]).  Pipeline per rank:
-        trace chunk k (packed, 12 B/ray) -> asynchronous exchange of chunk k while chunk k+1 is traced
-        -> on the destination, a side stream waits for chunk k and expands it into the dense outputs.
-        Returns at once; PendingClosest.wait() orders the caller's stream behind the result."""
+        = rows bounds[rank] of the batch (default: self.bounds(n_total, dst, weighted=True) -- even shards
+        unless dst_share is set); results for all n_total rays on rank `dst` (None: on every rank), shaped
+        `batch_shape` (default [n_total]).  Pipeline per rank: trace chunk k (packed, 12 B/ray; the
+        destination rank: dense, straight into its rows of the outputs) -> asynchronous exchange of chunk k
+        while chunk k+1 is traced -> on the destination, a side stream waits for chunk k and expands the
+        peers' records into the dense outputs.  Returns at once; PendingClosest.wait() orders the caller's
+        stream behind the result."""
         world, rank = self.world, self.rank
-        lo, hi = shard_bounds(n_total, world, rank)
+        image = o.dim() == 3           # image-shaped shard: chunk by whole rows
+        # rays per image row: every rank must chunk alike, also one whose own shard is empty (and therefore
+        # flat) -- callers that know the batch's row length pass it (row_quantum)
+        per_row = int(row_quantum) if row_quantum else (o.shape[1] if image else 1)
+        sizes = list(bounds) if bounds is not None else self.bounds(n_total, dst, per_row, weighted=True)
+        lo, hi = sizes[rank]
         m = hi - lo
         if o.numel() // 3 != m:
             raise ValueError(f"rank {rank} holds {o.numel() // 3} rays but its shard of {n_total} is {m}")
@@ -248,19 +388,23 @@ class ShardedRayMeshIntersector:
         want = dst is None or rank == dst
         b = tuple(batch_shape) if batch_shape is not None else (n_total,)
         K = chunks if chunks else default_chunks(max(1, n_total // world))
-        image = o.dim() == 3           # image-shaped shard: chunk by whole rows
-        per_row = o.shape[1] if image else 1
-        sizes = [shard_bounds(n_total, world, r) for r in range(world)]
-        if image and any((z - a) % per_row for a, z in sizes):
+        if per_row > 1 and any((z - a) % per_row for a, z in sizes):
             # (cannot happen through intersects_closest; a caller that hands in an image-shaped shard of a
             # batch whose other shards are not whole rows gets the flat path)
-            o, d, image, per_row = o.reshape(-1, 3), d.expand(*o.shape).reshape(-1, 3), False, 1
+            if image:
+                o, d = o.reshape(-1, 3), d.expand(*o.shape).reshape(-1, 3)
+            image, per_row = False, 1
         # every rank must cut its shard into the SAME number of chunks (one exchange per chunk): bound K by
-        # the smallest shard, which every rank can compute
-        K = max(1, min(K, min((z - a) // per_row for a, z in sizes)))
-        # the destination traces straight into its slice of the full packed buffer
+        # the smallest non-empty shard, which every rank can compute
+        nonempty = [(z - a) // per_row for a, z in sizes if z > a]
+        K = max(1, min(K, min(nonempty) if nonempty else 1))
+        # The destination of a dst-gather traces its own rays dense, in place: nobody else needs its records.
+        # (dst=None: every rank's records travel, so everybody traces packed and expands everything.)
+        dense_mine = want and dst is not None and hasattr(self.local, "intersects_closest_into")
         packed_all = self._alloc((n_total, 3), torch.int32, dev) if want else None
-        mine = packed_all[lo:hi] if want else (self._alloc((m, 3), torch.int32, dev) if m > 0 else None)
+        mine = None
+        if not dense_mine:
+            mine = packed_all[lo:hi] if want else (self._alloc((m, 3), torch.int32, dev) if m > 0 else None)
         outs = flat_outs = None
         if want:
             # the five dense outputs out of ONE allocation (26 B per ray: loc | uv | tri | hit | front, each
@@ -275,19 +419,21 @@ class ShardedRayMeshIntersector:
             flat_outs = (hit, front, tri, loc, uv)
             outs = (hit.view(b), front.view(b), tri.view(b), loc.view(*b, 3), uv.view(*b, 2))
         cuda = dev.type == "cuda"
-        side = None
+        side = cur = None
         if cuda and want:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=dev)
             side = self._side
-            side.wait_stream(torch.cuda.current_stream(dev))     # the allocations above are ready
+            cur = torch.cuda.current_stream(dev)
+            side.wait_stream(cur)     # the allocations above are ready
         works_all = []
+        empty = None
         for k in range(K):
             # chunk k of every rank (every rank can compute everybody's bounds)
             cb = []
             for r in range(world):
-                rlo, rhi = shard_bounds(n_total, world, r)
-                if image:      # rows of rank r's shard: all shards of an image batch are whole rows
+                rlo, rhi = sizes[r]
+                if per_row > 1:      # rows of rank r's shard: all shards of an image batch are whole rows
                     rrows = (rhi - rlo) // per_row
                     a, z = shard_bounds(rrows, K, k)
                     cb.append((rlo + a * per_row, rlo + z * per_row))
@@ -296,27 +442,42 @@ class ShardedRayMeshIntersector:
                     cb.append((rlo + a, rlo + z))
             a, z = cb[rank][0] - lo, cb[rank][1] - lo
             if z > a:
-                if image:
-                    self.local.intersects_closest_packed(o[a // per_row:z // per_row], d[a // per_row:z // per_row], out=mine[a:z])
+                ok, dk = (o[a // per_row:z // per_row], d[a // per_row:z // per_row]) if image else (o[a:z], d[a:z])
+                if dense_mine:
+                    self.local.intersects_closest_into(ok, dk, tuple(x[lo + a:lo + z] for x in flat_outs))
                 else:
-                    self.local.intersects_closest_packed(o[a:z], d[a:z], out=mine[a:z])
+                    self.local.intersects_closest_packed(ok, dk, out=mine[a:z])
             if world > 1 or self.force_collectives:
-                src = mine[a:z] if m > 0 else torch.empty((0, 3), dtype=torch.int32, device=dev)
-                works = self._exchange(src, packed_all, cb, dst, async_op=True)
+                if dense_mine:
+                    # nothing of this rank travels: it only receives (its own rows of packed_all stay unused)
+                    rb = [(ra, rz) if r != rank else (ra, ra) for r, (ra, rz) in enumerate(cb)]
+                    if empty is None:
+                        empty = torch.empty((0, 3), dtype=torch.int32, device=dev)
+                    works = self._exchange_recv_only(empty, packed_all, rb, cb, dst)
+                else:
+                    src = mine[a:z] if m > 0 else torch.empty((0, 3), dtype=torch.int32, device=dev)
+                    works = self._exchange_send(src, packed_all, cb, dst)
             else:
                 works = []
             if want:
                 def expand_chunk():
-                    spans = [(ra, rz) for ra, rz in cb if rz > ra]
-                    if spans and all(spans[j][1] == spans[j + 1][0] for j in range(len(spans) - 1)):
-                        spans = [(spans[0][0], spans[-1][1])]          # one chunk per rank: one contiguous range
-                    for ra, rz in spans:
+                    spans = [(ra, rz) for r, (ra, rz) in enumerate(cb) if rz > ra and not (dense_mine and r == rank)]
+                    merged = []
+                    for ra, rz in spans:            # adjacent ranges (one chunk per rank): one launch
+                        if merged and merged[-1][1] == ra:
+                            merged[-1] = (merged[-1][0], rz)
+                        else:
+                            merged.append((ra, rz))
+                    for ra, rz in merged:
                         self.local.closest_expand(packed_all[ra:rz], outs=tuple(x[ra:rz] for x in flat_outs))
                 if side is not None:
+                    # the side stream runs behind the exchange of chunk k AND behind the caller's stream (the
+                    # local trace of chunk k, which fills this rank's rows of the records); `cur` was taken
+                    # OUTSIDE the side-stream context (inside it, current_stream() is the side stream itself)
+                    side.wait_stream(cur)
                     with torch.cuda.stream(side):
                         for w in works:
-                            w.wait()                                      # side stream behind the exchange of chunk k
-                        side.wait_stream(torch.cuda.current_stream(dev))  # ... and behind the local trace of chunk k
+                            w.wait()
                         expand_chunk()
                 else:
                     for w in works:
@@ -328,16 +489,32 @@ class ShardedRayMeshIntersector:
         if side is not None:
             event = torch.cuda.Event()
             event.record(side)
-        return PendingClosest(outs, event, works_all, keep=(packed_all, mine, o, d))
+        return PendingClosest(outs, event, works_all, keep=(packed_all, mine, o, d), device=dev if cuda else None)
+
+    def _exchange_send(self, src, packed_all, cb, dst):
+        return self._exchange(src, packed_all, cb, dst, async_op=True)
+
+    def _exchange_recv_only(self, empty, packed_all, rb, cb, dst):
+        """the destination's side of an exchange in which it sends nothing (its rays were traced dense).
+        Equal peer chunks still take ONE collective: the peers call gather(src, dst), so the destination
+        has to contribute a chunk of the same size -- it hands in its (unused) rows of the record buffer."""
+        sizes = [z - a for a, z in cb]
+        if len(set(sizes)) == 1 and sizes[0] > 0:
+            return self._exchange(packed_all[cb[self.rank][0]:cb[self.rank][1]], packed_all, cb, dst, async_op=True)
+        return self._exchange(empty, packed_all, rb, dst, async_op=True)
 
     def intersects_closest_async(self, origins, directions, dst: Optional[int] = 0,
                                  chunks: Optional[int] = None) -> PendingClosest:
         """intersects_closest (stream_compaction=False) of a batch that is visible on every rank, as an
         in-flight handle; see closest_of_shard_async."""
-        b, n, lo, hi, o, d = self._my_rays(origins, directions)
         if not self._can_pack() or (self.world == 1 and not self.force_collectives):
             return PendingClosest(self.intersects_closest(origins, directions, dst=dst))
-        return self.closest_of_shard_async(o, d, n, batch_shape=b, dst=dst, chunks=chunks)
+        n = origins.numel() // 3
+        q = origins.shape[1] if origins.dim() == 3 else 1
+        bounds = self.bounds(n, dst, q, weighted=True)
+        b, n, lo, hi, o, d = self._my_rays(origins, directions, bounds)
+        rows = q if q > 1 and all(a % q == 0 and z % q == 0 for a, z in bounds) else None
+        return self.closest_of_shard_async(o, d, n, batch_shape=b, dst=dst, chunks=chunks, bounds=bounds, row_quantum=rows)
 
     # ---- queries (same names / return orders as RayMeshIntersector) -------------------------
     def intersects_any(self, origins, directions, dst: Optional[int] = 0):
@@ -357,11 +534,11 @@ class ShardedRayMeshIntersector:
 
     def intersects_closest(self, origins, directions, stream_compaction: bool = False,
                            dst: Optional[int] = 0, chunks: Optional[int] = None):
+        if not stream_compaction and (self.world > 1 or self.force_collectives) and self._can_pack():
+            return self.intersects_closest_async(origins, directions, dst=dst, chunks=chunks).wait()
         b, n, lo, hi, o, d = self._my_rays(origins, directions)
         m = hi - lo
         if not stream_compaction:
-            if (self.world > 1 or self.force_collectives) and self._can_pack():
-                return self.closest_of_shard_async(o, d, n, batch_shape=b, dst=dst, chunks=chunks).wait()
             res = self.local.intersects_closest(o, d)
             outs = [self._gather_fixed(x.reshape(m, *x.shape[o.dim() - 1:]), n, dst) for x in res]
             if outs[0] is None:
@@ -384,3 +561,46 @@ class ShardedRayMeshIntersector:
         if loc is None:
             return None
         return loc, ray_idx, tri
+
+
+class EmulatedWorld(ShardedRayMeshIntersector):
+    """The DESTINATION rank's side of an N-rank closest-hit gather, on ONE GPU and without a communicator
+    (bench.py --emulate-world N; nothing here is a multi-GPU measurement).  This process is rank 0 of a
+    pretended world of N: it traces its own shard with the real tracer, the peers' 12-byte records were
+    traced beforehand (`peer_records`: int32 [n_total, 3], row i = the record of global ray i) and
+    "arrive" as device-to-device copies on a copy stream -- more HBM traffic than an xGMI receive, which
+    only writes -- and the expansion of the peers' rows runs on the side stream exactly as in
+    closest_of_shard_async.  What is measured is therefore the bound the destination rank puts on an
+    N-rank step: its own trace + N-1 arriving chunks + their expansion.  The peers only trace, so they
+    are never slower than this."""
+
+    def __init__(self, local, world: int, peer_records: torch.Tensor, dst_share=None, arrival_priority: bool = False):
+        super().__init__(local, group=None, gather_mode="packed", force_collectives=False, dst_share=None,
+                         stage_through_host=False)
+        self.world, self.rank = int(world), 0
+        if isinstance(dst_share, str):
+            dst_share = auto_dst_share(self.world) if dst_share == "auto" else float(dst_share)
+        self.dst_share = dst_share
+        self.force_collectives = True
+        self.peer_records = peer_records
+        self._copy = None
+        if arrival_priority:       # the side stream ahead of the trace in the dispatcher's queue
+            self._side = torch.cuda.Stream(device=peer_records.device, priority=-1)
+
+    def _exchange(self, src, out, bounds, dst, async_op=False):
+        dev = out.device
+        if self._copy is None:
+            self._copy = torch.cuda.Stream(device=dev)
+        cs = self._copy
+        cs.wait_stream(torch.cuda.current_stream(dev))      # `out` was allocated on the caller's stream
+        with torch.cuda.stream(cs):
+            for r, (lo, hi) in enumerate(bounds):
+                if r != self.rank and hi > lo:
+                    out[lo:hi].copy_(self.peer_records[lo:hi], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(cs)
+        w = _EventWork(ev, dev)
+        if async_op:
+            return [w]
+        w.wait()
+        return []
