@@ -250,6 +250,8 @@ int tr_trace_stats_query(const tr_bvh *bvh, const tr_rays *rays, int query, tr_t
  *    instead of 7 waves per SIMD: 64 registers and a hand-over that needs half the LDS scratch).
  *    "grid_nodes" (0 never / 1 measured on the first launches of a batch size / 2 always: closest and first launches that steal walk the
  *    32-byte grid nodes -- two 16-byte loads per visit -- instead of the exact 64-byte nodes).
+ *    "expand4" (0/1: tr_closest_expand handles four rays per thread with 16-byte accesses wherever the rows it is
+ *    given are 16-byte aligned; 0 = one ray per thread everywhere).
  *    None of them changes results.  Returns TR_ERR_INVALID_ARG for unknown names or values out
  *    of range.                                                                             */
 int tr_set_option(const char *name, int64_t value);
