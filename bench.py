@@ -74,6 +74,9 @@ def parse(argv=None):
                     help="ONE GPU: the destination rank's side of an N-rank run (own trace + N-1 chunks of records arriving as "
                          "device copies + their expansion; triro.ray.sharded.EmulatedWorld) -- a bound, not a measurement")
     ap.add_argument("--arrival-priority", action="store_true", help="--emulate-world: expansion stream at high priority")
+    ap.add_argument("--arrival", choices=["copy", "none"], default="copy",
+                    help="--emulate-world: how the peers' records arrive: device copies on a copy stream (pessimistic: blit "
+                         "kernels) or not at all (they are simply there: expansion cost only)")
     ap.add_argument("--stub", default=None, help="module:factory of a stand-in tracer (only with --backend gloo; tests)")
     return ap.parse_args(argv)
 
@@ -809,7 +812,7 @@ def run_emulation(args):
                 peer_ms = (time.perf_counter() - t0) / reps * 1e3
         expected.append([x.reshape(z - a, *x.shape[ok_.dim() - 1:]).clone() for x in r.intersects_closest(ok_, dk_)])
     sync()
-    E = EmulatedWorld(r, N, peer_records, dst_share=share, arrival_priority=args.arrival_priority)
+    E = EmulatedWorld(r, N, peer_records, dst_share=share, arrival_priority=args.arrival_priority, arrival=args.arrival)
     o0, d0 = rays_of(0)
     steps = args.steps
     warm = max(args.warmup, 20)
@@ -899,7 +902,8 @@ def run_emulation(args):
         "config": {"workload": f"{args.workload} {'weak' if weak else 'strong'}: {n_total} rays in {N} shards "
                                f"({args.rays if args.workload == 'c5i' else 'hash'} rays), headline mesh {len(f)} tris",
                    "rays_total": n_total, "rays_rank0": bounds[0][1] - bounds[0][0], "rays_peer": bounds[1][1] - bounds[1][0],
-                   "dst_share": share, "chunks": args.chunks or "auto", "arrival_priority": bool(args.arrival_priority)},
+                   "dst_share": share, "chunks": args.chunks or "auto", "arrival_priority": bool(args.arrival_priority),
+                   "arrival": args.arrival, "opts": list(args.opt)},
         "emulation": {"plain_1gpu_ms_per_step": round(plain_ms, 4), "plain_1gpu_rays": plain_n,
                       "rank0_ms_per_step": round(rank0_ms, 4), "rank0_own_trace_only_ms": round(own_ms, 4),
                       "peer_trace_ms_per_step": round(peer_ms, 4), "expansion_alone_ms": round(expand_ms, 4),

@@ -250,8 +250,11 @@ int tr_trace_stats_query(const tr_bvh *bvh, const tr_rays *rays, int query, tr_t
  *    instead of 7 waves per SIMD: 64 registers and a hand-over that needs half the LDS scratch).
  *    "grid_nodes" (0 never / 1 measured on the first launches of a batch size / 2 always: closest and first launches that steal walk the
  *    32-byte grid nodes -- two 16-byte loads per visit -- instead of the exact 64-byte nodes).
- *    "expand4" (0/1: tr_closest_expand handles four rays per thread with 16-byte accesses wherever the rows it is
- *    given are 16-byte aligned; 0 = one ray per thread everywhere).
+ *    "wide" (0/1: the streaming launch walks 8-wide nodes with 8-bit child boxes -- three levels of the binary
+ *    hierarchy collapsed into one 96-byte record, built on the first streaming query after a build / refit / load),
+ *    "wide_stack" (1..24: entries of a lane's traversal stack kept in LDS; the rest spills to global memory).
+ *    "expand4" (tr_closest_expand: 0 one ray per thread / 1 four rays per thread, 256 apart / 2 four adjacent rays per
+ *    thread with 16-byte accesses where the rows are aligned).
  *    None of them changes results.  Returns TR_ERR_INVALID_ARG for unknown names or values out
  *    of range.                                                                             */
 int tr_set_option(const char *name, int64_t value);

@@ -524,6 +524,125 @@ int oracle_location_fill(const void *mesh, const float *o, const float *d, int64
     return 0;
 }
 
+/* ------------------------------------------------------------------ */
+/* WATERTIGHT float64 reference (NOT the contract): the error bar on    */
+/* "bit-exact vs the reference".  The reference's triangle test runs on */
+/* RT cores (optixTrace, shaders.cu:86,163), documented as watertight;  */
+/* the contract above is Moller-Trumbore in float32, which can lose a   */
+/* ray that passes exactly through a shared edge.  This section answers */
+/* "how many rays of a batch can that touch": Woop / Benthin / Wald     */
+/* 2013 ("Watertight Ray/Triangle Intersection", JCGT 2(1)) evaluated   */
+/* in float64 from the float32 inputs -- edge functions of a shared     */
+/* edge are exact negations of each other for the two triangles, so a   */
+/* ray through the edge hits at least one of them -- behind a double    */
+/* precision slab test on slightly inflated boxes.  Nothing of the      */
+/* contract (padded boxes, t_key clamp, fma placement) is used.         */
+/* ------------------------------------------------------------------ */
+typedef struct {
+    double o[3], d[3];
+    int kx, ky, kz;
+    double Sx, Sy, Sz;
+    int valid;
+} wray_t;
+
+static void wray_setup(wray_t *w, const float *o, const float *d) {
+    w->valid = 1;
+    for (int i = 0; i < 3; i++) {
+        w->o[i] = o[i];
+        w->d[i] = d[i];
+        if (!isfinite(o[i]) || !isfinite(d[i])) w->valid = 0;
+    }
+    int kz = 0;
+    if (fabs(w->d[1]) > fabs(w->d[kz])) kz = 1;
+    if (fabs(w->d[2]) > fabs(w->d[kz])) kz = 2;
+    int kx = (kz + 1) % 3, ky = (kx + 1) % 3;
+    if (w->d[kz] < 0.0) { int t = kx; kx = ky; ky = t; }
+    w->kx = kx; w->ky = ky; w->kz = kz;
+    if (w->d[kz] == 0.0) { w->valid = 0; return; }   /* zero direction: hits nothing */
+    w->Sx = w->d[kx] / w->d[kz];
+    w->Sy = w->d[ky] / w->d[kz];
+    w->Sz = 1.0 / w->d[kz];
+}
+
+static inline int wt_tri(const wray_t *w, const float *a, const float *b, const float *c, double *t_out) {
+    const int kx = w->kx, ky = w->ky, kz = w->kz;
+    const double A[3] = {a[0] - w->o[0], a[1] - w->o[1], a[2] - w->o[2]};
+    const double B[3] = {b[0] - w->o[0], b[1] - w->o[1], b[2] - w->o[2]};
+    const double C[3] = {c[0] - w->o[0], c[1] - w->o[1], c[2] - w->o[2]};
+    const double Ax = A[kx] - w->Sx * A[kz], Ay = A[ky] - w->Sy * A[kz];
+    const double Bx = B[kx] - w->Sx * B[kz], By = B[ky] - w->Sy * B[kz];
+    const double Cx = C[kx] - w->Sx * C[kz], Cy = C[ky] - w->Sy * C[kz];
+    const double U = Cx * By - Cy * Bx, V = Ax * Cy - Ay * Cx, W = Bx * Ay - By * Ax;
+    if ((U < 0.0 || V < 0.0 || W < 0.0) && (U > 0.0 || V > 0.0 || W > 0.0)) return 0;   /* no culling: both windings */
+    const double det = U + V + W;
+    if (det == 0.0) return 0;
+    const double Az = w->Sz * A[kz], Bz = w->Sz * B[kz], Cz = w->Sz * C[kz];
+    const double t = (U * Az + V * Bz + W * Cz) / det;
+    if (!(t >= 0.0 && t <= (double)TR_TMAX)) return 0;
+    *t_out = t;
+    return 1;
+}
+
+/* double-precision slab on the node's float box inflated by 1e-7 of its magnitude (+ 1e-30) */
+static inline int wt_box(const wray_t *w, const float *lo, const float *hi, double tlimit) {
+    double tn = 0.0, tf = tlimit;
+    for (int i = 0; i < 3; i++) {
+        const double e = 1e-7 * (fabs((double)lo[i]) + fabs((double)hi[i])) + 1e-30;
+        const double l = (double)lo[i] - e, h = (double)hi[i] + e;
+        if (w->d[i] == 0.0) {
+            if (w->o[i] < l || w->o[i] > h) return 0;
+            continue;
+        }
+        double t1 = (l - w->o[i]) / w->d[i], t2 = (h - w->o[i]) / w->d[i];
+        if (t1 > t2) { double x = t1; t1 = t2; t2 = x; }
+        if (t1 > tn) tn = t1;
+        if (t2 < tf) tf = t2;
+    }
+    return tn <= tf * (1.0 + 1e-12) + 1e-300;
+}
+
+/* closest hit and hit count of every ray under the watertight float64 test; tri = -1 / t = inf on a miss */
+int oracle_watertight(const void *mesh, const float *o, const float *d, int64_t n, int nthreads,
+                      int32_t *tri, double *t, int32_t *count) {
+    const omesh_t *m = (const omesh_t *)mesh;
+    set_threads(nthreads);
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t i = 0; i < n; i++) {
+        wray_t w;
+        wray_setup(&w, o + 3 * i, d + 3 * i);
+        int32_t best = -1, cnt = 0;
+        double bt = INFINITY;
+        if (w.valid && m->nf > 0) {
+            int32_t stack[128];
+            int sp = 0;
+            stack[sp++] = 0;
+            while (sp > 0) {
+                const onode_t *nd = &m->nodes[stack[--sp]];
+                if (!wt_box(&w, nd->lo, nd->hi, (double)TR_TMAX)) continue;
+                if (nd->right < 0) {
+                    for (int32_t k = 0; k < -nd->right; k++) {
+                        const int32_t f = m->prim[nd->left + k];
+                        const float *a, *b, *c;
+                        tri_verts(m, f, &a, &b, &c);
+                        double th;
+                        if (wt_tri(&w, a, b, c, &th)) {
+                            cnt++;
+                            if (th < bt || (th == bt && f < best)) { bt = th; best = f; }
+                        }
+                    }
+                } else {
+                    stack[sp++] = nd->left;
+                    stack[sp++] = nd->right;
+                }
+            }
+        }
+        if (tri) tri[i] = best;
+        if (t) t[i] = bt;
+        if (count) count[i] = cnt;
+    }
+    return 0;
+}
+
 /* Strided ray fetch: shaders.cu:27-63 (getIndices + getRay) with the launch-param
  * marshaling of ray.cpp:151-159,177-179: shape/strides right-aligned in 4 slots,
  * shape padded with INT64_MAX, strides padded with 0, strides in elements.

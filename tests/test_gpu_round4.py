@@ -65,7 +65,8 @@ def test_bench_two_ranks_on_one_gpu_over_gloo(extra):
     ["--emulate-world", "4", "--scaling", "strong", "--dst-share", "auto"],
     ["--emulate-world", "8", "--workload", "c5ii", "--total-rays", "2000003", "--dst-share", "auto", "--chunks", "2"],
     ["--emulate-world", "3", "--workload", "c5ii", "--total-rays", "500000", "--arrival-priority"],
-], ids=["weak8", "strong4-weighted", "c5ii8-weighted", "c5ii3-priority"])
+    ["--emulate-world", "8", "--arrival", "none", "--opt", "expand4=3"],
+], ids=["weak8", "strong4-weighted", "c5ii8-weighted", "c5ii3-priority", "weak8-no-arrival-tiles"])
 def test_emulated_destination_rank_is_bit_exact(extra):
     """bench.py --emulate-world: rank 0's step with N-1 chunks of records arriving as device copies and expanded on
     the side stream; every row of the gathered outputs == a dense trace of that rank's rays"""
@@ -91,14 +92,14 @@ def test_vectorised_expansion_matches_the_scalar_kernel_and_the_dense_trace(devi
     packed = r.intersects_closest_packed(o, d)
     assert 0.2 < float(exp[0].float().mean()) < 0.95
     try:
-        for opt in (1, 0):
+        for opt in (1, 0, 2, 3):
             hops.set_option("expand4", opt)
             got = r.closest_expand(packed)
             for a, e in zip(got, exp):
                 assert torch.equal(a, e), opt
             # row ranges at every alignment, into slices of full-size outputs (what the destination rank does)
-            for lo in (0, 1, 2, 3, 4, 1001):
-                for hi in (n, n - 1, n - 2, n - 3, lo + 5, lo + 4):
+            for lo in (0, 1, 2, 3, 4, 16, 1001):
+                for hi in (n, n - 1, n - 2, n - 3, lo + 5, lo + 4, lo + 4096 + 1024, lo + 8192 + 5):
                     outs = (torch.zeros(n, dtype=torch.bool, device=device), torch.zeros(n, dtype=torch.bool, device=device),
                             torch.full((n,), -7, dtype=torch.int32, device=device), torch.full((n, 3), 9.0, device=device),
                             torch.full((n, 2), 9.0, device=device))

@@ -1,0 +1,128 @@
+"""8-wide compressed nodes of the streaming launch (csrc/tr_wide.h, option wide): structure of the collapsed
+hierarchy and bit-exact results against the oracle and against the binary streaming launch."""
+import numpy as np
+import pytest
+import torch
+
+import workloads as W
+from oracle.oracle import OracleIntersector
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def opts():
+    import triro.backend.ops as hops
+    saved = {}
+
+    def set_(**kw):
+        for k, v in kw.items():
+            saved.setdefault(k, None)
+            hops.set_option(k, v)
+    yield set_
+    defaults = {"stream": 1, "wide": 0, "wide_stack": 24, "stream_rays": 256, "stream_refill": 32}
+    for k in saved:
+        hops.set_option(k, defaults[k])
+
+
+def _mk(v, f, device):
+    from triro.ray.ray_optix import RayMeshIntersector
+    return RayMeshIntersector(vertices=torch.from_numpy(v).to(device), faces=torch.from_numpy(f).to(device))
+
+
+def _check_all(r, R, o, d, tag):
+    on, dn = o.cpu().numpy(), d.cpu().numpy()
+    hit, front, tri, loc, uv = r.intersects_closest(o, d)
+    eh, ef, et, el, eu = R.intersects_closest(on, dn)
+    assert np.array_equal(hit.cpu().numpy(), eh), tag
+    assert np.array_equal(tri.cpu().numpy(), et), tag
+    assert np.array_equal(front.cpu().numpy(), ef), tag
+    assert np.array_equal(loc.cpu().numpy(), el) and np.array_equal(uv.cpu().numpy(), eu), tag
+    assert np.array_equal(r.intersects_first(o, d).cpu().numpy(), et), tag
+    cnt = R.intersects_count(on, dn)
+    assert np.array_equal(r.intersects_count(o, d).cpu().numpy(), cnt), tag
+    assert np.array_equal(r.intersects_any(o, d).cpu().numpy(), cnt > 0), tag
+    return int(eh.sum()), int(cnt.max())
+
+
+@pytest.mark.parametrize("wide_stack", [24, 2])
+def test_wide_streaming_matches_the_oracle(device, opts, wide_stack):
+    """every query family through k_query_wide (stream forced) on a displaced sphere, nested shells (8 hits per
+    ray) and an unstructured soup (dozens of hits per ray: deep stacks), with the stack in LDS and with all but two
+    entries of it in the global spill rows"""
+    opts(stream=2, wide=1, wide_stack=wide_stack)
+    for name, (v, f), nrays in (("sphere", W.headline_mesh(5), 60_001), ("shells", W.nested_shells(4), 40_000),
+                                ("soup", W.random_soup(20_000, seed=3), 30_000)):
+        r = _mk(v, f, device)
+        R = OracleIntersector(v, f, mode=1)
+        lo, hi = v.min(0) * 1.5, v.max(0) * 1.5
+        o, d = W.hash_rays_torch(nrays, 77, lo, hi, device=device)
+        nh, mx = _check_all(r, R, o, d, (name, wide_stack))
+        assert nh > nrays // 50, name
+        if name == "soup":
+            assert mx >= 10
+        # rays from inside the scene, axis-aligned rays, rays that start on the surface
+        c = torch.from_numpy(((v.min(0) + v.max(0)) / 2).astype(np.float32)).to(device)
+        o2 = c.expand(4096, 3).contiguous()
+        d2 = torch.nn.functional.normalize(torch.randn(4096, 3, device=device, generator=torch.Generator(device=device).manual_seed(5)), dim=1)
+        d2[:64] = torch.tensor([1.0, 0.0, 0.0], device=device)
+        d2[64:128] = torch.tensor([0.0, 0.0, -1.0], device=device)
+        _check_all(r, R, o2, d2, (name, "inside"))
+
+
+def test_wide_equals_binary_streaming_and_survives_rebuilds(device, opts):
+    """wide = 1 against wide = 0 on a 1 M-ray batch (torch.equal), then refit, update_raw and a save / load round trip:
+    the wide nodes are derived data and must follow"""
+    from triro.ray.ray_optix import RayMeshIntersector
+    v, f = W.headline_mesh(6)
+    r = _mk(v, f, device)
+    lo, hi = v.min(0) * 1.5, v.max(0) * 1.5
+    o, d = W.hash_rays_torch(1 << 20, 99, lo, hi, device=device)
+    opts(stream=2, wide=0)
+    base = r.intersects_closest(o, d)
+    base_cnt = r.intersects_count(o, d)
+    opts(wide=1)
+    for a, e in zip(r.intersects_closest(o, d), base):
+        assert torch.equal(a, e)
+    assert torch.equal(r.intersects_count(o, d), base_cnt)
+    s2 = torch.cuda.Stream(device)                       # a second stream meets the wide nodes built on the first
+    s2.wait_stream(torch.cuda.current_stream(device))
+    with torch.cuda.stream(s2):
+        got2 = r.intersects_closest(o, d)
+    torch.cuda.current_stream(device).wait_stream(s2)
+    for a, e in zip(got2, base):
+        assert torch.equal(a, e)
+    v2 = W.displaced(v, seed=1, amplitude=0.05)
+    r.refit(torch.from_numpy(v2).to(device))
+    R2 = OracleIntersector(v2, f, mode=1)
+    _check_all(r, R2, o[:50_000], d[:50_000], "refit")
+    v3, f3 = W.nested_shells(4)
+    r.update_raw(torch.from_numpy(v3).to(device), torch.from_numpy(f3).to(device))
+    R3 = OracleIntersector(v3, f3, mode=1)
+    o3, d3 = W.hash_rays_torch(50_000, 5, v3.min(0) * 1.5, v3.max(0) * 1.5, device=device)
+    _check_all(r, R3, o3, d3, "update_raw")
+    import os
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        r.save(os.path.join(td, "m"))
+        r4 = RayMeshIntersector.load(os.path.join(td, "m"), device=device)
+    _check_all(r4, R3, o3, d3, "load")
+
+
+def test_wide_on_tiny_and_degenerate_meshes(device, opts):
+    """1, 2, 3 triangles; duplicated triangles (equal Morton keys: a chain-like hierarchy); a zero-area triangle"""
+    opts(stream=2, wide=1)
+    base_v = np.array([[0.5, -0.5, 0], [0, 0.5, 0], [-0.5, -0.5, 0], [0.5, -0.5, -1], [0, 0.5, -1], [-0.5, -0.5, -1],
+                       [0.5, -0.5, -2], [0, 0.5, -2], [-0.5, -0.5, -2]], np.float32)
+    g = torch.Generator(device=device).manual_seed(1)
+    o = torch.rand(5000, 3, device=device, generator=g) * 2 - 1
+    o[:, 2] = 3
+    d = torch.tensor([0.0, 0.0, -1.0], device=device).expand(5000, 3).contiguous() + 0.05 * (torch.rand(5000, 3, device=device, generator=g) - 0.5)
+    for nt in (1, 2, 3):
+        f = np.arange(3 * nt, dtype=np.int32).reshape(nt, 3)
+        r = _mk(base_v, f, device)
+        _check_all(r, OracleIntersector(base_v, f, mode=0), o, d, nt)
+    f = np.array([[0, 1, 2]] * 40 + [[3, 4, 5]] * 3 + [[6, 6, 6]], np.int32)       # 40 copies, 3 copies, a degenerate one
+    r = _mk(base_v, f, device)
+    nh, mx = _check_all(r, OracleIntersector(base_v, f, mode=0), o, d, "duplicates")
+    assert mx == 43

@@ -48,7 +48,9 @@ const opt_desc OPTS[] = {
     {"lds_top", &tr_options::lds_top, 0, 2, false},
     {"occ8", &tr_options::occ8, 0, 2, false},
     {"split_floor", &tr_options::split_floor, 0, 100000, false},
-    {"expand4", &tr_options::expand4, 0, 1, true},
+    {"expand4", &tr_options::expand4, 0, 3, false},
+    {"wide", &tr_options::wide, 0, 1, true},
+    {"wide_stack", &tr_options::wide_stack, 1, 24, false},
 };
 constexpr int NUM_OPTS = (int)(sizeof(OPTS) / sizeof(OPTS[0]));
 struct opt_store {
@@ -287,8 +289,13 @@ int tr_bvh_destroy(tr_bvh* bvh) {
             if (bvh->arena && hipFree(bvh->arena) != hipSuccess) status = tr_fail(TR_ERR_HIP, "hipFree(arena)");
             if (bvh->refit_temp && hipFree(bvh->refit_temp) != hipSuccess) status = tr_fail(TR_ERR_HIP, "hipFree(refit_temp)");
             if (bvh->top_table && hipFree(bvh->top_table) != hipSuccess) status = tr_fail(TR_ERR_HIP, "hipFree(top_table)");
+            if (bvh->wnodes && hipFree(bvh->wnodes) != hipSuccess) status = tr_fail(TR_ERR_HIP, "hipFree(wnodes)");
+            if (bvh->wflag && hipFree(bvh->wflag) != hipSuccess) status = tr_fail(TR_ERR_HIP, "hipFree(wflag)");
+            if (bvh->widx && hipFree(bvh->widx) != hipSuccess) status = tr_fail(TR_ERR_HIP, "hipFree(widx)");
+            if (bvh->wide_event) (void)hipEventDestroy(bvh->wide_event);
             for (int k = 0; k < TR_SCHED_SLOTS; k++) {
                 if (bvh->sched[k].buf && hipFree(bvh->sched[k].buf) != hipSuccess) status = tr_fail(TR_ERR_HIP, "hipFree(sched)");
+                if (bvh->sched[k].wspill && hipFree(bvh->sched[k].wspill) != hipSuccess) status = tr_fail(TR_ERR_HIP, "hipFree(wspill)");
                 for (int e = 0; e < 16; e++)
                     if (bvh->sched[k].gn_ev[e]) (void)hipEventDestroy(bvh->sched[k].gn_ev[e]);
             }

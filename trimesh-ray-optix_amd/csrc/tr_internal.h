@@ -7,6 +7,7 @@
 
 #include "../../include/triro_hip.h"
 #include "tr_bvh.h"
+#include "tr_wide.h"
 
 // error plumbing ----------------------------------------------------------------------
 void tr_set_error(const std::string& msg);
@@ -51,6 +52,9 @@ struct tr_sched_slot {
     bool gn_final = false;
     bool gn_events = false;
     hipEvent_t gn_ev[16] = {};
+    // per-lane stack overflow rows of the wide streaming launch on this stream (k_query_wide; grown on demand)
+    int32_t* wspill = nullptr;
+    size_t wspill_elems = 0;
     void gn_reset() { gn_key = 0; gn_count = 0; gn_choice = -1; gn_rounds = 0; gn_prev = -1; gn_since = 0; gn_final = false; }
 };
 
@@ -78,6 +82,17 @@ struct tr_bvh {
     // queried this handle, so launches on different streams never share hint buffers.
     tr_sched_slot sched[TR_SCHED_SLOTS];
     std::mutex* sched_mutex = nullptr;
+    // 8-wide compressed nodes of the streaming launch (tr_wide.h): derived data, built by the first streaming
+    // query after a build / refit / load on that query's stream (under sched_mutex); other streams wait for
+    // wide_event
+    tr_wnode* wnodes = nullptr;
+    int64_t wcap = 0, wcount = 0;
+    uint8_t* wflag = nullptr;     // per binary node: round in which it was found to be the root of a wide node, 0 = none
+    int64_t* widx = nullptr;      // exclusive scan of the flags (+ one word for the total)
+    int64_t wtmp_cap = 0;
+    bool wide_valid = false;
+    hipEvent_t wide_event = nullptr;
+    hipStream_t wide_stream = nullptr;
     tr_launch_info last_launch = {};     // tr_bvh_last_launch (written under sched_mutex)
     bool have_last_launch = false;
 };
@@ -170,7 +185,9 @@ struct tr_options {
     int leaf_vote = 32;   // unordered schedule: lanes with a queued leaf that fire a leaf phase
     int occ8 = 1;         // stealing closest / first launches on the grid nodes at 8 waves per SIMD (64 registers, slim hand-over scratch): 0 never, 1 from 2 M rays on, 2 always
     int lds_top = 0;      // LDS-staged node packets for closest / first launches that steal: 0 off, 1 at 128-thread blocks, 2 at 256-thread blocks
-    int expand4 = 1;      // tr_closest_expand: four rays per thread with 16-byte accesses where the rows are aligned (0: one ray per thread)
+    int wide = 0;         // the streaming launch walks 8-wide compressed nodes (tr_wide.h; built on first use): 0 off, 1 on
+    int wide_stack = 24;  // ... entries of a lane's stack kept in LDS (<= 24; the rest lives in a global spill row; tests lower it)
+    int expand4 = 1;      // tr_closest_expand: 0 one ray per thread, 1 four rays per thread 256 apart (loads of four rays in flight), 2 four adjacent rays with 16-byte accesses (slower)
     int usteal = 1;       // unordered count launches hand owed subtrees over between lanes and use split launch slots: 0 off, 1 on, >= 2 forced trip threshold
 };
 tr_options tr_opts();   // snapshot by value

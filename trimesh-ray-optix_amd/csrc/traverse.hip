@@ -1364,34 +1364,71 @@ __global__ __launch_bounds__(256) void k_compact_closest(
 // One thread per ray: {face | front << 30, u, v} -> hit, front, tri, loc, uv with tr_bary_outputs on
 // the mesh's own vertex / face arrays (the arena's triangle records are verbatim copies of them), so
 // the outputs carry the bits tr_intersects_closest would have written.  Any output may be NULL.
+// R rays per thread, 256 apart (R = 4, round 4): the kernel is three DEPENDENT round trips deep (record -> face row ->
+// vertex rows -> stores), and with one ray per thread the chip's resident threads hold 0.5 M rays of a 7 M-ray
+// expansion at a time: 14 rounds x 3 round trips = 112 us = 2.5 TB/s.  Four independent rays per thread put four
+// times as many loads in flight per round trip; the accesses of a wave stay as coalesced as before (lane t
+// touches rays t, t + 256, ...).
+template <int R>
 __global__ __launch_bounds__(256) void k_closest_expand(const tr_packed_hit* __restrict__ packed, int64_t n,
                                                         const float* __restrict__ verts, int64_t nv,
                                                         const int32_t* __restrict__ faces, int64_t nf,
                                                         uint8_t* __restrict__ hit, uint8_t* __restrict__ front,
                                                         int32_t* __restrict__ tri, float* __restrict__ loc,
                                                         float* __restrict__ uv) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const tr_packed_hit ph = packed[i];
-    float l3[3] = {0.f, 0.f, 0.f}, u2[2] = {0.f, 0.f};
-    uint8_t h = 0, fr = 0;
-    int32_t t = -1;
-    const uint32_t face = ph.tri & 0x3fffffffu;
-    if (!(ph.tri & 0x80000000u) && (int64_t)face < nf) {
-        const int32_t i0 = faces[3 * (int64_t)face], i1 = faces[3 * (int64_t)face + 1], i2 = faces[3 * (int64_t)face + 2];
-        if ((uint32_t)i0 < (uint64_t)nv && (uint32_t)i1 < (uint64_t)nv && (uint32_t)i2 < (uint64_t)nv) {
-            const float* a = verts + 3 * (int64_t)i0; const float* b = verts + 3 * (int64_t)i1; const float* c = verts + 3 * (int64_t)i2;
-            tr_bary_outputs(ph.u, ph.v, a[0], a[1], a[2], b[0], b[1], b[2], c[0], c[1], c[2], l3, u2);
-            h = 1; fr = (ph.tri >> 30) & 1u; t = (int32_t)face;
-        }
+    const int64_t i0 = (int64_t)blockIdx.x * (256 * R) + threadIdx.x;
+    // 12-byte rows are fetched as ONE 96-bit gather each (a struct copy; three scalar element reads compile to a
+    // dwordx2 + a dword: 8 instead of 4 gather instructions per ray, and the gather instructions -- one lookup per
+    // distinct line each -- are what bounds this kernel: 1.8 -> TB/s, profiles/r04_emulate_run2.jsonl).  An empty
+    // mesh has no row 0 to read for the misses: any valid 12 bytes will do.
+    struct row3i { int32_t a, b, c; };
+    struct row3f { float x, y, z; };
+    const row3i* frow = reinterpret_cast<const row3i*>(nf > 0 ? (const void*)faces : (const void*)packed);
+    const row3f* vrow = reinterpret_cast<const row3f*>(nv > 0 ? (const void*)verts : (const void*)packed);
+    tr_packed_hit ph[R];
+    row3i fi[R];
+    bool ok[R];
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        const int64_t i = i0 + 256 * k;
+        ph[k] = packed[i < n ? i : 0];
     }
-    if (hit) hit[i] = h;
-    if (front) front[i] = fr;
-    if (tri) tri[i] = t;
-    if (loc) { loc[3 * i] = l3[0]; loc[3 * i + 1] = l3[1]; loc[3 * i + 2] = l3[2]; }
-    if (uv) { uv[2 * i] = u2[0]; uv[2 * i + 1] = u2[1]; }
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        const uint32_t face = ph[k].tri & 0x3fffffffu;
+        ok[k] = !(ph[k].tri & 0x80000000u) && (int64_t)face < nf && i0 + 256 * k < n;
+        fi[k] = frow[ok[k] ? face : 0u];
+    }
+    float va[R][9];
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        ok[k] = ok[k] && (uint32_t)fi[k].a < (uint64_t)nv && (uint32_t)fi[k].b < (uint64_t)nv && (uint32_t)fi[k].c < (uint64_t)nv;
+        const row3f a = vrow[ok[k] ? fi[k].a : 0], bb = vrow[ok[k] ? fi[k].b : 0], c = vrow[ok[k] ? fi[k].c : 0];
+        va[k][0] = a.x; va[k][1] = a.y; va[k][2] = a.z; va[k][3] = bb.x; va[k][4] = bb.y; va[k][5] = bb.z;
+        va[k][6] = c.x; va[k][7] = c.y; va[k][8] = c.z;
+    }
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        const int64_t i = i0 + 256 * k;
+        if (i >= n) continue;
+        float l3[3] = {0.f, 0.f, 0.f}, u2[2] = {0.f, 0.f};
+        uint8_t h = 0, fr = 0;
+        int32_t t = -1;
+        if (ok[k]) {
+            tr_bary_outputs(ph[k].u, ph[k].v, va[k][0], va[k][1], va[k][2], va[k][3], va[k][4], va[k][5], va[k][6], va[k][7], va[k][8], l3, u2);
+            h = 1; fr = (ph[k].tri >> 30) & 1u; t = (int32_t)(ph[k].tri & 0x3fffffffu);
+        }
+        if (hit) hit[i] = h;
+        if (front) front[i] = fr;
+        if (tri) tri[i] = t;
+        if (loc) { loc[3 * i] = l3[0]; loc[3 * i + 1] = l3[1]; loc[3 * i + 2] = l3[2]; }
+        if (uv) { uv[2 * i] = u2[0]; uv[2 * i + 1] = u2[1]; }
+    }
 }
 
+// (option expand4 = 2; measured SLOWER than one ray per thread -- 1.49 against 2.49 TB/s on 7.3 M rays,
+// profiles/r04_emulate_run1.jsonl: a wave's 16-byte accesses at a 48-byte stride touch every line three times and
+// the non-temporal hints keep them from merging -- kept for the record and for A/B runs.)
 // Four rays per thread, every global access 16 bytes wide (round 4).  The destination rank of a ray-sharded
 // run expands the records of ALL its peers (7 x the rays it traces itself at 8 GPUs) beside its own trace, so
 // this kernel has to run near the memory system's rate: 48 B of records in, 104 B of outputs per thread as
@@ -1457,6 +1494,87 @@ __global__ __launch_bounds__(256) void k_closest_expand4(const tr_u4* __restrict
         __builtin_nontemporal_store(tr_fl4{u[4], u[5], u[6], u[7]}, uv4 + 2 * g + 1);
     }
 }
+
+// (option expand4 = 3)  1024 rays per workgroup, every global access a fully coalesced 16-byte access: the records
+// are staged into LDS with consecutive lanes loading consecutive 16 bytes, thread t expands rays t, t + 256, t + 512,
+// t + 768 of the tile (12-byte rows at a 12-byte stride: no bank conflicts), the outputs go back through LDS and
+// leave as consecutive 16-byte stores.  Full tiles with 16-byte aligned rows only (the host sends the rest to the
+// per-ray kernel).
+__global__ __launch_bounds__(256) void k_closest_expand_tile(const tr_u4* __restrict__ packed16, int64_t ntiles,
+                                                             const float* __restrict__ verts, int64_t nv,
+                                                             const int32_t* __restrict__ faces, int64_t nf,
+                                                             tr_u4* __restrict__ hit16, tr_u4* __restrict__ front16,
+                                                             tr_u4* __restrict__ tri16, tr_u4* __restrict__ loc16,
+                                                             tr_u4* __restrict__ uv16) {
+    __shared__ tr_u4 s_rec[768];      // 1024 x 12 B: records in, loc out
+    __shared__ tr_u4 s_uv[512];       // 1024 x 8 B
+    __shared__ tr_u4 s_tri[256];      // 1024 x 4 B
+    __shared__ tr_u4 s_hit[64], s_front[64];
+    const int t = threadIdx.x;
+    const int64_t tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    const tr_u4* src = packed16 + tile * 768;
+    s_rec[t] = src[t]; s_rec[t + 256] = src[t + 256]; s_rec[t + 512] = src[t + 512];
+    __syncthreads();
+    const uint32_t* rec = reinterpret_cast<const uint32_t*>(s_rec);
+    uint32_t w[4][3];
+    bool ok[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int r = t + 256 * k;
+        w[k][0] = rec[3 * r]; w[k][1] = rec[3 * r + 1]; w[k][2] = rec[3 * r + 2];
+    }
+    __syncthreads();                  // all records are in registers: s_rec is free for the locations
+    struct row3i { int32_t a, b, c; };
+    struct row3f { float x, y, z; };
+    const row3i* frow = reinterpret_cast<const row3i*>(nf > 0 ? (const void*)faces : (const void*)packed16);
+    const row3f* vrow = reinterpret_cast<const row3f*>(nv > 0 ? (const void*)verts : (const void*)packed16);
+    row3i fi[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t face = w[k][0] & 0x3fffffffu;
+        ok[k] = !(w[k][0] & 0x80000000u) && (int64_t)face < nf;
+        fi[k] = frow[ok[k] ? face : 0u];
+    }
+    float va[4][9];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        ok[k] = ok[k] && (uint32_t)fi[k].a < (uint64_t)nv && (uint32_t)fi[k].b < (uint64_t)nv && (uint32_t)fi[k].c < (uint64_t)nv;
+        const row3f a = vrow[ok[k] ? fi[k].a : 0], bb = vrow[ok[k] ? fi[k].b : 0], c = vrow[ok[k] ? fi[k].c : 0];
+        va[k][0] = a.x; va[k][1] = a.y; va[k][2] = a.z; va[k][3] = bb.x; va[k][4] = bb.y; va[k][5] = bb.z;
+        va[k][6] = c.x; va[k][7] = c.y; va[k][8] = c.z;
+    }
+    float* o_loc = reinterpret_cast<float*>(s_rec);
+    float* o_uv = reinterpret_cast<float*>(s_uv);
+    int32_t* o_tri = reinterpret_cast<int32_t*>(s_tri);
+    uint8_t* o_hit = reinterpret_cast<uint8_t*>(s_hit);
+    uint8_t* o_front = reinterpret_cast<uint8_t*>(s_front);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int r = t + 256 * k;
+        float l3[3] = {0.f, 0.f, 0.f}, u2[2] = {0.f, 0.f};
+        uint8_t h = 0, fr = 0;
+        int32_t tf = -1;
+        if (ok[k]) {
+            tr_bary_outputs(__uint_as_float(w[k][1]), __uint_as_float(w[k][2]), va[k][0], va[k][1], va[k][2], va[k][3], va[k][4],
+                            va[k][5], va[k][6], va[k][7], va[k][8], l3, u2);
+            h = 1; fr = (w[k][0] >> 30) & 1u; tf = (int32_t)(w[k][0] & 0x3fffffffu);
+        }
+        o_loc[3 * r] = l3[0]; o_loc[3 * r + 1] = l3[1]; o_loc[3 * r + 2] = l3[2];
+        o_uv[2 * r] = u2[0]; o_uv[2 * r + 1] = u2[1];
+        o_tri[r] = tf; o_hit[r] = h; o_front[r] = fr;
+    }
+    __syncthreads();
+    if (loc16) { tr_u4* d = loc16 + tile * 768; d[t] = s_rec[t]; d[t + 256] = s_rec[t + 256]; d[t + 512] = s_rec[t + 512]; }
+    if (uv16) { tr_u4* d = uv16 + tile * 512; d[t] = s_uv[t]; d[t + 256] = s_uv[t + 256]; }
+    if (tri16) tri16[tile * 256 + t] = s_tri[t];
+    if (t < 64) {
+        if (hit16) hit16[tile * 64 + t] = s_hit[t];
+        if (front16) front16[tile * 64 + t] = s_front[t];
+    }
+}
+
+#include "traverse_wide.inc"
 
 // ---- host side ----------------------------------------------------------------------------------
 int make_fetch(const tr_rays* rays, RayFetch* rf) {
@@ -1645,6 +1763,11 @@ int gn_pick(const tr_bvh* bvh, hipStream_t stream, int cls, int64_t key, hipEven
     return t->gn_prev > 0;       // undecided: the previous measurement's flavour (exact nodes the first time)
 }
 
+// the 8-wide nodes of the handle, built if necessary (defined behind the scan kernels' host wrapper); NULL = not
+// available for this launch (the caller keeps the binary streaming launch)
+const tr_wnode* ensure_wide(const tr_bvh* bvh, hipStream_t stream);
+int32_t* wide_spill(const tr_bvh* bvh, hipStream_t stream, size_t elems);
+
 template <int Q, bool STATS>
 int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
                  unsigned long long* d_stats, hipStream_t stream) {
@@ -1739,7 +1862,35 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
                     if (grid > resident) grid = resident;
                     sxc = 0;
                 }
-                if (compact && !STATS)
+                bool wide_launched = false;
+                if constexpr (!STATS) {
+                    // 8-wide compressed nodes (option wide): a third of the dependent fetches of the binary walk
+                    const tr_wnode* wn = (opt.wide && addr32) ? ensure_wide(bvh, stream) : nullptr;
+                    if (wn) {
+                        static std::atomic<int> wocc_a{0};   // per instantiation <Q>
+                        int wocc = wocc_a.load(std::memory_order_relaxed);
+                        if (wocc == 0) {
+                            int nb = 0;
+                            hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_query_wide<Q>, 128, 0);
+                            wocc = (e == hipSuccess && nb > 0) ? nb : 8;
+                            wocc_a.store(wocc, std::memory_order_relaxed);
+                        }
+                        unsigned wgrid = (unsigned)((nwaves + 1) / 2);
+                        if (work) { const unsigned resident = (unsigned)st->num_cus * (unsigned)wocc; if (wgrid > resident) wgrid = resident; }
+                        // stack bound: 7 pending siblings per wide level + the 8 children of the node in hand
+                        const int need = 7 * ((bvh->depth + 2) / 3) + 9;
+                        const int lds_cap = opt.wide_stack < TR_WSTACK ? opt.wide_stack : TR_WSTACK;
+                        const int spill_cap = need > lds_cap ? need - lds_cap : 0;
+                        int32_t* spill = spill_cap > 0 ? wide_spill(bvh, stream, (size_t)wgrid * 128 * (size_t)spill_cap) : nullptr;
+                        if (spill_cap == 0 || spill) {
+                            hipLaunchKernelGGL((k_query_wide<Q>), dim3(wgrid), dim3(128), 0, stream, view, wn, rf, out, rpw,
+                                               opt.stream_refill, sel, work, spill, spill_cap, lds_cap);
+                            wide_launched = true;
+                        }
+                    }
+                }
+                if (wide_launched) {
+                } else if (compact && !STATS)
                     hipLaunchKernelGGL((k_query_stream_occ8<Q>), dim3(grid), dim3(128), 0, stream,
                                        view, rf, out, rpw, opt.stream_refill, sxc, d_stats, sel, work);
                 else if (compact)
@@ -2028,6 +2179,69 @@ int scan_impl(const T* d_in, int64_t n, int32_t cap, int64_t* d_offsets, int64_t
     return TR_OK;
 }
 
+// ---- 8-wide nodes: construction on first use (traverse_wide.inc) ----------------------------------------------
+const tr_wnode* ensure_wide(const tr_bvh* cbvh, hipStream_t stream) {
+    tr_bvh* bvh = const_cast<tr_bvh*>(cbvh);
+    if (!bvh->sched_mutex || bvh->num_nodes < 1 || bvh->num_tris < 2) return nullptr;
+    std::lock_guard<std::mutex> lock(*bvh->sched_mutex);
+    if (bvh->wide_valid) {
+        if (stream != bvh->wide_stream && bvh->wide_event) (void)hipStreamWaitEvent(stream, bvh->wide_event, 0);
+        return bvh->wnodes;
+    }
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
+    const int64_t n = bvh->num_nodes;
+    if (bvh->wtmp_cap < n) {
+        if (bvh->wflag) (void)hipFree(bvh->wflag);
+        if (bvh->widx) (void)hipFree(bvh->widx);
+        bvh->wflag = nullptr; bvh->widx = nullptr; bvh->wtmp_cap = 0;
+        if (hipMalloc((void**)&bvh->wflag, (size_t)n) != hipSuccess || hipMalloc((void**)&bvh->widx, sizeof(int64_t) * (size_t)(n + 1)) != hipSuccess) {
+            (void)hipGetLastError();
+            if (bvh->wflag) { (void)hipFree(bvh->wflag); bvh->wflag = nullptr; }
+            return nullptr;
+        }
+        bvh->wtmp_cap = n;
+    }
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    const int rounds = (bvh->depth + 2) / 3 + 1;
+    for (int r = 0; r <= rounds; r++)
+        hipLaunchKernelGGL(k_wide_mark, dim3(blocks), dim3(256), 0, stream, bvh->nodes, n, bvh->wflag, r);
+    int64_t nw = 0;
+    if (scan_impl<uint8_t>(bvh->wflag, n, 1, bvh->widx, bvh->widx + n, &nw, stream) != TR_OK || nw < 1) return nullptr;
+    if (nw * (int64_t)sizeof(tr_wnode) >= ((int64_t)1 << 32)) return nullptr;      // 32-bit offsets in the kernel
+    if (bvh->wcap < nw) {
+        if (bvh->wnodes) (void)hipFree(bvh->wnodes);
+        bvh->wnodes = nullptr; bvh->wcap = 0;
+        if (hipMalloc((void**)&bvh->wnodes, sizeof(tr_wnode) * (size_t)nw) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        bvh->wcap = nw;
+    }
+    hipLaunchKernelGGL(k_wide_emit, dim3(blocks), dim3(256), 0, stream, bvh->nodes, n, bvh->wflag, bvh->widx, bvh->wnodes);
+    if (hipGetLastError() != hipSuccess) return nullptr;
+    if (!bvh->wide_event && hipEventCreateWithFlags(&bvh->wide_event, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); bvh->wide_event = nullptr; }
+    if (bvh->wide_event) (void)hipEventRecord(bvh->wide_event, stream);
+    else (void)hipStreamSynchronize(stream);
+    bvh->wide_stream = stream;
+    bvh->wcount = nw;
+    bvh->wide_valid = true;
+    return bvh->wnodes;
+}
+
+int32_t* wide_spill(const tr_bvh* cbvh, hipStream_t stream, size_t elems) {
+    tr_bvh* bvh = const_cast<tr_bvh*>(cbvh);
+    if (!bvh->sched_mutex) return nullptr;
+    std::lock_guard<std::mutex> lock(*bvh->sched_mutex);
+    tr_sched_slot* slot = sched_slot(bvh, stream, 0);
+    if (!slot) return nullptr;
+    if (slot->wspill_elems < elems) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
+        if (slot->wspill) { (void)hipStreamSynchronize(stream); (void)hipFree(slot->wspill); slot->wspill = nullptr; slot->wspill_elems = 0; }
+        if (hipMalloc((void**)&slot->wspill, elems * sizeof(int32_t)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        slot->wspill_elems = elems;
+    }
+    return slot->wspill;
+}
+
 }  // namespace
 
 extern "C" {
@@ -2066,22 +2280,45 @@ int tr_closest_expand(const tr_packed_hit* d_packed, int64_t n, const float* d_v
     if (n == 0) return TR_OK;
     if (!d_packed) return tr_fail(TR_ERR_INVALID_ARG, "d_packed == NULL");
     if (nf > 0 && (!d_vertices || !d_faces)) return tr_fail(TR_ERR_INVALID_ARG, "null mesh pointer");
-    // the body in groups of four rays with 16-byte accesses (k_closest_expand4) when every row pointer is
-    // 16-byte aligned (rows of full-size outputs at multiples of four rays are); the rest one ray per thread
-    const uintptr_t align_bits = (uintptr_t)d_packed | (uintptr_t)d_tri | (uintptr_t)d_loc | (uintptr_t)d_uv |
-                                 (((uintptr_t)d_hit | (uintptr_t)d_front) << 2);
-    const int64_t n4 = (align_bits & 15) == 0 && tr_opts().expand4 ? n / 4 : 0;
-    if (n4 > 0)
-        hipLaunchKernelGGL(k_closest_expand4, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                           reinterpret_cast<const tr_u4*>(d_packed), n4, d_vertices, nv, d_faces, nf,
-                           reinterpret_cast<uint32_t*>(d_hit), reinterpret_cast<uint32_t*>(d_front),
-                           reinterpret_cast<tr_u4*>(d_tri), reinterpret_cast<tr_fl4*>(d_loc), reinterpret_cast<tr_fl4*>(d_uv));
-    const int64_t done = 4 * n4, rest = n - done;
-    if (rest > 0)
-        hipLaunchKernelGGL(k_closest_expand, dim3((unsigned)((rest + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                           d_packed + done, rest, d_vertices, nv, d_faces, nf, d_hit ? d_hit + done : nullptr,
-                           d_front ? d_front + done : nullptr, d_tri ? d_tri + done : nullptr,
-                           d_loc ? d_loc + 3 * done : nullptr, d_uv ? d_uv + 2 * done : nullptr);
+    // expand4: 0 one ray per thread, 1 (default) four rays per thread 256 apart, 2 four adjacent rays per thread with
+    // 16-byte accesses for the aligned body (k_closest_expand4), 3 tiles of 1024 rays staged through LDS, every
+    // global access coalesced (k_closest_expand_tile; aligned full tiles, the rest as mode 1)
+    const int mode = tr_opts().expand4;
+    int64_t done = 0;
+    if (mode == 2) {
+        const uintptr_t align_bits = (uintptr_t)d_packed | (uintptr_t)d_tri | (uintptr_t)d_loc | (uintptr_t)d_uv |
+                                     (((uintptr_t)d_hit | (uintptr_t)d_front) << 2);
+        const int64_t n4 = (align_bits & 15) == 0 ? n / 4 : 0;
+        if (n4 > 0)
+            hipLaunchKernelGGL(k_closest_expand4, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                               reinterpret_cast<const tr_u4*>(d_packed), n4, d_vertices, nv, d_faces, nf,
+                               reinterpret_cast<uint32_t*>(d_hit), reinterpret_cast<uint32_t*>(d_front),
+                               reinterpret_cast<tr_u4*>(d_tri), reinterpret_cast<tr_fl4*>(d_loc), reinterpret_cast<tr_fl4*>(d_uv));
+        done = 4 * n4;
+    } else if (mode == 3) {
+        const uintptr_t align_bits = (uintptr_t)d_packed | (uintptr_t)d_tri | (uintptr_t)d_loc | (uintptr_t)d_uv |
+                                     (uintptr_t)d_hit | (uintptr_t)d_front;
+        const int64_t ntiles = (align_bits & 15) == 0 ? n / 1024 : 0;
+        if (ntiles > 0)
+            hipLaunchKernelGGL(k_closest_expand_tile, dim3((unsigned)ntiles), dim3(256), 0, (hipStream_t)stream,
+                               reinterpret_cast<const tr_u4*>(d_packed), ntiles, d_vertices, nv, d_faces, nf,
+                               reinterpret_cast<tr_u4*>(d_hit), reinterpret_cast<tr_u4*>(d_front),
+                               reinterpret_cast<tr_u4*>(d_tri), reinterpret_cast<tr_u4*>(d_loc), reinterpret_cast<tr_u4*>(d_uv));
+        done = 1024 * ntiles;
+    }
+    const int64_t rest = n - done;
+    if (rest > 0) {
+        const tr_packed_hit* pp = d_packed + done;
+        uint8_t* ph = d_hit ? d_hit + done : nullptr; uint8_t* pf = d_front ? d_front + done : nullptr;
+        int32_t* pt = d_tri ? d_tri + done : nullptr;
+        float* pl = d_loc ? d_loc + 3 * done : nullptr; float* pu = d_uv ? d_uv + 2 * done : nullptr;
+        if (mode != 0 && rest >= 4096)
+            hipLaunchKernelGGL(k_closest_expand<4>, dim3((unsigned)((rest + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream,
+                               pp, rest, d_vertices, nv, d_faces, nf, ph, pf, pt, pl, pu);
+        else
+            hipLaunchKernelGGL(k_closest_expand<1>, dim3((unsigned)((rest + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                               pp, rest, d_vertices, nv, d_faces, nf, ph, pf, pt, pl, pu);
+    }
     TR_HIP_TRY(hipGetLastError());
     return TR_OK;
 }

@@ -471,10 +471,13 @@ class ShardedRayMeshIntersector:
                     for ra, rz in merged:
                         self.local.closest_expand(packed_all[ra:rz], outs=tuple(x[ra:rz] for x in flat_outs))
                 if side is not None:
-                    # the side stream runs behind the exchange of chunk k AND behind the caller's stream (the
-                    # local trace of chunk k, which fills this rank's rows of the records); `cur` was taken
-                    # OUTSIDE the side-stream context (inside it, current_stream() is the side stream itself)
-                    side.wait_stream(cur)
+                    # the side stream runs behind the exchange of chunk k AND -- when this rank's own rows are records
+                    # too -- behind the caller's stream (the local trace of chunk k fills them); `cur` was taken
+                    # OUTSIDE the side-stream context (inside it, current_stream() is the side stream itself).
+                    # A destination that traces dense expands only the peers' rows: nothing to wait for, the
+                    # expansion of chunk k overlaps the trace of chunk k.
+                    if not dense_mine:
+                        side.wait_stream(cur)
                     with torch.cuda.stream(side):
                         for w in works:
                             w.wait()
@@ -574,7 +577,8 @@ class EmulatedWorld(ShardedRayMeshIntersector):
     N-rank step: its own trace + N-1 arriving chunks + their expansion.  The peers only trace, so they
     are never slower than this."""
 
-    def __init__(self, local, world: int, peer_records: torch.Tensor, dst_share=None, arrival_priority: bool = False):
+    def __init__(self, local, world: int, peer_records: torch.Tensor, dst_share=None, arrival_priority: bool = False,
+                 arrival: str = "copy"):
         super().__init__(local, group=None, gather_mode="packed", force_collectives=False, dst_share=None,
                          stage_through_host=False)
         self.world, self.rank = int(world), 0
@@ -584,11 +588,28 @@ class EmulatedWorld(ShardedRayMeshIntersector):
         self.force_collectives = True
         self.peer_records = peer_records
         self._copy = None
+        # arrival: "copy" = device-to-device copies on a copy stream (blit kernels: they take CUs and read as much
+        # as they write -- a pessimistic stand-in for an xGMI receive); "none" = the records are simply there
+        # (the record buffer IS peer_records): the optimistic end, expansion cost only
+        if arrival not in ("copy", "none"):
+            raise ValueError("arrival must be 'copy' or 'none'")
+        self.arrival = arrival
+        if arrival == "none":
+            n_total = peer_records.shape[0]
+            plain_alloc = self._alloc
+
+            def alloc(shape, dtype, device):
+                if tuple(shape) == (n_total, 3) and dtype == torch.int32:
+                    return self.peer_records
+                return plain_alloc(shape, dtype, device)
+            self._alloc = alloc
         if arrival_priority:       # the side stream ahead of the trace in the dispatcher's queue
             self._side = torch.cuda.Stream(device=peer_records.device, priority=-1)
 
     def _exchange(self, src, out, bounds, dst, async_op=False):
         dev = out.device
+        if self.arrival == "none":
+            return []
         if self._copy is None:
             self._copy = torch.cuda.Stream(device=dev)
         cs = self._copy
