@@ -50,9 +50,19 @@ def run(name, r, o, d, queries, reps=8, warm=3):
             else:
                 same = all(torch.equal(a, b) for a, b in zip(out, ref[q]))
             sec = timeit(lambda: fn(o, d), reps, warm)
+            st = None
+            try:
+                hops.set_option("stream", 2)
+                m = min(n, 1 << 21)
+                t = hops.trace_stats(r.as_wrapper, o[:m], d[:m], q)
+                st = {"node_visits_per_ray": round(t["node_visits"] / t["rays"], 2), "tri_tests_per_ray": round(t["tri_tests"] / t["rays"], 2)}
+            except Exception as exc:
+                st = str(exc)
+            finally:
+                hops.set_option("stream", 1)
             print(json.dumps(dict(config=name, query=q, wide=wide, rays=n, ms=round(sec * 1e3, 4), grays_per_s=round(n / sec / 1e9, 3),
-                                  identical_to_binary=same, tris=int(r.bvh_info()["num_tris"]), depth=int(r.bvh_info()["depth"]))), flush=True)
-    hops.set_option("wide", 0)
+                                  identical_to_binary=same, stats=st, tris=int(r.bvh_info()["num_tris"]), depth=int(r.bvh_info()["depth"]))), flush=True)
+    hops.set_option("wide", 2)
 
 
 for k, v_ in extra.items():

@@ -39,13 +39,15 @@ def compare(name, v, f, o, d):
     whit = wtri >= 0
     both = hit & whit
     tdiff = both & (tri != wtri)
-    close = np.abs(t - wt) <= 1e-5 * np.maximum(1.0, np.abs(wt))
+    with np.errstate(invalid="ignore"):
+        dt = np.where(both, np.abs(np.where(both, t, 0.0) - np.where(both, wt, 0.0)), np.inf)
+    close = dt <= 1e-5 * np.maximum(1.0, np.abs(np.where(both, wt, 1.0)))
     n = hit.size
     res = dict(config=name, rays=int(n), triangles=int(len(f)), hits_contract=int(hit.sum()), hits_watertight=int(whit.sum()),
                only_contract=int((hit & ~whit).sum()), only_watertight=int((~hit & whit).sum()),
                tri_diff_same_t=int((tdiff & close).sum()), tri_diff_other=int((tdiff & ~close).sum()),
                count_diff=int((cnt != wcnt).sum()),
-               max_rel_t_diff_same_tri=float(np.max(np.abs(t - wt)[both & ~tdiff] / np.maximum(1.0, np.abs(wt[both & ~tdiff])), initial=0.0)))
+               max_rel_t_diff_same_tri=float(np.max(dt[both & ~tdiff] / np.maximum(1.0, np.abs(wt[both & ~tdiff])), initial=0.0)))
     res["hit_mask_diff_rate"] = (res["only_contract"] + res["only_watertight"]) / n
     res["real_disagreement_rate"] = (res["only_contract"] + res["only_watertight"] + res["tri_diff_other"]) / n
     return res

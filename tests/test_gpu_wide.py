@@ -20,7 +20,7 @@ def opts():
             saved.setdefault(k, None)
             hops.set_option(k, v)
     yield set_
-    defaults = {"stream": 1, "wide": 0, "wide_stack": 24, "stream_rays": 256, "stream_refill": 32}
+    defaults = {"stream": 1, "wide": 2, "wide_stack": 12, "stream_rays": 256, "stream_refill": 32}
     for k in saved:
         hops.set_option(k, defaults[k])
 
@@ -45,7 +45,7 @@ def _check_all(r, R, o, d, tag):
     return int(eh.sum()), int(cnt.max())
 
 
-@pytest.mark.parametrize("wide_stack", [24, 2])
+@pytest.mark.parametrize("wide_stack", [12, 2])
 def test_wide_streaming_matches_the_oracle(device, opts, wide_stack):
     """every query family through k_query_wide (stream forced) on a displaced sphere, nested shells (8 hits per
     ray) and an unstructured soup (dozens of hits per ray: deep stacks), with the stack in LDS and with all but two

@@ -49,8 +49,9 @@ const opt_desc OPTS[] = {
     {"occ8", &tr_options::occ8, 0, 2, false},
     {"split_floor", &tr_options::split_floor, 0, 100000, false},
     {"expand4", &tr_options::expand4, 0, 3, false},
-    {"wide", &tr_options::wide, 0, 1, true},
-    {"wide_stack", &tr_options::wide_stack, 1, 24, false},
+    {"expand_cus", &tr_options::expand_cus, 0, 64, false},
+    {"wide", &tr_options::wide, 0, 2, false},
+    {"wide_stack", &tr_options::wide_stack, 1, 12, false},
 };
 constexpr int NUM_OPTS = (int)(sizeof(OPTS) / sizeof(OPTS[0]));
 struct opt_store {

@@ -1426,6 +1426,70 @@ __global__ __launch_bounds__(256) void k_closest_expand(const tr_packed_hit* __r
     }
 }
 
+// (option expand4 = 1, the default)  R rays per thread, 256 apart, the face and vertex rows through BUFFER loads:
+// a record that is a miss (45 % of the headline image, more of a batch of unrelated rays) gets an offset beyond the
+// buffer, and a buffer load out of range returns zeros WITHOUT touching memory -- so the loads stay unconditional
+// (all R rays' gathers of a thread are in flight together) and the misses cost nothing.  (With plain loads the
+// misses either branch around the gathers -- one ray per thread, 2.4 TB/s -- or all read row 0: one cache line
+// hammered by every CU, 2.0 TB/s; profiles/r04_expand_variants.txt.)  Grid-stride loop: `expand_cus` caps the
+// grid, so that the expansion the destination rank of a sharded run does BESIDE its own trace holds a few waves per
+// CU for longer instead of competing for every wave slot (triro/ray/sharded.py).
+template <int R>
+__global__ __launch_bounds__(256) void k_closest_expand_buf(const tr_packed_hit* __restrict__ packed, int64_t n,
+                                                            const float* __restrict__ verts, int64_t nv,
+                                                            const int32_t* __restrict__ faces, int64_t nf,
+                                                            uint8_t* __restrict__ hit, uint8_t* __restrict__ front,
+                                                            int32_t* __restrict__ tri, float* __restrict__ loc,
+                                                            float* __restrict__ uv) {
+    typedef int tr_v3i __attribute__((ext_vector_type(3)));
+    const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc((void*)faces, 0, (int)(nf * 12), 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void*)verts, 0, (int)(nv * 12), 0x00020000);
+    for (int64_t i0 = (int64_t)blockIdx.x * (256 * R) + threadIdx.x; i0 < n; i0 += (int64_t)gridDim.x * (256 * R)) {
+        tr_packed_hit ph[R];
+        tr_v3i fi[R];
+        bool ok[R];
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            const int64_t i = i0 + 256 * k;
+            ph[k] = packed[i < n ? i : i0];
+        }
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            const uint32_t face = ph[k].tri & 0x3fffffffu;
+            ok[k] = !(ph[k].tri & 0x80000000u) && (int64_t)face < nf && i0 + 256 * k < n;
+            fi[k] = __builtin_amdgcn_raw_buffer_load_b96(frs, ok[k] ? face * 12u : 0xffffffffu, 0, 0);
+        }
+        float va[R][9];
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            ok[k] = ok[k] && (uint32_t)fi[k].x < (uint64_t)nv && (uint32_t)fi[k].y < (uint64_t)nv && (uint32_t)fi[k].z < (uint64_t)nv;
+            const tr_v3i a = __builtin_amdgcn_raw_buffer_load_b96(vrs, ok[k] ? (uint32_t)fi[k].x * 12u : 0xffffffffu, 0, 0);
+            const tr_v3i b = __builtin_amdgcn_raw_buffer_load_b96(vrs, ok[k] ? (uint32_t)fi[k].y * 12u : 0xffffffffu, 0, 0);
+            const tr_v3i c = __builtin_amdgcn_raw_buffer_load_b96(vrs, ok[k] ? (uint32_t)fi[k].z * 12u : 0xffffffffu, 0, 0);
+            va[k][0] = __int_as_float(a.x); va[k][1] = __int_as_float(a.y); va[k][2] = __int_as_float(a.z);
+            va[k][3] = __int_as_float(b.x); va[k][4] = __int_as_float(b.y); va[k][5] = __int_as_float(b.z);
+            va[k][6] = __int_as_float(c.x); va[k][7] = __int_as_float(c.y); va[k][8] = __int_as_float(c.z);
+        }
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            const int64_t i = i0 + 256 * k;
+            if (i >= n) continue;
+            float l3[3] = {0.f, 0.f, 0.f}, u2[2] = {0.f, 0.f};
+            uint8_t h = 0, fr = 0;
+            int32_t t = -1;
+            if (ok[k]) {
+                tr_bary_outputs(ph[k].u, ph[k].v, va[k][0], va[k][1], va[k][2], va[k][3], va[k][4], va[k][5], va[k][6], va[k][7], va[k][8], l3, u2);
+                h = 1; fr = (ph[k].tri >> 30) & 1u; t = (int32_t)(ph[k].tri & 0x3fffffffu);
+            }
+            if (hit) hit[i] = h;
+            if (front) front[i] = fr;
+            if (tri) tri[i] = t;
+            if (loc) { loc[3 * i] = l3[0]; loc[3 * i + 1] = l3[1]; loc[3 * i + 2] = l3[2]; }
+            if (uv) { uv[2 * i] = u2[0]; uv[2 * i + 1] = u2[1]; }
+        }
+    }
+}
+
 // (option expand4 = 2; measured SLOWER than one ray per thread -- 1.49 against 2.49 TB/s on 7.3 M rays,
 // profiles/r04_emulate_run1.jsonl: a wave's 16-byte accesses at a 48-byte stride touch every line three times and
 // the non-temporal hints keep them from merging -- kept for the record and for A/B runs.)
@@ -1863,28 +1927,33 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
                     sxc = 0;
                 }
                 bool wide_launched = false;
-                if constexpr (!STATS) {
+                {
                     // 8-wide compressed nodes (option wide): a third of the dependent fetches of the binary walk
-                    const tr_wnode* wn = (opt.wide && addr32) ? ensure_wide(bvh, stream) : nullptr;
+                    // wide: 0 never, 1 always, 2 (default) where it was measured faster than the binary grid nodes: meshes
+                    // from 3 M triangles on (5.2 M triangles: closest -10 %) and count launches from 1 M triangles on
+                    // (C5(ii) shard count -9 %); on the 1.31 M-triangle headline mesh closest / any are equal within
+                    // 1 %, on the 82 k-triangle C2 mesh the binary walk wins by 5...22 % (profiles/r04_ab_wide.txt)
+                    const bool wide_auto = bvh->num_tris >= 3000000 || (Q == TR_Q_COUNT && bvh->num_tris >= 1000000);
+                    const tr_wnode* wn = ((opt.wide == 1 || (opt.wide == 2 && wide_auto)) && addr32) ? ensure_wide(bvh, stream) : nullptr;
                     if (wn) {
-                        static std::atomic<int> wocc_a{0};   // per instantiation <Q>
+                        static std::atomic<int> wocc_a{0};   // per instantiation <Q, STATS>
                         int wocc = wocc_a.load(std::memory_order_relaxed);
                         if (wocc == 0) {
                             int nb = 0;
-                            hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_query_wide<Q>, 128, 0);
+                            hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_query_wide<Q, STATS>, 128, 0);
                             wocc = (e == hipSuccess && nb > 0) ? nb : 8;
                             wocc_a.store(wocc, std::memory_order_relaxed);
                         }
                         unsigned wgrid = (unsigned)((nwaves + 1) / 2);
                         if (work) { const unsigned resident = (unsigned)st->num_cus * (unsigned)wocc; if (wgrid > resident) wgrid = resident; }
-                        // stack bound: 7 pending siblings per wide level + the 8 children of the node in hand
+                        // node-stack bound: 7 pending siblings per wide level + the 8 children of the node in hand
                         const int need = 7 * ((bvh->depth + 2) / 3) + 9;
                         const int lds_cap = opt.wide_stack < TR_WSTACK ? opt.wide_stack : TR_WSTACK;
                         const int spill_cap = need > lds_cap ? need - lds_cap : 0;
                         int32_t* spill = spill_cap > 0 ? wide_spill(bvh, stream, (size_t)wgrid * 128 * (size_t)spill_cap) : nullptr;
                         if (spill_cap == 0 || spill) {
-                            hipLaunchKernelGGL((k_query_wide<Q>), dim3(wgrid), dim3(128), 0, stream, view, wn, rf, out, rpw,
-                                               opt.stream_refill, sel, work, spill, spill_cap, lds_cap);
+                            hipLaunchKernelGGL((k_query_wide<Q, STATS>), dim3(wgrid), dim3(128), 0, stream, view, wn, rf, out, rpw,
+                                               opt.stream_refill, sel, work, spill, spill_cap, lds_cap, d_stats);
                             wide_launched = true;
                         }
                     }
@@ -2312,7 +2381,19 @@ int tr_closest_expand(const tr_packed_hit* d_packed, int64_t n, const float* d_v
         uint8_t* ph = d_hit ? d_hit + done : nullptr; uint8_t* pf = d_front ? d_front + done : nullptr;
         int32_t* pt = d_tri ? d_tri + done : nullptr;
         float* pl = d_loc ? d_loc + 3 * done : nullptr; float* pu = d_uv ? d_uv + 2 * done : nullptr;
-        if (mode != 0 && rest >= 4096)
+        const bool buf_ok = nf * 12 < ((int64_t)1 << 31) && nv * 12 < ((int64_t)1 << 31) && nf > 0 && nv > 0;
+        if (mode == 1 && rest >= 4096 && buf_ok) {
+            int64_t blocks = (rest + 1023) / 1024;
+            const tr_options o2 = tr_opts();
+            if (o2.expand_cus > 0) {
+                int dev = 0;
+                tr_device_state* st = nullptr;
+                if (hipGetDevice(&dev) == hipSuccess && tr_get_device_state(dev, &st) == TR_OK && blocks > (int64_t)st->num_cus * o2.expand_cus)
+                    blocks = (int64_t)st->num_cus * o2.expand_cus;
+            }
+            hipLaunchKernelGGL(k_closest_expand_buf<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                               pp, rest, d_vertices, nv, d_faces, nf, ph, pf, pt, pl, pu);
+        } else if (mode != 0 && rest >= 4096)
             hipLaunchKernelGGL(k_closest_expand<4>, dim3((unsigned)((rest + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream,
                                pp, rest, d_vertices, nv, d_faces, nf, ph, pf, pt, pl, pu);
         else
