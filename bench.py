@@ -789,6 +789,7 @@ def run_emulation(args):
 
     # ---- the peers' records and the expected dense results, outside the clock ----------------------
     peer_records = torch.empty((n_total, 3), dtype=torch.int32, device=dev)
+    slots = os.environ.get("TRIRO_PACKED_SLOTS", "1") != "0"      # the record form ShardedRayMeshIntersector will expand
     expected = []
     peer_ms = 0.0
     for k in range(N):
@@ -799,15 +800,15 @@ def run_emulation(args):
             continue
         if k > 0:
             for _ in range(3):
-                r.intersects_closest_packed(ok_, dk_, out=peer_records[a:z])
+                r.intersects_closest_packed(ok_, dk_, out=peer_records[a:z], slots=slots)
             if k == 1:      # what a peer's step costs (its trace into records; it sends them asynchronously)
                 reps = 20 if z - a < (1 << 22) else 5
                 for _ in range(reps if z - a < (1 << 22) else 2):
-                    r.intersects_closest_packed(ok_, dk_, out=peer_records[a:z])
+                    r.intersects_closest_packed(ok_, dk_, out=peer_records[a:z], slots=slots)
                 sync()
                 t0 = time.perf_counter()
                 for _ in range(reps):
-                    r.intersects_closest_packed(ok_, dk_, out=peer_records[a:z])
+                    r.intersects_closest_packed(ok_, dk_, out=peer_records[a:z], slots=slots)
                 sync()
                 peer_ms = (time.perf_counter() - t0) / reps * 1e3
         expected.append([x.reshape(z - a, *x.shape[ok_.dim() - 1:]).clone() for x in r.intersects_closest(ok_, dk_)])
@@ -867,11 +868,11 @@ def run_emulation(args):
     flat = [x.reshape(n_total, *x.shape[len(bshape):]) for x in out]
     pa, pz = bounds[1][0], bounds[-1][1]
     for _ in range(5):
-        r.closest_expand(peer_records[pa:pz], outs=tuple(x[pa:pz] for x in flat))
+        r.closest_expand(peer_records[pa:pz], outs=tuple(x[pa:pz] for x in flat), slots=slots)
     sync()
     t0 = time.perf_counter()
     for _ in range(20):
-        r.closest_expand(peer_records[pa:pz], outs=tuple(x[pa:pz] for x in flat))
+        r.closest_expand(peer_records[pa:pz], outs=tuple(x[pa:pz] for x in flat), slots=slots)
     sync()
     expand_ms = (time.perf_counter() - t0) / 20 * 1e3
     # ---- verification: every row against a dense trace of that rank's rays ---------------------------
@@ -903,7 +904,7 @@ def run_emulation(args):
                                f"({args.rays if args.workload == 'c5i' else 'hash'} rays), headline mesh {len(f)} tris",
                    "rays_total": n_total, "rays_rank0": bounds[0][1] - bounds[0][0], "rays_peer": bounds[1][1] - bounds[1][0],
                    "dst_share": share, "chunks": args.chunks or "auto", "arrival_priority": bool(args.arrival_priority),
-                   "arrival": args.arrival, "opts": list(args.opt)},
+                   "arrival": args.arrival, "opts": list(args.opt), "record_form": "slot" if slots else "face"},
         "emulation": {"plain_1gpu_ms_per_step": round(plain_ms, 4), "plain_1gpu_rays": plain_n,
                       "rank0_ms_per_step": round(rank0_ms, 4), "rank0_own_trace_only_ms": round(own_ms, 4),
                       "peer_trace_ms_per_step": round(peer_ms, 4), "expansion_alone_ms": round(expand_ms, 4),

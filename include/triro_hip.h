@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define TR_ABI_VERSION 6
+#define TR_ABI_VERSION 7
 #define TR_MAX_ANYHIT_SIZE 8 /* LaunchParams.h:8  (per-ray cap of intersects_location) */
 #define TR_MAX_SIZE_LENGTH 4 /* LaunchParams.h:9  (ray tensors have <= 4 dims)         */
 #define TR_MAX_HITS_CAP 32   /* largest `cap` tr_intersects_location_fill accepts      */
@@ -167,6 +167,18 @@ int tr_intersects_closest_packed(const tr_bvh *bvh, const tr_rays *rays, tr_pack
 int tr_closest_expand(const tr_packed_hit *d_packed, int64_t n, const float *d_vertices, int64_t nv,
                       const int32_t *d_faces, int64_t nf, uint8_t *d_hit, uint8_t *d_front,
                       int32_t *d_tri, float *d_loc, float *d_uv, void *stream);
+
+/* ... the same with the ARENA SLOT of the hit triangle in place of the face index (ABI 7): the destination rank of a
+ *    sharded run then reads ONE 48-byte triangle record per hit (vertices + face index, Morton-ordered: rays that hit
+ *    neighbouring triangles read neighbouring records) instead of a face row and three vertex rows in four different
+ *    cache lines -- the expansion is bound by the lines its gathers pull through the fabric (profiles/
+ *    r04_expand_micro.jsonl).  Slots are only meaningful for the hierarchy that produced them or a bit-identical
+ *    replica of it: same mesh, same build options (the builder is deterministic: DESIGN.md 4.1).  Same outputs, bit
+ *    for bit, as tr_closest_expand on the face form.                                                        */
+int tr_intersects_closest_packed_slots(const tr_bvh *bvh, const tr_rays *rays, tr_packed_hit *d_packed,
+                                       void *stream);
+int tr_closest_expand_slots(const tr_bvh *bvh, const tr_packed_hit *d_packed, int64_t n, uint8_t *d_hit,
+                            uint8_t *d_front, int32_t *d_tri, float *d_loc3, float *d_uv2, void *stream);
 
 /* -- multi-hit (intersectsLocation, ray.cpp:324-378):
  *    tr_hits_scan replaces the torch glue of ray.cpp:333-342: d_offsets[i] = exclusive

@@ -91,7 +91,24 @@ for name, rec in (("all-miss records", miss), ("image records (55 % hits)", img)
             hops.set_option("expand4", mode)
             sec = timeit(lambda: r.closest_expand(rr, outs=outs), reps=10)
             out(what=name, mode=mode, rays=rays, ms=round(sec * 1e3, 4), gbps=round(rays * 38 / sec / 1e9, 1))
-        # how much of it is the five output streams?  hit / front / tri only, then loc / uv only
-        hops.set_option("expand4", 0)
         del outs
 hops.set_option("expand4", 1)
+# slot form: one 48-byte triangle record per hit
+recs = []
+for k in range(7):
+    d = torch.from_numpy(np.roll(d_np, k * 7 + 7, axis=0)).to(dev)
+    recs.append(r.intersects_closest_packed(o, d, slots=True))
+img_s = torch.cat(recs)
+for rays, rr in ((n, img_s),) + (((93_000_000, img_s.repeat(13, 1)[:93_000_000]),) if a.big else ()):
+    outs = outs_for(rays)
+    sec = timeit(lambda: r.closest_expand(rr, outs=outs, slots=True), reps=10)
+    out(what="image records, SLOT form", rays=rays, ms=round(sec * 1e3, 4), gbps=round(rays * 38 / sec / 1e9, 1))
+    del outs
+# incoherent hits: the records of 12.5 M hash rays (a C5(ii) shard), both forms
+ho, hd = W.hash_rays_torch(12_500_000, 99, v.min(0) * 1.5, v.max(0) * 1.5, device=dev)
+for slots in (False, True):
+    rec = r.intersects_closest_packed(ho, hd, slots=slots)
+    outs = outs_for(rec.shape[0])
+    sec = timeit(lambda: r.closest_expand(rec, outs=outs, slots=slots), reps=10)
+    out(what="C5(ii) shard records, " + ("SLOT" if slots else "face") + " form", rays=rec.shape[0], hit_fraction=round(float((rec[:, 0] >= 0).float().mean()), 4),
+        ms=round(sec * 1e3, 4), gbps=round(rec.shape[0] * 38 / sec / 1e9, 1))

@@ -382,6 +382,63 @@ void sim_steps_bottom(const void* nodes, const void* links, const void* tris, in
 }
 #endif
 
+// Packet statistics of the UNORDERED (count) traversal for groups of `group` consecutive rays (a wave: the caller
+// hands the rays in wave order, e.g. 8x8 pixel tiles): per group
+//   out[0] = node visits summed over the rays          (what per-lane traversal pays in lane-visits)
+//   out[1] = node visits of the slowest ray            (>= the wave-trips of the per-lane kernel's node phase)
+//   out[2] = distinct nodes visited by ANY ray         (= the trips of a wave-packet traversal: one node per trip)
+//   out[3] = leaf tests summed over the rays, out[4] = leaf tests of the busiest ray, out[5] = distinct leaves
+// (scripts/round4/exp_packet_count.py: is a packet traversal for count / location on image tiles worth building?)
+void sim_packet_stats(const void* nodes_, int64_t nf, const float* o, const float* d, int64_t n, int group, int64_t* out) {
+    const tr_node* nodes = (const tr_node*)nodes_;
+    std::vector<tr_ray> rays((size_t)group);
+    std::vector<int32_t> per_ray((size_t)group), per_ray_leaf((size_t)group);
+    std::vector<int32_t> stack;
+    std::vector<uint64_t> masks;       // per stack entry: which rays of the group reach the node
+    for (int64_t g = 0; g * group < n; g++) {
+        const int m = (int)((g + 1) * group <= n ? group : n - g * group);
+        uint64_t all = 0;
+        for (int k = 0; k < m; k++) {
+            const int64_t i = g * group + k;
+            if (tr_ray_setup(rays[k], o[3 * i], o[3 * i + 1], o[3 * i + 2], d[3 * i], d[3 * i + 1], d[3 * i + 2])) all |= 1ull << k;
+            per_ray[k] = 0; per_ray_leaf[k] = 0;
+        }
+        int64_t sum = 0, uni = 0, lsum = 0, luni = 0;
+        stack.clear(); masks.clear();
+        if (nf >= 2 && all) { stack.push_back(0); masks.push_back(all); }
+        while (!stack.empty()) {
+            const int32_t nd = stack.back(); stack.pop_back();
+            const uint64_t mk = masks.back(); masks.pop_back();
+            uni++;
+            const tr_node& N = nodes[nd];
+            uint64_t h0 = 0, h1 = 0;
+            for (int k = 0; k < m; k++) {
+                if (!((mk >> k) & 1ull)) continue;
+                per_ray[k]++; sum++;
+                float tn0, tf0, tn1, tf1;
+                const tr_f4* np = reinterpret_cast<const tr_f4*>(&N);
+                tr_node_slabs(rays[k], np[0], np[1], np[2], tn0, tf0, tn1, tf1);
+                if (tr_slab_hit(tn0, tf0, TR_TMAX)) h0 |= 1ull << k;
+                if (tr_slab_hit(tn1, tf1, TR_TMAX)) h1 |= 1ull << k;
+            }
+            const int32_t cs[2] = {N.c0, N.c1};
+            const uint64_t hs[2] = {h0, h1};
+            for (int e = 0; e < 2; e++) {
+                if (!hs[e]) continue;
+                if (cs[e] >= 0) { stack.push_back(cs[e]); masks.push_back(hs[e]); }
+                else {
+                    luni++;
+                    for (int k = 0; k < m; k++) if ((hs[e] >> k) & 1ull) { per_ray_leaf[k]++; lsum++; }
+                }
+            }
+        }
+        int32_t mx = 0, lmx = 0;
+        for (int k = 0; k < m; k++) { mx = per_ray[k] > mx ? per_ray[k] : mx; lmx = per_ray_leaf[k] > lmx ? per_ray_leaf[k] : lmx; }
+        out[6 * g + 0] = sum; out[6 * g + 1] = mx; out[6 * g + 2] = uni;
+        out[6 * g + 3] = lsum; out[6 * g + 4] = lmx; out[6 * g + 5] = luni;
+    }
+}
+
 // multi-hit: counts[i] hits (uncapped), first min(count,cap) nearest written at i*cap
 void sim_location(const void* nodes, const void* links, const void* tris, int64_t nf, const float* o,
                   const float* d, int64_t n, int32_t cap, int32_t* count, int32_t* tri_out, float* t_out) {

@@ -38,6 +38,7 @@ def lib():
         L.sim_use_fused.argtypes = [C.c_int]
         L.sim_use_unordered.argtypes = [C.c_int]
         L.sim_steps.argtypes = [C.c_void_p] * 3 + [C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        L.sim_packet_stats.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -110,6 +111,16 @@ class SimBVH:
         lib().sim_steps(self.nodes.ctypes.data, self.links.ctypes.data, self.tris.ctypes.data, self.nf,
                         o.ctypes.data, d.ctypes.data, n, nv.ctypes.data, tt.ctypes.data)
         return nv, tt
+
+    def packet_stats(self, o, d, group=64):
+        """per group of `group` consecutive rays: [lane-visits, slowest ray's visits, distinct nodes, leaf tests, busiest
+        ray's leaf tests, distinct leaves] of the unordered (count) traversal on the exact nodes (sim_packet_stats)"""
+        o = np.ascontiguousarray(o, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)
+        n = len(o)
+        out = np.zeros(((n + group - 1) // group, 6), np.int64)
+        lib().sim_packet_stats(self.nodes.ctypes.data, self.nf, o.ctypes.data, d.ctypes.data, n, group, out.ctypes.data)
+        return out
 
     def location(self, o, d, cap=8):
         lib().sim_set_qnodes(self.qnodes.ctypes.data, self.frame.ctypes.data)

@@ -118,6 +118,43 @@ def test_vectorised_expansion_matches_the_scalar_kernel_and_the_dense_trace(devi
     assert not bool(hit[::7].any())
 
 
+def test_slot_form_records_expand_to_the_dense_outputs(device):
+    """ABI 7: records that name the arena slot of the triangle (intersects_closest_packed(slots=True)) expand -- one
+    48-byte triangle record per hit -- to the bits of intersects_closest; a second intersector built from the same
+    mesh is a bit-identical replica and expands them just the same (what the destination rank of a sharded run does)"""
+    from triro.ray.ray_optix import RayMeshIntersector
+    v, f = W.headline_mesh(6)
+    mk = lambda: RayMeshIntersector(vertices=torch.from_numpy(v).to(device), faces=torch.from_numpy(f).to(device))  # noqa: E731
+    r, replica = mk(), mk()
+    rad = float(np.linalg.norm(v, axis=1).max())
+    o_np, d_np = W.pinhole_grid(301, 203, distance=2.5 * rad)
+    o = torch.from_numpy(np.ascontiguousarray(o_np)).to(device)
+    d = torch.from_numpy(d_np).to(device)
+    lo, hi = v.min(0) * 1.5, v.max(0) * 1.5
+    ho, hd = W.hash_rays_torch(3_000_001, 99, lo, hi, device=device)          # the streaming launch writes records too
+    for oo, dd in ((o, d), (ho, hd)):
+        exp = r.intersects_closest(oo, dd)
+        rec_s = r.intersects_closest_packed(oo, dd, slots=True)
+        rec_f = r.intersects_closest_packed(oo, dd)
+        assert torch.equal(rec_s[:, 1:], rec_f[:, 1:]) and torch.equal(rec_s[:, 0] < 0, rec_f[:, 0] < 0)
+        assert not torch.equal(rec_s[:, 0], rec_f[:, 0])                        # slots are not face indices
+        b = oo.shape[:-1]
+        for who in (r, replica):
+            got = who.closest_expand(rec_s, batch_shape=b, slots=True)
+            for a, e in zip(got, exp):
+                assert torch.equal(a, e)
+        # small and unaligned row ranges (the one-ray kernel), corrupt slots
+        n = rec_s.shape[0]
+        flat = [x.reshape(n, *x.shape[len(b):]) for x in exp]
+        for lo_, hi_ in ((0, 5), (3, 4000), (7, 5000 + 7)):
+            got = r.closest_expand(rec_s[lo_:hi_].contiguous(), slots=True)
+            for a, e in zip(got, flat):
+                assert torch.equal(a, e[lo_:hi_])
+        bad = rec_s.clone()
+        bad[::5, 0] = 0x3fffffff
+        assert not bool(r.closest_expand(bad, slots=True)[0].reshape(-1)[::5].any())
+
+
 def test_destination_traces_dense_in_place(device):
     """intersects_closest_into: rows of preallocated full-size outputs == the ordinary call"""
     from triro.ray.ray_optix import RayMeshIntersector

@@ -39,6 +39,7 @@ struct QueryOut {
     tr_hit_entry* hits;   // TR_Q_LOCATION: [n, cap] unsorted nearest hits (tr_topk<0>)
     int32_t cap;
     tr_packed_hit* packed;   // TR_Q_CLOSEST: when set, 12 bytes per ray instead of the five arrays
+    int packed_slots;        // ... with the arena slot of the triangle instead of its face index (tr_intersects_closest_packed_slots)
 };
 
 // strided fetch of ray `idx`: the reference's getRay/getIndices (shaders.cu:27-63) with
@@ -89,7 +90,7 @@ __device__ __forceinline__ void write_result(const tr_bvh_view& b, const QueryOu
                 tr_hit h; h.t = res.best_t;
                 tr_tri_duv(r, t.ax, t.ay, t.az, t.bx, t.by, t.bz, t.cx, t.cy, t.cz, h.det, h.U, h.V);
                 tr_hit_bary(h, ph.u, ph.v);
-                ph.tri = (uint32_t)res.best_face | (h.det > 0.f ? 0x40000000u : 0u);
+                ph.tri = (uint32_t)(out.packed_slots ? res.best_slot : res.best_face) | (h.det > 0.f ? 0x40000000u : 0u);
             }
             out.packed[i] = ph;
             return;
@@ -1490,6 +1491,57 @@ __global__ __launch_bounds__(256) void k_closest_expand_buf(const tr_packed_hit*
     }
 }
 
+// Slot form (tr_closest_expand_slots): the record names the arena slot of the triangle; ONE 48-byte triangle record
+// (three 16-byte buffer loads, out of range = a miss = no memory access) holds the vertices and the face index.
+template <int R>
+__global__ __launch_bounds__(256) void k_closest_expand_slots(const tr_packed_hit* __restrict__ packed, int64_t n,
+                                                              const tr_tri* __restrict__ tris, int64_t nt,
+                                                              uint8_t* __restrict__ hit, uint8_t* __restrict__ front,
+                                                              int32_t* __restrict__ tri, float* __restrict__ loc,
+                                                              float* __restrict__ uv) {
+    typedef int tr_v4i __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc((void*)tris, 0, (int)(nt * (int64_t)sizeof(tr_tri)), 0x00020000);
+    for (int64_t i0 = (int64_t)blockIdx.x * (256 * R) + threadIdx.x; i0 < n; i0 += (int64_t)gridDim.x * (256 * R)) {
+        tr_packed_hit ph[R];
+        bool ok[R];
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            const int64_t i = i0 + 256 * k;
+            ph[k] = packed[i < n ? i : i0];
+        }
+        tr_v4i q0[R], q1[R], q2[R];
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            const uint32_t slot = ph[k].tri & 0x3fffffffu;
+            ok[k] = !(ph[k].tri & 0x80000000u) && (int64_t)slot < nt && i0 + 256 * k < n;
+            const uint32_t off = ok[k] ? slot * (uint32_t)sizeof(tr_tri) : 0xffffffffu;
+            q0[k] = __builtin_amdgcn_raw_buffer_load_b128(trs, off, 0, 0);
+            q1[k] = __builtin_amdgcn_raw_buffer_load_b128(trs, ok[k] ? off + 16u : 0xffffffffu, 0, 0);
+            q2[k] = __builtin_amdgcn_raw_buffer_load_b128(trs, ok[k] ? off + 32u : 0xffffffffu, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            const int64_t i = i0 + 256 * k;
+            if (i >= n) continue;
+            float l3[3] = {0.f, 0.f, 0.f}, u2[2] = {0.f, 0.f};
+            uint8_t h = 0, fr = 0;
+            int32_t t = -1;
+            if (ok[k]) {
+                // record layout (tr_tri): ax ay az bx | by bz cx cy | cz face . .
+                tr_bary_outputs(ph[k].u, ph[k].v, __int_as_float(q0[k].x), __int_as_float(q0[k].y), __int_as_float(q0[k].z),
+                                __int_as_float(q0[k].w), __int_as_float(q1[k].x), __int_as_float(q1[k].y),
+                                __int_as_float(q1[k].z), __int_as_float(q1[k].w), __int_as_float(q2[k].x), l3, u2);
+                h = 1; fr = (ph[k].tri >> 30) & 1u; t = q2[k].y;
+            }
+            if (hit) hit[i] = h;
+            if (front) front[i] = fr;
+            if (tri) tri[i] = t;
+            if (loc) { loc[3 * i] = l3[0]; loc[3 * i + 1] = l3[1]; loc[3 * i + 2] = l3[2]; }
+            if (uv) { uv[2 * i] = u2[0]; uv[2 * i + 1] = u2[1]; }
+        }
+    }
+}
+
 // (option expand4 = 2; measured SLOWER than one ray per thread -- 1.49 against 2.49 TB/s on 7.3 M rays,
 // profiles/r04_emulate_run1.jsonl: a wave's 16-byte accesses at a 48-byte stride touch every line three times and
 // the non-temporal hints keep them from merging -- kept for the record and for A/B runs.)
@@ -2399,6 +2451,38 @@ int tr_closest_expand(const tr_packed_hit* d_packed, int64_t n, const float* d_v
         else
             hipLaunchKernelGGL(k_closest_expand<1>, dim3((unsigned)((rest + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                                pp, rest, d_vertices, nv, d_faces, nf, ph, pf, pt, pl, pu);
+    }
+    TR_HIP_TRY(hipGetLastError());
+    return TR_OK;
+}
+
+int tr_intersects_closest_packed_slots(const tr_bvh* bvh, const tr_rays* rays, tr_packed_hit* d_packed, void* stream) {
+    if (rays && rays->nray > 0 && !d_packed) return tr_fail(TR_ERR_INVALID_ARG, "d_packed == NULL");
+    if (bvh && bvh->num_tris >= ((int64_t)1 << 30)) return tr_fail(TR_ERR_INVALID_ARG, "packed results hold triangle slots below 2^30");
+    QueryOut out = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, d_packed, 1};
+    return launch_query<TR_Q_CLOSEST, false>(bvh, rays, out, nullptr, (hipStream_t)stream);
+}
+
+int tr_closest_expand_slots(const tr_bvh* bvh, const tr_packed_hit* d_packed, int64_t n, uint8_t* d_hit, uint8_t* d_front,
+                            int32_t* d_tri, float* d_loc, float* d_uv, void* stream) {
+    if (!bvh) return tr_fail(TR_ERR_INVALID_ARG, "bvh == NULL");
+    if (n < 0) return tr_fail(TR_ERR_INVALID_ARG, "negative size");
+    if (n == 0) return TR_OK;
+    if (!d_packed) return tr_fail(TR_ERR_INVALID_ARG, "d_packed == NULL");
+    if (bvh->num_tris * (int64_t)sizeof(tr_tri) >= ((int64_t)1 << 31)) return tr_fail(TR_ERR_INVALID_ARG, "slot form needs a triangle array below 2 GiB");
+    tr_device_guard guard;
+    TR_TRY(enter_bvh_device(bvh, nullptr, &guard));
+    tr_device_state* st;
+    TR_TRY(tr_get_device_state(bvh->device, &st));
+    const tr_options opt = tr_opts();
+    if (n >= 4096) {
+        int64_t blocks = (n + 1023) / 1024;
+        if (opt.expand_cus > 0 && blocks > (int64_t)st->num_cus * opt.expand_cus) blocks = (int64_t)st->num_cus * opt.expand_cus;
+        hipLaunchKernelGGL(k_closest_expand_slots<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                           d_packed, n, bvh->tris, bvh->num_tris, d_hit, d_front, d_tri, d_loc, d_uv);
+    } else {
+        hipLaunchKernelGGL(k_closest_expand_slots<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           d_packed, n, bvh->tris, bvh->num_tris, d_hit, d_front, d_tri, d_loc, d_uv);
     }
     TR_HIP_TRY(hipGetLastError());
     return TR_OK;

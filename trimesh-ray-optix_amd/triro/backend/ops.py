@@ -30,7 +30,7 @@ MAX_ANYHIT_SIZE = 8   # LaunchParams.h:8
 MAX_SIZE_LENGTH = 4   # LaunchParams.h:9
 
 _LIB_NAME = "libtriro_hip.so"
-ABI_VERSION = 6     # TR_ABI_VERSION of include/triro_hip.h this binding was written against
+ABI_VERSION = 7     # TR_ABI_VERSION of include/triro_hip.h this binding was written against
 _lib = None
 _lib_error = None
 
@@ -91,6 +91,8 @@ ABI = {
     "tr_intersects_count": (_int, [_vp, C.POINTER(TrRays), _vp, _vp]),
     "tr_intersects_closest_packed": (_int, [_vp, C.POINTER(TrRays), _vp, _vp]),
     "tr_closest_expand": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tr_intersects_closest_packed_slots": (_int, [_vp, C.POINTER(TrRays), _vp, _vp]),
+    "tr_closest_expand_slots": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tr_hits_scan": (_int, [_vp, _i64, _i32, _vp, _vp, C.POINTER(_i64), _vp]),
     "tr_intersects_location_fill": (_int, [_vp, C.POINTER(TrRays), _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
     "tr_intersects_count_topk": (_int, [_vp, C.POINTER(TrRays), _i32, _vp, _vp, _vp]),
@@ -262,7 +264,7 @@ def intersects_closest(accel_structure, origins, dirs, outs=None) -> Tuple[torch
     return hit, front, tri, loc, uv
 
 
-def intersects_closest_packed(accel_structure, origins, dirs, out: torch.Tensor = None) -> torch.Tensor:
+def intersects_closest_packed(accel_structure, origins, dirs, out: torch.Tensor = None, slots: bool = False) -> torch.Tensor:
     """Closest hit as 12 bytes per ray: int32 [n, 3] rows {face | front << 30 (-1 on a miss), u bits,
     v bits} (tr_packed_hit).  What a ray-sharded run sends over xGMI instead of the 26 B/ray of the five
     dense outputs; `closest_expand` rebuilds those bit for bit.  `out`: optional preallocated [n, 3]
@@ -273,10 +275,39 @@ def intersects_closest_packed(accel_structure, origins, dirs, out: torch.Tensor 
         out = torch.empty((n, 3), dtype=torch.int32, device=dev)
     elif out.dtype != torch.int32 or tuple(out.shape) != (n, 3) or not out.is_contiguous() or out.device != dev:
         raise ValueError("out must be a contiguous int32 [n, 3] tensor on the rays' device")
+    # slots: the record names the ARENA SLOT of the triangle instead of its face index (tr_intersects_closest_packed_slots):
+    # cheaper to expand (closest_expand_slots), valid only for this hierarchy or a bit-identical replica of it
+    fn = get_module().tr_intersects_closest_packed_slots if slots else get_module().tr_intersects_closest_packed
     with torch.cuda.device(dev):
-        _check(get_module().tr_intersects_closest_packed(_handle(accel_structure, origins), C.byref(make_rays(origins, dirs)),
-                                                         out.data_ptr(), _stream_ptr(dev)))
+        _check(fn(_handle(accel_structure, origins), C.byref(make_rays(origins, dirs)), out.data_ptr(), _stream_ptr(dev)))
     return out
+
+
+def closest_expand_slots(accel_structure, packed: torch.Tensor, batch_shape=None, outs=None):
+    """tr_closest_expand_slots: slot-form records (intersects_closest_packed(..., slots=True), of this hierarchy or of a
+    bit-identical replica) -> (hit, front, tri_idx, loc, uv), bit-identical to intersects_closest on the same rays."""
+    if packed.dtype != torch.int32 or packed.dim() != 2 or packed.shape[1] != 3 or not packed.is_contiguous() or not packed.is_cuda:
+        raise ValueError("packed must be a contiguous int32 [n, 3] tensor on the GPU")
+    dev, n = packed.device, packed.shape[0]
+    if outs is not None:
+        want = ((torch.bool, (n,)), (torch.bool, (n,)), (torch.int32, (n,)), (torch.float32, (n, 3)), (torch.float32, (n, 2)))
+        if len(outs) != 5 or any(t.dtype != dt or tuple(t.shape) != sh or not t.is_contiguous() or t.device != dev
+                                 for t, (dt, sh) in zip(outs, want)):
+            raise ValueError("outs must be contiguous (bool[n], bool[n], int32[n], float32[n,3], float32[n,2]) on the device of packed")
+        hit, front, tri, loc, uv = outs
+    else:
+        b = tuple(batch_shape) if batch_shape is not None else (n,)
+        hit = torch.empty(b, dtype=torch.bool, device=dev)
+        front = torch.empty(b, dtype=torch.bool, device=dev)
+        tri = torch.empty(b, dtype=torch.int32, device=dev)
+        loc = torch.empty((*b, 3), dtype=torch.float32, device=dev)
+        uv = torch.empty((*b, 2), dtype=torch.float32, device=dev)
+        if hit.numel() != n:
+            raise ValueError(f"batch_shape {b} does not hold {n} rays")
+    with torch.cuda.device(dev):
+        _check(get_module().tr_closest_expand_slots(_handle(accel_structure, packed), packed.data_ptr(), n, hit.data_ptr(),
+                                                    front.data_ptr(), tri.data_ptr(), loc.data_ptr(), uv.data_ptr(), _stream_ptr(dev)))
+    return hit, front, tri, loc, uv
 
 
 def closest_expand(packed: torch.Tensor, vertices: torch.Tensor, faces: torch.Tensor, batch_shape=None, outs=None):

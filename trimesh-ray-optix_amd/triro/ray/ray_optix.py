@@ -116,14 +116,21 @@ class RayMeshIntersector:
         straight into its rows of the full-size results (triro.ray.sharded; not in the reference)."""
         return hops.intersects_closest(self.as_wrapper, origins, directions, outs=outs)
 
-    def intersects_closest_packed(self, origins, directions, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Closest hit as int32 [n, 3] rows {tri_idx | front << 30 (-1: miss), u bits, v bits}: 12 bytes
-        per ray (not in the reference; what a ray-sharded run sends over xGMI, triro.ray.sharded)."""
-        return hops.intersects_closest_packed(self.as_wrapper, origins, directions, out)
+    packed_slots = True     # this tracer offers the slot form of the packed records (triro.ray.sharded)
 
-    def closest_expand(self, packed: torch.Tensor, batch_shape=None, outs=None):
+    def intersects_closest_packed(self, origins, directions, out: Optional[torch.Tensor] = None, slots: bool = False) -> torch.Tensor:
+        """Closest hit as int32 [n, 3] rows {tri_idx | front << 30 (-1: miss), u bits, v bits}: 12 bytes
+        per ray (not in the reference; what a ray-sharded run sends over xGMI, triro.ray.sharded).
+        slots=True: the arena slot of the triangle in place of tri_idx -- only meaningful for this acceleration
+        structure or a bit-identical replica (same mesh, same options; the builder is deterministic), and
+        cheaper to expand there (closest_expand(..., slots=True))."""
+        return hops.intersects_closest_packed(self.as_wrapper, origins, directions, out, slots)
+
+    def closest_expand(self, packed: torch.Tensor, batch_shape=None, outs=None, slots: bool = False):
         """packed rows -> (hit, front, tri_idx, loc, uv), bit-identical to intersects_closest on the same
         rays; uses this intersector's mesh (any rank's replica will do: the meshes are identical)."""
+        if slots:
+            return hops.closest_expand_slots(self.as_wrapper, packed, batch_shape, outs)
         dev = packed.device
         v = self.mesh_vertices if self.mesh_vertices.device == dev else self.mesh_vertices.to(dev)
         f = self.mesh_faces if self.mesh_faces.device == dev else self.mesh_faces.to(dev)

@@ -182,6 +182,10 @@ class ShardedRayMeshIntersector:
         else:
             self._stage_cpu_too = bool(stage_through_host)
         self._stage = bool(stage_through_host)
+        # slot form of the packed records (RayMeshIntersector.packed_slots): the destination reads one 48-byte triangle
+        # record per hit instead of four rows in four cache lines; needs bit-identical replicas on all ranks (same
+        # mesh, same build options -- the builder is deterministic).  TRIRO_PACKED_SLOTS=0 keeps the face form.
+        self.slots = bool(getattr(local, "packed_slots", False)) and os.environ.get("TRIRO_PACKED_SLOTS", "1") != "0"
         self._side = None      # side stream of the destination rank (wait for chunk, expand)
 
     # ---- helpers -------------------------------------------------------------------------
@@ -446,7 +450,10 @@ class ShardedRayMeshIntersector:
                 if dense_mine:
                     self.local.intersects_closest_into(ok, dk, tuple(x[lo + a:lo + z] for x in flat_outs))
                 else:
-                    self.local.intersects_closest_packed(ok, dk, out=mine[a:z])
+                    if self.slots:
+                        self.local.intersects_closest_packed(ok, dk, out=mine[a:z], slots=True)
+                    else:
+                        self.local.intersects_closest_packed(ok, dk, out=mine[a:z])
             if world > 1 or self.force_collectives:
                 if dense_mine:
                     # nothing of this rank travels: it only receives (its own rows of packed_all stay unused)
@@ -469,7 +476,10 @@ class ShardedRayMeshIntersector:
                         else:
                             merged.append((ra, rz))
                     for ra, rz in merged:
-                        self.local.closest_expand(packed_all[ra:rz], outs=tuple(x[ra:rz] for x in flat_outs))
+                        if self.slots:
+                            self.local.closest_expand(packed_all[ra:rz], outs=tuple(x[ra:rz] for x in flat_outs), slots=True)
+                        else:
+                            self.local.closest_expand(packed_all[ra:rz], outs=tuple(x[ra:rz] for x in flat_outs))
                 if side is not None:
                     # the side stream runs behind the exchange of chunk k AND -- when this rank's own rows are records
                     # too -- behind the caller's stream (the local trace of chunk k fills them); `cur` was taken
@@ -586,7 +596,7 @@ class EmulatedWorld(ShardedRayMeshIntersector):
             dst_share = auto_dst_share(self.world) if dst_share == "auto" else float(dst_share)
         self.dst_share = dst_share
         self.force_collectives = True
-        self.peer_records = peer_records
+        self.peer_records = peer_records      # (slot form when self.slots: bench.py traces them accordingly)
         self._copy = None
         # arrival: "copy" = device-to-device copies on a copy stream (blit kernels: they take CUs and read as much
         # as they write -- a pessimistic stand-in for an xGMI receive); "none" = the records are simply there
