@@ -264,7 +264,8 @@ int tr_trace_stats_query(const tr_bvh *bvh, const tr_rays *rays, int query, tr_t
  *    32-byte grid nodes -- two 16-byte loads per visit -- instead of the exact 64-byte nodes).
  *    "wide" (0 never / 1 always / 2 where measured faster -- meshes from 3 M triangles on, count launches from 1 M on: the streaming launch walks 8-wide nodes with 8-bit child boxes -- three levels of the binary
  *    hierarchy collapsed into one 96-byte record, built on the first streaming query after a build / refit / load),
- *    "wide_stack" (1..12: entries of a lane's node stack kept in LDS; the rest spills to global memory).
+ *    "wide_direct" (0 never / 1 multi-hit list launches on meshes from 500 k triangles on / 2 count and location / 3 every query: the direct launch -- tiles, learned order -- walks
+ *    the 8-wide nodes with the per-lane two-stack walk of the streaming launch), "wide_stack" (1..12: entries of a lane's node stack kept in LDS; the rest spills to global memory).
  *    "expand4" (tr_closest_expand: 0 one ray per thread / 1 four rays per thread, 256 apart, mesh rows through buffer
  *    loads so that misses fetch nothing / 2 four adjacent rays per thread with 16-byte accesses where the rows are
  *    aligned / 3 tiles of 1024 rays staged through LDS), "expand_cus" (0 = one workgroup per 1024 rays; N = at most N

@@ -6,6 +6,7 @@
            c4 (4 nested shells 1 310 720 tris, 1024^2 pinhole), c5i (headline mesh, 1024^2 pinhole; --res),
            c5s (headline mesh, one 12.5 M-ray shard of the 100 M hash rays)
            terrain (workloads.terrain(): 1 048 352-tri height field, grazing camera, 16:9 rays, --res = width)
+           soup (1 000 000 small triangles scattered in a cube, camera outside, 16:9 rays, --res = width)
            room (workloads.interior_room(): 909 088 tris, camera INSIDE, 640x360 rays in the reference's
            published shape -- stride-0 origin; --res scales the image: res x res*9/16)
   queries: closest any first count location closest_compact
@@ -52,6 +53,8 @@ elif a.config == "room":
     v, f = W.interior_room()
 elif a.config == "terrain":
     v, f = W.terrain()
+elif a.config == "soup":
+    v, f = W.random_soup(1_000_000, seed=5, extent=1.0, size=0.02)      # tests/test_gpu_soup.py's cloud
 else:
     v, f = W.headline_mesh(a.subdiv)
 r = RayMeshIntersector(vertices=T(v), faces=T(f))
@@ -62,11 +65,12 @@ if a.config == "c3":
 elif a.config == "c5s":
     n = 100_000_000 // 8
     o, d = W.hash_rays_torch(n, 99, v.min(0) * 1.5, v.max(0) * 1.5, device=dev)
-elif a.config in ("room", "terrain"):
+elif a.config in ("room", "terrain", "soup"):
     # the reference's ray shape (16:9, stride-0 origin); --res = image width (default 640; terrain also 1024 ...)
     w = 640 if (a.res == 1024 and a.config == "room") else a.res
     h = w * 9 // 16
-    eye, target = (W.INTERIOR_EYE, W.INTERIOR_TARGET) if a.config == "room" else (W.TERRAIN_EYE, W.TERRAIN_TARGET)
+    eye, target = {"room": (W.INTERIOR_EYE, W.INTERIOR_TARGET), "terrain": (W.TERRAIN_EYE, W.TERRAIN_TARGET),
+                   "soup": ((-2.2, 0.6, -1.8), (0.2, -0.1, 0.1))}[a.config]
     _, dn = W.ref_shape_rays(eye, target, w, h, 444.0 * w / 640)
     o = torch.from_numpy(np.array(eye, np.float32)).to(dev).expand(h, w, 3)
     d = T(dn)

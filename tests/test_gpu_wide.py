@@ -20,7 +20,7 @@ def opts():
             saved.setdefault(k, None)
             hops.set_option(k, v)
     yield set_
-    defaults = {"stream": 1, "wide": 2, "wide_stack": 12, "stream_rays": 256, "stream_refill": 32}
+    defaults = {"stream": 1, "wide": 2, "wide_stack": 12, "stream_rays": 256, "stream_refill": 32, "wide_direct": 1, "adaptive": 1}
     for k in saved:
         hops.set_option(k, defaults[k])
 
@@ -126,3 +126,29 @@ def test_wide_on_tiny_and_degenerate_meshes(device, opts):
     r = _mk(base_v, f, device)
     nh, mx = _check_all(r, OracleIntersector(base_v, f, mode=0), o, d, "duplicates")
     assert mx == 43
+
+
+@pytest.mark.parametrize("wide_stack", [12, 3])
+def test_direct_launch_on_wide_nodes_matches_the_oracle(device, opts, wide_stack):
+    """option wide_direct = 3: every query family of the DIRECT launch (image tiles, learned launch order over several
+    launches) on the 8-wide nodes, incl. the multi-hit list (location) with more hits than its cap"""
+    opts(wide_direct=3, wide_stack=wide_stack)
+    for name, (v, f), cam in (("shells", W.nested_shells(5), 2.5), ("sphere", W.headline_mesh(6), None), ("soup", W.random_soup(30_000, seed=5), 4.0)):
+        r = _mk(v, f, device)
+        R = OracleIntersector(v, f, mode=1)
+        dist = cam if cam is not None else 2.5 * float(np.linalg.norm(v, axis=1).max())
+        o_np, d_np = W.pinhole_grid(256, 192, distance=dist)
+        o = torch.from_numpy(np.ascontiguousarray(o_np)).to(device)
+        d = torch.from_numpy(d_np).to(device)
+        for launch in range(5):            # cold order, measured order, re-measured order
+            nh, mx = _check_all(r, R, o, d, (name, wide_stack, launch))
+        assert r.as_wrapper.last_launch()["shape"] == 4
+        loc, ray, tri = r.intersects_location(o, d)
+        el, er, et = R.intersects_location(o_np, d_np)
+        assert np.array_equal(ray.cpu().numpy(), er) and np.array_equal(tri.cpu().numpy(), et), name
+        assert np.array_equal(loc.cpu().numpy(), el), name
+        if name == "soup":
+            assert mx > 8                   # the list replaces entries beyond its cap
+        # flat, ragged batch (no tiles) and a tiny one
+        for m in (1, 63, 5001):
+            _check_all(r, R, o.reshape(-1, 3)[:m].contiguous(), d.reshape(-1, 3)[:m].contiguous(), (name, "flat", m))

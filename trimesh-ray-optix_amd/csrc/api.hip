@@ -52,6 +52,7 @@ const opt_desc OPTS[] = {
     {"expand_cus", &tr_options::expand_cus, 0, 64, false},
     {"wide", &tr_options::wide, 0, 2, false},
     {"wide_stack", &tr_options::wide_stack, 1, 12, false},
+    {"wide_direct", &tr_options::wide_direct, 0, 3, false},
 };
 constexpr int NUM_OPTS = (int)(sizeof(OPTS) / sizeof(OPTS[0]));
 struct opt_store {

@@ -186,6 +186,7 @@ struct tr_options {
     int occ8 = 1;         // stealing closest / first launches on the grid nodes at 8 waves per SIMD (64 registers, slim hand-over scratch): 0 never, 1 from 2 M rays on, 2 always
     int lds_top = 0;      // LDS-staged node packets for closest / first launches that steal: 0 off, 1 at 128-thread blocks, 2 at 256-thread blocks
     int wide = 2;         // the streaming launch walks 8-wide compressed nodes (tr_wide.h; built on first use): 0 never, 1 always, 2 where measured faster (>= 3 M triangles; count from 1 M triangles on)
+    int wide_direct = 1;  // the DIRECT launch on the 8-wide nodes (k_query_direct_wide): 0 never, 1 location launches on meshes >= 500 k triangles (where measured faster), 2 count and location, 3 every query
     int wide_stack = 12;  // ... entries of a lane's node stack kept in LDS (<= 12; the rest lives in a global spill row; tests lower it)
     int expand_cus = 0;   // tr_closest_expand (expand4 = 1): at most this many workgroups per CU, grid-stride beyond (0: one workgroup per 1024 rays)
     int expand4 = 1;      // tr_closest_expand: 0 one ray per thread, 1 four rays per thread 256 apart, rows through buffer loads (misses fetch nothing), 2 four adjacent rays with 16-byte accesses, 3 LDS-staged tiles of 1024 rays

@@ -662,6 +662,8 @@ __device__ __forceinline__ void flush_stats(const tr_counters& c, unsigned long 
     }
 }
 
+#include "traverse_wide.inc"
+
 #ifdef TR_TIMELINE
 // experiment build only (not part of the ABI): TR_TIMELINE = number of wave records kept
 __device__ unsigned long long g_timeline[4 * TR_TIMELINE];
@@ -675,7 +677,8 @@ __device__ __forceinline__ void query_direct_body(const tr_bvh_view& b, const Ra
                                                   const uint32_t* __restrict__ order, int order_split,
                                                   uint32_t* __restrict__ cost,
                                                   unsigned long long* stats,
-                                                  const int* __restrict__ sel) {
+                                                  const int* __restrict__ sel,
+                                                  const tr_wide_args& wa = tr_wide_args{nullptr, nullptr, 0, 0}) {
     // dual launch (k_probe_coherence): this launch shape is the one for coherent batches (id 0)
     if (sel && *sel != 0) return;
 #ifdef TR_LDS_PAD
@@ -689,7 +692,7 @@ __device__ __forceinline__ void query_direct_body(const tr_bvh_view& b, const Ra
     const unsigned long long tl_start = wall_clock64();
 #endif
     const unsigned long long t_start = cost ? wall_clock64() : 0ull;
-    __shared__ int32_t ring_lds[TR_RING * BS];
+    __shared__ int32_t ring_lds[MODE == 4 ? 1 : TR_RING * BS];
     const tr_ring ring = {ring_lds + threadIdx.x, BS};
     // LDS-staged node packets: the top levels of the tree, once per workgroup (4 KiB, L2-resident source)
     __shared__ tr_i4 top_lds[LT ? 2 * TR_TOP_SLOTS : 1];
@@ -758,7 +761,27 @@ __device__ __forceinline__ void query_direct_body(const tr_bvh_view& b, const Ra
 #ifdef TR_TIMELINE
     unsigned long long tl_extra = 0;
 #endif
-    if (MODE == 2) {
+    if (MODE == 4) {
+        // 8-wide compressed nodes, one ray per lane (wave_traverse_wide): count / location / closest / first / any
+        __shared__ int32_t wstack_lds[(TR_WNODES + TR_WLEAVES) * BS];
+        const bool in_range = i < rf.n;
+        float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
+        if (in_range) fetch_ray(rf, i, o, d);
+        tr_ray r;
+        const bool valid = tr_ray_setup(r, o[0], o[1], o[2], d[0], d[1], d[2]) && in_range;
+        tr_result res;
+        if constexpr (Q == TR_Q_LOCATION) {
+            tr_topk<0> top;
+            top.ent = out.hits + (in_range ? i : 0) * out.cap;
+            top.tris = b.tris;
+            top.cap = out.cap;
+            wave_traverse_wide<Q, 0, STATS, BS>(b, wa, r, valid, res, top, cnt, wstack_lds);
+        } else {
+            tr_topk<1> top;
+            wave_traverse_wide<Q, 1, STATS, BS>(b, wa, r, valid, res, top, cnt, wstack_lds);
+        }
+        if (in_range) write_result<Q>(b, out, i, r, res);
+    } else if (MODE == 2) {
         // the steal_min argument carries the leaf-phase vote threshold of this schedule
         __shared__ int32_t leafq_lds[TR_LEAFQ * BS];
         const tr_leafq lq = {leafq_lds + threadIdx.x, BS};
@@ -841,6 +864,17 @@ void k_query_direct_occ8(tr_bvh_view b, RayFetch rf, QueryOut out, int xcd_map, 
                          unsigned long long* stats, const int* __restrict__ sel) {
     query_direct_body<Q, false, true, 128, 1, false, true, false, true>(b, rf, out, xcd_map, scramble, tile_w, steal_min, order,
                                                                         order_split, cost, stats, sel);
+}
+
+// The direct launch on the 8-wide compressed nodes (query_direct_body MODE 4; option wide_direct): the block -> ray
+// map, the tiles and the learned launch order of the direct launch, the per-lane two-stack walk of k_query_wide.
+template <int Q, bool STATS>
+__global__ __launch_bounds__(128) void k_query_direct_wide(tr_bvh_view b, RayFetch rf, QueryOut out, int xcd_map, int scramble,
+                                                           int tile_w, const uint32_t* __restrict__ order, int order_split,
+                                                           uint32_t* __restrict__ cost, unsigned long long* stats,
+                                                           const int* __restrict__ sel, tr_wide_args wa) {
+    query_direct_body<Q, STATS, true, 128, 4, false, false, false, false>(b, rf, out, xcd_map, scramble, tile_w, 0, order, order_split,
+                                                                          cost, stats, sel, wa);
 }
 
 // Order the blocks of the last launch by measured cost, most expensive first: one workgroup,
@@ -1690,8 +1724,6 @@ __global__ __launch_bounds__(256) void k_closest_expand_tile(const tr_u4* __rest
     }
 }
 
-#include "traverse_wide.inc"
-
 // ---- host side ----------------------------------------------------------------------------------
 int make_fetch(const tr_rays* rays, RayFetch* rf) {
     if (!rays) return tr_fail(TR_ERR_INVALID_ARG, "rays == NULL");
@@ -2077,6 +2109,15 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
         // ... with hand-over of owed subtrees between the lanes of a wave and split launch slots (count;
         // wave_count_unordered_steal).  usteal: 0 off, 1 on, >= 2 forced with that trip threshold.
         const bool usteal = unord && Q == TR_Q_COUNT && !STATS && bs == 128 && opt.usteal > 0;
+        // The direct launch on the 8-wide compressed nodes (k_query_direct_wide): its own launch shape -- no stealing, no
+        // split blocks, the plain learned order.  Option wide_direct: 0 never, 1 (default) where measured faster -- the
+        // multi-hit LIST query (the one unordered query that does not steal) on meshes from 500 k triangles on: terrain
+        // location 0.58 -> 0.46 ms, the million-triangle cloud 3.24 -> 3.08, C4 0.934 -> 0.892, but the 82 k-triangle C2
+        // mesh 0.37 -> 0.40 (profiles/r04_policy_*.txt) --, 2 count and location everywhere, 3 every query (closest / first /
+        // any lose 25...50 % without stealing and splitting; count loses 2...20 % to its stealing binary launch)
+        const bool wd_query = opt.wide_direct == 3 || (opt.wide_direct == 2 && (Q == TR_Q_COUNT || Q == TR_Q_LOCATION)) ||
+                              (opt.wide_direct == 1 && Q == TR_Q_LOCATION && bvh->num_tris >= 500000);
+        const bool use_wd = wd_query && addr32 && bs == 128 && bvh->num_tris >= 2 && !opt.persistent;
         // Block splitting: the nblocks >> N most expensive blocks of the previous launch get two launch
         // slots each.  A launch ends with its most expensive waves (scripts/exp_timeline.py: with 8x8
         // tiles everything but ~100 waves of the headline image is done after 215 us of 320), and those
@@ -2106,6 +2147,7 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
             else if (!can_tile8 && nblocks_direct <= 2048) split_shift = 4;
         }
         int64_t split = 0;
+        if (use_wd) split_shift = 0;
         if (split_shift > 0 && (bs == 128 || lt_query) && nblocks_direct >= (opt.split > 1 ? 64 : 512)) split = (nblocks_direct >> split_shift) / 8;
         if (nblocks_direct + 12 * split > TR_SCHED_MAX || !opt.adaptive) split = 0;   // no learned order, no split
         const int64_t split4 = split >> 2;
@@ -2145,7 +2187,24 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
             fprintf(stderr, "[triro] query %d: rays %lld blocks %lld slots %lld tile 0x%x split %lld order %d cost %d steal %d unordered %d compact %d\n",
                     Q, (long long)rf.n, (long long)nblocks_direct, (long long)nslots, (unsigned)tile_w, (long long)split,
                     order != nullptr, cost != nullptr, (int)steal, (int)unord, compact ? 1 : (deep ? 2 : 0));
-        if (unord) {
+        bool wd_launched = false;
+        if (use_wd) {
+            const tr_wnode* wn = ensure_wide(bvh, stream);
+            if (wn) {
+                const int need = 7 * ((bvh->depth + 2) / 3) + 9;
+                const int lds_cap = opt.wide_stack < TR_WSTACK ? opt.wide_stack : TR_WSTACK;
+                const int spill_cap = need > lds_cap ? need - lds_cap : 0;
+                int32_t* spill = spill_cap > 0 ? wide_spill(bvh, stream, (size_t)nslots * 128 * (size_t)spill_cap) : nullptr;
+                if (spill_cap == 0 || spill) {
+                    const tr_wide_args wa = {wn, spill, spill_cap, lds_cap};
+                    hipLaunchKernelGGL((k_query_direct_wide<Q, STATS>), dim3((unsigned)nslots), dim3(128), 0, stream, view, rf, out,
+                                       xc, scramble, tile_w, order, (int)split_key, cost, d_stats, sel, wa);
+                    wd_launched = true;
+                }
+            }
+        }
+        if (wd_launched) {
+        } else if (unord) {
             if constexpr (Q == TR_Q_COUNT || Q == TR_Q_LOCATION || Q == TR_Q_ANY) {
                 const int leaf_min = opt.leaf_vote;
                 if constexpr (Q == TR_Q_COUNT && !STATS) {
@@ -2243,12 +2302,12 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
             std::lock_guard<std::mutex> lock(*mb->sched_mutex);
             tr_launch_info& li = mb->last_launch;
             li.rays = rf.n; li.blocks = nblocks_direct; li.slots = nslots; li.query = Q;
-            li.shape = unord ? (usteal ? 3 : 2) : (steal ? 1 : 0);
+            li.shape = wd_launched ? 4 : (unord ? (usteal ? 3 : 2) : (steal ? 1 : 0));
             li.tile_rows_lg = tile_w ? (tile_w >> 28) & 3 : 0;
             li.split_blocks = order ? (int32_t)split : 0;
             li.reserved = 0;
             li.learned_order = order != nullptr;
-            li.grid_nodes = qn_used || unord;
+            li.grid_nodes = (qn_used || unord) && !wd_launched;
             li.addressing = compact ? 1 : (deep ? 2 : 0);
             mb->have_last_launch = true;
         }
