@@ -867,12 +867,13 @@ def run_emulation(args):
     # expansion alone (all peers' rows, nothing else running)
     flat = [x.reshape(n_total, *x.shape[len(bshape):]) for x in out]
     pa, pz = bounds[1][0], bounds[-1][1]
+    rl = {"row_length": row_quantum} if (slots and row_quantum) else {}
     for _ in range(5):
-        r.closest_expand(peer_records[pa:pz], outs=tuple(x[pa:pz] for x in flat), slots=slots)
+        r.closest_expand(peer_records[pa:pz], outs=tuple(x[pa:pz] for x in flat), slots=slots, **rl)
     sync()
     t0 = time.perf_counter()
     for _ in range(20):
-        r.closest_expand(peer_records[pa:pz], outs=tuple(x[pa:pz] for x in flat), slots=slots)
+        r.closest_expand(peer_records[pa:pz], outs=tuple(x[pa:pz] for x in flat), slots=slots, **rl)
     sync()
     expand_ms = (time.perf_counter() - t0) / 20 * 1e3
     # ---- verification: every row against a dense trace of that rank's rays ---------------------------

@@ -179,6 +179,12 @@ int tr_intersects_closest_packed_slots(const tr_bvh *bvh, const tr_rays *rays, t
                                        void *stream);
 int tr_closest_expand_slots(const tr_bvh *bvh, const tr_packed_hit *d_packed, int64_t n, uint8_t *d_hit,
                             uint8_t *d_front, int32_t *d_tri, float *d_loc3, float *d_uv2, void *stream);
+/* ... for records that are ROWS OF AN IMAGE (row_length pixels each; n a multiple of 8 rows, row_length of 32): a wave
+ *    expands 8x8 pixel tiles, so that the neighbouring rays that hit the same triangle read its record once.  Any
+ *    other shape (row_length 0 included) takes the linear kernel.  Same outputs.                              */
+int tr_closest_expand_slots_rows(const tr_bvh *bvh, const tr_packed_hit *d_packed, int64_t n, int64_t row_length,
+                                 uint8_t *d_hit, uint8_t *d_front, int32_t *d_tri, float *d_loc3, float *d_uv2,
+                                 void *stream);
 
 /* -- multi-hit (intersectsLocation, ray.cpp:324-378):
  *    tr_hits_scan replaces the torch glue of ray.cpp:333-342: d_offsets[i] = exclusive
@@ -269,7 +275,8 @@ int tr_trace_stats_query(const tr_bvh *bvh, const tr_rays *rays, int query, tr_t
  *    "expand4" (tr_closest_expand: 0 one ray per thread / 1 four rays per thread, 256 apart, mesh rows through buffer
  *    loads so that misses fetch nothing / 2 four adjacent rays per thread with 16-byte accesses where the rows are
  *    aligned / 3 tiles of 1024 rays staged through LDS), "expand_cus" (0 = one workgroup per 1024 rays; N = at most N
- *    workgroups per CU, grid-stride beyond: an expansion that runs beside a trace).
+ *    workgroups per CU, grid-stride beyond: an expansion that runs beside a trace), "expand_tiles" (0/1:
+ *    tr_closest_expand_slots_rows takes 8x8 pixel tiles per wave on image-shaped rows).
  *    None of them changes results.  Returns TR_ERR_INVALID_ARG for unknown names or values out
  *    of range.                                                                             */
 int tr_set_option(const char *name, int64_t value);

@@ -103,6 +103,8 @@ for rays, rr in ((n, img_s),) + (((93_000_000, img_s.repeat(13, 1)[:93_000_000])
     outs = outs_for(rays)
     sec = timeit(lambda: r.closest_expand(rr, outs=outs, slots=True), reps=10)
     out(what="image records, SLOT form", rays=rays, ms=round(sec * 1e3, 4), gbps=round(rays * 38 / sec / 1e9, 1))
+    sec = timeit(lambda: r.closest_expand(rr, outs=outs, slots=True, row_length=1024), reps=10)
+    out(what="image records, SLOT form, 8x8 tiles", rays=rays, ms=round(sec * 1e3, 4), gbps=round(rays * 38 / sec / 1e9, 1))
     del outs
 # incoherent hits: the records of 12.5 M hash rays (a C5(ii) shard), both forms
 ho, hd = W.hash_rays_torch(12_500_000, 99, v.min(0) * 1.5, v.max(0) * 1.5, device=dev)

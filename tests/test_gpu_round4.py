@@ -143,6 +143,26 @@ def test_slot_form_records_expand_to_the_dense_outputs(device):
             got = who.closest_expand(rec_s, batch_shape=b, slots=True)
             for a, e in zip(got, exp):
                 assert torch.equal(a, e)
+        # image rows in 8x8 pixel tiles (tr_closest_expand_slots_rows), into row slices of full-size outputs
+        if oo.dim() == 3:
+            H, Wd = 96, 352                                        # a multiple of 8 rows, of 32 pixels
+            o2 = torch.from_numpy(np.ascontiguousarray(W.pinhole_grid(Wd, H, distance=2.5 * rad)[0])).to(device)
+            d2 = torch.from_numpy(W.pinhole_grid(Wd, H, distance=2.5 * rad)[1]).to(device)
+            exp2 = [x.reshape(H * Wd, *x.shape[2:]) for x in r.intersects_closest(o2, d2)]
+            rec2 = r.intersects_closest_packed(o2, d2, slots=True)
+            for rows in ((0, H), (8, 72), (16, 24)):
+                a_, z_ = rows[0] * Wd, rows[1] * Wd
+                outs = (torch.zeros(H * Wd, dtype=torch.bool, device=device), torch.zeros(H * Wd, dtype=torch.bool, device=device),
+                        torch.full((H * Wd,), -7, dtype=torch.int32, device=device), torch.full((H * Wd, 3), 9.0, device=device),
+                        torch.full((H * Wd, 2), 9.0, device=device))
+                replica.closest_expand(rec2[a_:z_], outs=tuple(x[a_:z_] for x in outs), slots=True, row_length=Wd)
+                for a, e in zip(outs, exp2):
+                    assert torch.equal(a[a_:z_], e[a_:z_]), rows
+                assert int((outs[2][:a_] != -7).sum()) == 0 and int((outs[2][z_:] != -7).sum()) == 0
+            # shapes the tiled kernel does not take (rows not a multiple of 8, width not of 32) fall back, same bits
+            got = r.closest_expand(rec2[:5 * Wd].contiguous(), slots=True, row_length=Wd)
+            for a, e in zip(got, exp2):
+                assert torch.equal(a, e[:5 * Wd])
         # small and unaligned row ranges (the one-ray kernel), corrupt slots
         n = rec_s.shape[0]
         flat = [x.reshape(n, *x.shape[len(b):]) for x in exp]

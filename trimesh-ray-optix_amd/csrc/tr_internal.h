@@ -189,6 +189,7 @@ struct tr_options {
     int wide_direct = 1;  // the DIRECT launch on the 8-wide nodes (k_query_direct_wide): 0 never, 1 location launches on meshes >= 500 k triangles (where measured faster), 2 count and location, 3 every query
     int wide_stack = 12;  // ... entries of a lane's node stack kept in LDS (<= 12; the rest lives in a global spill row; tests lower it)
     int expand_cus = 0;   // tr_closest_expand (expand4 = 1): at most this many workgroups per CU, grid-stride beyond (0: one workgroup per 1024 rays)
+    int expand_tiles = 1; // tr_closest_expand_slots_rows: 8x8 pixel tiles per wave on image-shaped rows (0: rows of 256 pixels)
     int expand4 = 1;      // tr_closest_expand: 0 one ray per thread, 1 four rays per thread 256 apart, rows through buffer loads (misses fetch nothing), 2 four adjacent rays with 16-byte accesses, 3 LDS-staged tiles of 1024 rays
     int usteal = 1;       // unordered count launches hand owed subtrees over between lanes and use split launch slots: 0 off, 1 on, >= 2 forced trip threshold
 };

@@ -1576,6 +1576,65 @@ __global__ __launch_bounds__(256) void k_closest_expand_slots(const tr_packed_hi
     }
 }
 
+// Slot form on IMAGE-shaped rows (tr_closest_expand_slots with a row length): a wave takes 8x8 pixel tiles (four of
+// them, side by side) instead of 256 pixels of one row.  A triangle of the headline image covers ~5 pixels -- about
+// 2 x 2 -- so in row order every triangle record is fetched again by the waves of the rows above and below (other
+// workgroups, other XCDs, other L2s: 120 bytes of fabric traffic per hit for a 48-byte record that five rays share);
+// in tile order the rays that share a record sit in the same wave.  Records are read and outputs written in
+// segments of 8 pixels (96 / 8 / 32 / 96 / 64 bytes): partial lines that the L2 merges.
+__global__ __launch_bounds__(256) void k_closest_expand_slots_tiled(const tr_packed_hit* __restrict__ packed, int64_t n, int64_t width,
+                                                                    const tr_tri* __restrict__ tris, int64_t nt,
+                                                                    uint8_t* __restrict__ hit, uint8_t* __restrict__ front,
+                                                                    int32_t* __restrict__ tri, float* __restrict__ loc,
+                                                                    float* __restrict__ uv) {
+    typedef int tr_v4i __attribute__((ext_vector_type(4)));
+    constexpr int R = 4;
+    const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc((void*)tris, 0, (int)(nt * (int64_t)sizeof(tr_tri)), 0x00020000);
+    const int lane = threadIdx.x & 63;
+    const int64_t tpr = width >> 3;                       // tiles per row of tiles
+    const int64_t ntiles = (n / width >> 3) * tpr;        // n is a multiple of 8 * width
+    // wave w of the grid takes tiles 4w .. 4w+3 (consecutive in x; width % 32 == 0 keeps them in one row of tiles)
+    for (int64_t t0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * R; t0 < ntiles; t0 += (int64_t)gridDim.x * 4 * R) {
+        int64_t idx[R];
+        tr_packed_hit ph[R];
+        bool ok[R];
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            const int64_t t = t0 + k, ty = t / tpr, tx = t - ty * tpr;
+            idx[k] = ((ty << 3) + (lane >> 3)) * width + (tx << 3) + (lane & 7);
+            ph[k] = packed[idx[k]];
+        }
+        tr_v4i q0[R], q1[R], q2[R];
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            const uint32_t slot = ph[k].tri & 0x3fffffffu;
+            ok[k] = !(ph[k].tri & 0x80000000u) && (int64_t)slot < nt;
+            const uint32_t off = ok[k] ? slot * (uint32_t)sizeof(tr_tri) : 0xffffffffu;
+            q0[k] = __builtin_amdgcn_raw_buffer_load_b128(trs, off, 0, 0);
+            q1[k] = __builtin_amdgcn_raw_buffer_load_b128(trs, ok[k] ? off + 16u : 0xffffffffu, 0, 0);
+            q2[k] = __builtin_amdgcn_raw_buffer_load_b128(trs, ok[k] ? off + 32u : 0xffffffffu, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            const int64_t i = idx[k];
+            float l3[3] = {0.f, 0.f, 0.f}, u2[2] = {0.f, 0.f};
+            uint8_t h = 0, fr = 0;
+            int32_t t = -1;
+            if (ok[k]) {
+                tr_bary_outputs(ph[k].u, ph[k].v, __int_as_float(q0[k].x), __int_as_float(q0[k].y), __int_as_float(q0[k].z),
+                                __int_as_float(q0[k].w), __int_as_float(q1[k].x), __int_as_float(q1[k].y),
+                                __int_as_float(q1[k].z), __int_as_float(q1[k].w), __int_as_float(q2[k].x), l3, u2);
+                h = 1; fr = (ph[k].tri >> 30) & 1u; t = q2[k].y;
+            }
+            if (hit) hit[i] = h;
+            if (front) front[i] = fr;
+            if (tri) tri[i] = t;
+            if (loc) { loc[3 * i] = l3[0]; loc[3 * i + 1] = l3[1]; loc[3 * i + 2] = l3[2]; }
+            if (uv) { uv[2 * i] = u2[0]; uv[2 * i + 1] = u2[1]; }
+        }
+    }
+}
+
 // (option expand4 = 2; measured SLOWER than one ray per thread -- 1.49 against 2.49 TB/s on 7.3 M rays,
 // profiles/r04_emulate_run1.jsonl: a wave's 16-byte accesses at a 48-byte stride touch every line three times and
 // the non-temporal hints keep them from merging -- kept for the record and for A/B runs.)
@@ -2522,10 +2581,10 @@ int tr_intersects_closest_packed_slots(const tr_bvh* bvh, const tr_rays* rays, t
     return launch_query<TR_Q_CLOSEST, false>(bvh, rays, out, nullptr, (hipStream_t)stream);
 }
 
-int tr_closest_expand_slots(const tr_bvh* bvh, const tr_packed_hit* d_packed, int64_t n, uint8_t* d_hit, uint8_t* d_front,
-                            int32_t* d_tri, float* d_loc, float* d_uv, void* stream) {
+int tr_closest_expand_slots_rows(const tr_bvh* bvh, const tr_packed_hit* d_packed, int64_t n, int64_t row_length, uint8_t* d_hit,
+                                 uint8_t* d_front, int32_t* d_tri, float* d_loc, float* d_uv, void* stream) {
     if (!bvh) return tr_fail(TR_ERR_INVALID_ARG, "bvh == NULL");
-    if (n < 0) return tr_fail(TR_ERR_INVALID_ARG, "negative size");
+    if (n < 0 || row_length < 0) return tr_fail(TR_ERR_INVALID_ARG, "negative size");
     if (n == 0) return TR_OK;
     if (!d_packed) return tr_fail(TR_ERR_INVALID_ARG, "d_packed == NULL");
     if (bvh->num_tris * (int64_t)sizeof(tr_tri) >= ((int64_t)1 << 31)) return tr_fail(TR_ERR_INVALID_ARG, "slot form needs a triangle array below 2 GiB");
@@ -2534,7 +2593,16 @@ int tr_closest_expand_slots(const tr_bvh* bvh, const tr_packed_hit* d_packed, in
     tr_device_state* st;
     TR_TRY(tr_get_device_state(bvh->device, &st));
     const tr_options opt = tr_opts();
-    if (n >= 4096) {
+    // image-shaped rows (row_length pixels each, a multiple of 8 rows in all): 8x8 pixel tiles per wave, so that the rays
+    // that share a triangle record share a wave (option expand_tiles)
+    const bool tiled = opt.expand_tiles && row_length >= 32 && row_length % 32 == 0 && n % (8 * row_length) == 0 && n >= 4096;
+    if (tiled) {
+        const int64_t ntiles = n / 64;
+        int64_t blocks = (ntiles + 15) / 16;                  // 4 waves x 4 tiles per workgroup and pass
+        if (opt.expand_cus > 0 && blocks > (int64_t)st->num_cus * opt.expand_cus) blocks = (int64_t)st->num_cus * opt.expand_cus;
+        hipLaunchKernelGGL(k_closest_expand_slots_tiled, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                           d_packed, n, row_length, bvh->tris, bvh->num_tris, d_hit, d_front, d_tri, d_loc, d_uv);
+    } else if (n >= 4096) {
         int64_t blocks = (n + 1023) / 1024;
         if (opt.expand_cus > 0 && blocks > (int64_t)st->num_cus * opt.expand_cus) blocks = (int64_t)st->num_cus * opt.expand_cus;
         hipLaunchKernelGGL(k_closest_expand_slots<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
@@ -2545,6 +2613,11 @@ int tr_closest_expand_slots(const tr_bvh* bvh, const tr_packed_hit* d_packed, in
     }
     TR_HIP_TRY(hipGetLastError());
     return TR_OK;
+}
+
+int tr_closest_expand_slots(const tr_bvh* bvh, const tr_packed_hit* d_packed, int64_t n, uint8_t* d_hit, uint8_t* d_front,
+                            int32_t* d_tri, float* d_loc, float* d_uv, void* stream) {
+    return tr_closest_expand_slots_rows(bvh, d_packed, n, 0, d_hit, d_front, d_tri, d_loc, d_uv, stream);
 }
 
 int tr_intersects_count(const tr_bvh* bvh, const tr_rays* rays, int32_t* d_count, void* stream) {

@@ -93,6 +93,7 @@ ABI = {
     "tr_closest_expand": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tr_intersects_closest_packed_slots": (_int, [_vp, C.POINTER(TrRays), _vp, _vp]),
     "tr_closest_expand_slots": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tr_closest_expand_slots_rows": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tr_hits_scan": (_int, [_vp, _i64, _i32, _vp, _vp, C.POINTER(_i64), _vp]),
     "tr_intersects_location_fill": (_int, [_vp, C.POINTER(TrRays), _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
     "tr_intersects_count_topk": (_int, [_vp, C.POINTER(TrRays), _i32, _vp, _vp, _vp]),
@@ -283,7 +284,7 @@ def intersects_closest_packed(accel_structure, origins, dirs, out: torch.Tensor 
     return out
 
 
-def closest_expand_slots(accel_structure, packed: torch.Tensor, batch_shape=None, outs=None):
+def closest_expand_slots(accel_structure, packed: torch.Tensor, batch_shape=None, outs=None, row_length: int = 0):
     """tr_closest_expand_slots: slot-form records (intersects_closest_packed(..., slots=True), of this hierarchy or of a
     bit-identical replica) -> (hit, front, tri_idx, loc, uv), bit-identical to intersects_closest on the same rays."""
     if packed.dtype != torch.int32 or packed.dim() != 2 or packed.shape[1] != 3 or not packed.is_contiguous() or not packed.is_cuda:
@@ -304,9 +305,11 @@ def closest_expand_slots(accel_structure, packed: torch.Tensor, batch_shape=None
         uv = torch.empty((*b, 2), dtype=torch.float32, device=dev)
         if hit.numel() != n:
             raise ValueError(f"batch_shape {b} does not hold {n} rays")
+    # row_length: the records are whole rows of an image of that width (tr_closest_expand_slots_rows: 8x8 tiles per wave)
     with torch.cuda.device(dev):
-        _check(get_module().tr_closest_expand_slots(_handle(accel_structure, packed), packed.data_ptr(), n, hit.data_ptr(),
-                                                    front.data_ptr(), tri.data_ptr(), loc.data_ptr(), uv.data_ptr(), _stream_ptr(dev)))
+        _check(get_module().tr_closest_expand_slots_rows(_handle(accel_structure, packed), packed.data_ptr(), n, int(row_length),
+                                                         hit.data_ptr(), front.data_ptr(), tri.data_ptr(), loc.data_ptr(),
+                                                         uv.data_ptr(), _stream_ptr(dev)))
     return hit, front, tri, loc, uv
 
 

@@ -126,11 +126,12 @@ class RayMeshIntersector:
         cheaper to expand there (closest_expand(..., slots=True))."""
         return hops.intersects_closest_packed(self.as_wrapper, origins, directions, out, slots)
 
-    def closest_expand(self, packed: torch.Tensor, batch_shape=None, outs=None, slots: bool = False):
+    def closest_expand(self, packed: torch.Tensor, batch_shape=None, outs=None, slots: bool = False, row_length: int = 0):
         """packed rows -> (hit, front, tri_idx, loc, uv), bit-identical to intersects_closest on the same
-        rays; uses this intersector's mesh (any rank's replica will do: the meshes are identical)."""
+        rays; uses this intersector's mesh (any rank's replica will do: the meshes are identical).
+        row_length (slot form): the records are whole rows of an image of that width -- expanded in 8x8 pixel tiles."""
         if slots:
-            return hops.closest_expand_slots(self.as_wrapper, packed, batch_shape, outs)
+            return hops.closest_expand_slots(self.as_wrapper, packed, batch_shape, outs, row_length)
         dev = packed.device
         v = self.mesh_vertices if self.mesh_vertices.device == dev else self.mesh_vertices.to(dev)
         f = self.mesh_faces if self.mesh_faces.device == dev else self.mesh_faces.to(dev)

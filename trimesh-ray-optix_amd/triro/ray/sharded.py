@@ -477,7 +477,9 @@ class ShardedRayMeshIntersector:
                             merged.append((ra, rz))
                     for ra, rz in merged:
                         if self.slots:
-                            self.local.closest_expand(packed_all[ra:rz], outs=tuple(x[ra:rz] for x in flat_outs), slots=True)
+                            # (rows of an image: the expansion takes 8x8 pixel tiles per wave)
+                            self.local.closest_expand(packed_all[ra:rz], outs=tuple(x[ra:rz] for x in flat_outs), slots=True,
+                                                      row_length=per_row if per_row > 1 else 0)
                         else:
                             self.local.closest_expand(packed_all[ra:rz], outs=tuple(x[ra:rz] for x in flat_outs))
                 if side is not None:
