@@ -19,7 +19,8 @@ T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
 DEFAULTS = {"steal": 1, "tile": 1, "block_size": 128, "adaptive": 1, "xcd_chunk": 128, "compact": 1, "scramble": 1,
             "persistent": 0, "blocks_per_cu": 8,
             "tile_small": 4, "unordered": 1, "leaf_vote": 32, "stream": 1, "stream_rays": 256, "stream_refill": 32, "stream_dynamic": 1,
-            "split": 1, "split_steal": 8, "grid_nodes": 1, "split_outlier": 1, "split_floor": 40, "usteal": 1, "lds_top": 0, "occ8": 1}
+            "split": 1, "split_steal": 8, "grid_nodes": 1, "split_outlier": 1, "split_floor": 40, "usteal": 1, "lds_top": 0, "occ8": 1,
+            "wide": 2, "wide_stack": 12, "wide_direct": 1, "expand4": 1, "expand_cus": 0, "expand_tiles": 1}
 bad = 0
 for it in range(a.iters):
     kind = rng.integers(0, 5)
@@ -67,7 +68,10 @@ for it in range(a.iters):
             "grid_nodes": int(rng.choice([0, 1, 2, 2])),
             # round 3: device-side split criterion, stealing in the unordered count launch, LDS-staged node packets
             "split_outlier": int(rng.choice([0, 1, 1, 4, 8, 30])), "split_floor": int(rng.choice([0, 0, 0, 40])),
-            "usteal": int(rng.choice([0, 1, 1, 2, 8, 64])), "lds_top": int(rng.choice([0, 0, 1, 2])), "occ8": int(rng.choice([0, 1, 2, 2]))}
+            "usteal": int(rng.choice([0, 1, 1, 2, 8, 64])), "lds_top": int(rng.choice([0, 0, 1, 2])), "occ8": int(rng.choice([0, 1, 2, 2])),
+            # round 4: 8-wide compressed nodes (streaming launch, direct launch), their stack split, the expansion kernels
+            "wide": int(rng.choice([0, 1, 1, 2])), "wide_stack": int(rng.choice([1, 2, 5, 12])), "wide_direct": int(rng.choice([0, 1, 2, 3, 3])),
+            "expand4": int(rng.choice([0, 1, 1, 2, 3])), "expand_cus": int(rng.choice([0, 0, 1, 3])), "expand_tiles": int(rng.choice([0, 1]))}
     for k, val in opts.items(): hops.set_option(k, val)
     try:
         r = RayMeshIntersector(vertices=T(v), faces=T(f)); R = OracleIntersector(v, f, 1)
@@ -87,6 +91,11 @@ for it in range(a.iters):
             # round 3: 12-byte packed closest records expand to the dense outputs bit for bit
             exp5 = r.closest_expand(r.intersects_closest_packed(ot, dt), batch_shape=ot.shape[:-1])
             ok &= all(np.array_equal(x.cpu().numpy().reshape(e.shape), e) for x, e in zip(exp5, (hit, front, tri, loc, uv)))
+            # round 4: slot-form records, expanded linearly and (image-shaped batches) in 8x8 tiles
+            recs = r.intersects_closest_packed(ot, dt, slots=True)
+            for rl in ((0, ot.shape[1]) if ot.dim() == 3 else (0,)):
+                exp6 = r.closest_expand(recs, batch_shape=ot.shape[:-1], slots=True, row_length=int(rl))
+                ok &= all(np.array_equal(x.cpu().numpy().reshape(e.shape), e) for x, e in zip(exp6, (hit, front, tri, loc, uv)))
             if not ok: break
     finally:
         for k, val in DEFAULTS.items(): hops.set_option(k, val)

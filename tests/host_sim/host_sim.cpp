@@ -121,6 +121,27 @@ static int32_t build_split_rec(SimBvh& b, const std::vector<uint64_t>& keys, con
             if (left * 8 >= n && (n - left) * 8 >= n) m = lo;
         }
     }
+    if (split_mode == 4 && z - a >= 2) {
+        // EXPERIMENT (scripts/round4/exp_tree_quality.py): the split index that minimises the surface-area heuristic
+        // area(left) * n_left + area(right) * n_right over ALL positions of the Morton-ordered range (a full sweep)
+        const int64_t n = z - a + 1;
+        std::vector<float> suf(6 * n);
+        float bx[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (int64_t i = n - 1; i >= 0; i--) {
+            const float* s = &sbox[6 * (a + i)];
+            for (int k = 0; k < 3; k++) { bx[k] = fminf(bx[k], s[k]); bx[3 + k] = fmaxf(bx[3 + k], s[3 + k]); }
+            for (int k = 0; k < 6; k++) suf[6 * i + k] = bx[k];
+        }
+        auto area = [](const float* q) { const float x = q[3] - q[0], y = q[4] - q[1], zz = q[5] - q[2]; return x * y + y * zz + zz * x; };
+        float pre[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        double best = 1e300;
+        for (int64_t i = 0; i + 1 < n; i++) {
+            const float* s = &sbox[6 * (a + i)];
+            for (int k = 0; k < 3; k++) { pre[k] = fminf(pre[k], s[k]); pre[3 + k] = fmaxf(pre[3 + k], s[3 + k]); }
+            const double c = (double)area(pre) * (double)(i + 1) + (double)area(&suf[6 * (i + 1)]) * (double)(n - i - 1);
+            if (c < best) { best = c; m = a + i; }
+        }
+    }
     const int32_t l = build_split_rec(b, keys, sbox, ibox, cl, cr, par, a, m, next, split_mode, depth + 1, maxdepth);
     const int32_t r = build_split_rec(b, keys, sbox, ibox, cl, cr, par, m + 1, z, next, split_mode, depth + 1, maxdepth);
     cl[me] = l; cr[me] = r;
@@ -208,7 +229,7 @@ void* sim_build(const float* verts, int64_t nv, const int32_t* faces, int64_t nf
     }
     if (nf >= 2) {
         int h = -1;
-        if (force_mode == 2 || force_mode == 3) { h = build_hierarchy_split(*b, skeys, sbox, force_mode); b->key_mode = force_mode; }
+        if (force_mode == 2 || force_mode == 3 || force_mode == 4) { h = build_hierarchy_split(*b, skeys, sbox, force_mode); b->key_mode = force_mode; }
         else {
         if (force_mode != 1) { h = build_hierarchy<0>(*b, skeys, sbox); b->key_mode = 0; }
         if (force_mode == 1 || (force_mode < 0 && h > 64)) { h = build_hierarchy<1>(*b, skeys, sbox); b->key_mode = 1; }

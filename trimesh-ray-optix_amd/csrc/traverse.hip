@@ -1591,20 +1591,30 @@ __global__ __launch_bounds__(256) void k_closest_expand_slots_tiled(const tr_pac
     constexpr int R = 4;
     const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc((void*)tris, 0, (int)(nt * (int64_t)sizeof(tr_tri)), 0x00020000);
     const int lane = threadIdx.x & 63;
-    const int64_t tpr = width >> 3;                       // tiles per row of tiles
-    const int64_t ntiles = (n / width >> 3) * tpr;        // n is a multiple of 8 * width
-    // wave w of the grid takes tiles 4w .. 4w+3 (consecutive in x; width % 32 == 0 keeps them in one row of tiles)
-    for (int64_t t0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * R; t0 < ntiles; t0 += (int64_t)gridDim.x * 4 * R) {
-        int64_t idx[R];
-        tr_packed_hit ph[R];
-        bool ok[R];
+    // a wave takes a block of 8 rows x 32 pixels; its R = 4 rays per lane are four strips of 2 rows x 32 pixels, so
+    // that one memory instruction of the wave touches two runs of 32 pixels (hit 32 B, tri 128 B, loc 384 B, uv 256 B
+    // each) -- with one 8x8 tile per instruction the runs were 8 pixels long and the pure-stream part of the kernel ran
+    // at 0.072 instead of 0.046 ms -- while the block still holds the rays that share triangle records
+    const uint32_t gpr = (uint32_t)(width >> 5);                      // blocks per row of blocks (32-bit: images below 2^31 pixels wide)
+    const int64_t ngroups = (n / width >> 3) * (int64_t)gpr;          // n is a multiple of 8 * width
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    // wave w of the grid takes block w, then the block `stride` further on: a persistent grid (the host sizes it to what
+    // is resident -- 28 672 waves of 3 us each, one per 256 rays, kept 3 of a CU's 20 wave slots busy:
+    // profiles/r04_expand_pmc_tiles_vs_rows.txt), software-pipelined: the records of the NEXT block are requested
+    // before the triangle records of this one are used
+    auto ray_index = [&](int64_t g, int k) {
+        const uint32_t gy = (uint32_t)(g / gpr), gx = (uint32_t)(g - (int64_t)gy * gpr);
+        return ((int64_t)((gy << 3) + (uint32_t)(2 * k) + (uint32_t)(lane >> 5))) * width + (int64_t)((gx << 5) + (uint32_t)(lane & 31));
+    };
+    int64_t t0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t0 >= ngroups) return;
+    int64_t idx[R];
+    tr_packed_hit ph[R];
 #pragma unroll
-        for (int k = 0; k < R; k++) {
-            const int64_t t = t0 + k, ty = t / tpr, tx = t - ty * tpr;
-            idx[k] = ((ty << 3) + (lane >> 3)) * width + (tx << 3) + (lane & 7);
-            ph[k] = packed[idx[k]];
-        }
+    for (int k = 0; k < R; k++) { idx[k] = ray_index(t0, k); ph[k] = packed[idx[k]]; }
+    for (;;) {
         tr_v4i q0[R], q1[R], q2[R];
+        bool ok[R];
 #pragma unroll
         for (int k = 0; k < R; k++) {
             const uint32_t slot = ph[k].tri & 0x3fffffffu;
@@ -1613,6 +1623,15 @@ __global__ __launch_bounds__(256) void k_closest_expand_slots_tiled(const tr_pac
             q0[k] = __builtin_amdgcn_raw_buffer_load_b128(trs, off, 0, 0);
             q1[k] = __builtin_amdgcn_raw_buffer_load_b128(trs, ok[k] ? off + 16u : 0xffffffffu, 0, 0);
             q2[k] = __builtin_amdgcn_raw_buffer_load_b128(trs, ok[k] ? off + 32u : 0xffffffffu, 0, 0);
+        }
+        // the next group's records (wave-uniform condition)
+        const int64_t t1 = t0 + stride;
+        const bool more = t1 < ngroups;
+        int64_t nidx[R];
+        tr_packed_hit nph[R];
+        if (more) {
+#pragma unroll
+            for (int k = 0; k < R; k++) { nidx[k] = ray_index(t1, k); nph[k] = packed[nidx[k]]; }
         }
 #pragma unroll
         for (int k = 0; k < R; k++) {
@@ -1632,6 +1651,10 @@ __global__ __launch_bounds__(256) void k_closest_expand_slots_tiled(const tr_pac
             if (loc) { loc[3 * i] = l3[0]; loc[3 * i + 1] = l3[1]; loc[3 * i + 2] = l3[2]; }
             if (uv) { uv[2 * i] = u2[0]; uv[2 * i + 1] = u2[1]; }
         }
+        if (!more) break;
+        t0 = t1;
+#pragma unroll
+        for (int k = 0; k < R; k++) { idx[k] = nidx[k]; ph[k] = nph[k]; }
     }
 }
 
@@ -2597,8 +2620,9 @@ int tr_closest_expand_slots_rows(const tr_bvh* bvh, const tr_packed_hit* d_packe
     // that share a triangle record share a wave (option expand_tiles)
     const bool tiled = opt.expand_tiles && row_length >= 32 && row_length % 32 == 0 && n % (8 * row_length) == 0 && n >= 4096;
     if (tiled) {
-        const int64_t ntiles = n / 64;
-        int64_t blocks = (ntiles + 15) / 16;                  // 4 waves x 4 tiles per workgroup and pass
+        int64_t blocks = (n / 256 + 3) / 4;                   // 4 waves per workgroup, one block of 8 x 32 pixels per wave and pass
+        // one wave per block of 8 rows x 32 pixels (expand_cus = N > 0: at most N workgroups per CU, the waves loop;
+        // measured on 7.3 M records of the headline image: no cap 0.066 ms, 8 per CU 0.072, what is resident 0.078)
         if (opt.expand_cus > 0 && blocks > (int64_t)st->num_cus * opt.expand_cus) blocks = (int64_t)st->num_cus * opt.expand_cus;
         hipLaunchKernelGGL(k_closest_expand_slots_tiled, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                            d_packed, n, row_length, bvh->tris, bvh->num_tris, d_hit, d_front, d_tri, d_loc, d_uv);
