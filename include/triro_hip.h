@@ -268,6 +268,8 @@ int tr_trace_stats_query(const tr_bvh *bvh, const tr_rays *rays, int query, tr_t
  *    instead of 7 waves per SIMD: 64 registers and a hand-over that needs half the LDS scratch).
  *    "grid_nodes" (0 never / 1 measured on the first launches of a batch size / 2 always: closest and first launches that steal walk the
  *    32-byte grid nodes -- two 16-byte loads per visit -- instead of the exact 64-byte nodes).
+ *    "order_transfer" (0/1: the first launch of a new image resolution on a (handle, stream) starts from the block costs
+ *    measured at the previous resolution, resampled onto its blocks, instead of the static order),
  *    "wide" (0 never / 1 always / 2 where measured faster -- meshes from 3 M triangles on, count launches from 1 M on: the streaming launch walks 8-wide nodes with 8-bit child boxes -- three levels of the binary
  *    hierarchy collapsed into one 96-byte record, built on the first streaming query after a build / refit / load),
  *    "wide_direct" (0 never / 1 multi-hit list launches on meshes from 500 k triangles on / 2 count and location / 3 every query: the direct launch -- tiles, learned order -- walks

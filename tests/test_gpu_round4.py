@@ -223,3 +223,40 @@ def test_async_closest_without_collectives_orders_the_side_stream(device):
             for a, e in zip(got, exp):
                 assert torch.equal(a, e), (type(local).__name__, k)
             del junk
+
+
+def test_learned_order_survives_a_change_of_resolution(device):
+    """VERDICT r03 #7b: the first launch of a new image resolution takes an order resampled from the previous
+    resolution's block costs (k_sched_rescale) -- and returns the same bits as ever"""
+    import triro.backend.ops as hops
+    from triro.ray.ray_optix import RayMeshIntersector
+    v, f = W.headline_mesh(6)
+    R = OracleIntersector(v, f, mode=1)
+    rad = float(np.linalg.norm(v, axis=1).max())
+
+    def rays(res):
+        o_np, d_np = W.pinhole_grid(res, res, distance=2.5 * rad)
+        return o_np, d_np, torch.from_numpy(np.ascontiguousarray(o_np)).to(device), torch.from_numpy(d_np).to(device)
+    try:
+        for transfer in (1, 0):
+            hops.set_option("order_transfer", transfer)
+            r = RayMeshIntersector(vertices=torch.from_numpy(v).to(device), faces=torch.from_numpy(f).to(device))
+            _, _, o1, d1 = rays(384)
+            for _ in range(14):
+                r.intersects_closest(o1, d1)
+            assert r.as_wrapper.last_launch()["learned_order"] == 1
+            for res in (512, 256, 640):               # up, down, up: every change starts from the previous shape
+                o_np, d_np, o2, d2 = rays(res)
+                hit, front, tri, loc, uv = r.intersects_closest(o2, d2)
+                assert r.as_wrapper.last_launch()["learned_order"] == transfer, (transfer, res)
+                eh, ef, et, el, eu = R.intersects_closest(o_np, d_np)
+                assert np.array_equal(hit.cpu().numpy(), eh) and np.array_equal(tri.cpu().numpy(), et)
+                assert np.array_equal(loc.cpu().numpy(), el) and np.array_equal(uv.cpu().numpy(), eu)
+                assert np.array_equal(r.intersects_count(o2, d2).cpu().numpy(), R.intersects_count(o_np, d_np))
+                for _ in range(3):
+                    r.intersects_closest(o2, d2)
+            # a flat batch in between cannot borrow an image's costs, and does not break anything
+            hit = r.intersects_closest(o2.reshape(-1, 3), d2.reshape(-1, 3))[0]
+            assert np.array_equal(hit.cpu().numpy(), eh.reshape(-1))
+    finally:
+        hops.set_option("order_transfer", 1)

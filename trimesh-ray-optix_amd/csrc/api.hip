@@ -51,6 +51,7 @@ const opt_desc OPTS[] = {
     {"expand4", &tr_options::expand4, 0, 3, false},
     {"expand_cus", &tr_options::expand_cus, 0, 64, false},
     {"expand_tiles", &tr_options::expand_tiles, 0, 1, true},
+    {"order_transfer", &tr_options::order_transfer, 0, 1, true},
     {"wide", &tr_options::wide, 0, 2, false},
     {"wide_stack", &tr_options::wide_stack, 1, 12, false},
     {"wide_direct", &tr_options::wide_direct, 0, 3, false},

@@ -39,7 +39,12 @@ struct tr_sched_slot {
     uint32_t* buf = nullptr;
     int64_t nblocks = 0;    // block count the current order was measured for (0 = none)
     int64_t split = 0;      // ... and the number of split blocks per XCD the order was written with
+    int lgh = 0;            // ... and the rows-per-tile exponent of its block -> ray map
     int64_t launches = 0;   // launches with this block count so far
+    // shape of the launch whose costs the last k_sched_sort kept (k_sched_rescale lends them to the next batch shape)
+    bool prev_valid = false;
+    int64_t prev_nblocks = 0, prev_w = 0, prev_h = 0;
+    int prev_lgh = 0;
     bool used = false;
     // node-flavour tuner of the stealing closest / first launches (grid_nodes = 1): two launches on
     // the exact nodes and two on the grid nodes are timed with events, the faster flavour stays
@@ -185,6 +190,7 @@ struct tr_options {
     int leaf_vote = 32;   // unordered schedule: lanes with a queued leaf that fire a leaf phase
     int occ8 = 1;         // stealing closest / first launches on the grid nodes at 8 waves per SIMD (64 registers, slim hand-over scratch): 0 never, 1 from 2 M rays on, 2 always
     int lds_top = 0;      // LDS-staged node packets for closest / first launches that steal: 0 off, 1 at 128-thread blocks, 2 at 256-thread blocks
+    int order_transfer = 1;   // a batch of a new image shape starts from the previous shape's block costs, resampled (0: from the static order)
     int wide = 2;         // the streaming launch walks 8-wide compressed nodes (tr_wide.h; built on first use): 0 never, 1 always, 2 where measured faster (>= 3 M triangles; count from 1 M triangles on)
     int wide_direct = 1;  // the DIRECT launch on the 8-wide nodes (k_query_direct_wide): 0 never, 1 location launches on meshes >= 500 k triangles (where measured faster), 2 count and location, 3 every query
     int wide_stack = 12;  // ... entries of a lane's node stack kept in LDS (<= 12; the rest lives in a global spill row; tests lower it)

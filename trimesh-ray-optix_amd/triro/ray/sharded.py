@@ -71,13 +71,15 @@ def weighted_bounds(n: int, weights: Sequence[float], quantum: int = 1) -> List[
     return [(edges[r] * quantum, edges[r + 1] * quantum) for r in range(world)]
 
 
-def auto_dst_share(world: int, rho: float = 0.07) -> float:
+def auto_dst_share(world: int, rho: float = 0.10) -> float:
     """Share of an EVEN shard the destination rank of a packed closest-hit gather should trace so that
     all ranks finish together: the destination spends rho x (a ray's trace time) on every ray somebody
     else traced (receive + expansion), so with s = its fraction of the batch
         s + rho (1 - s) = (1 - s) / (world - 1).
-    rho = 0.07: 10 us of expansion against 137 us of tracing per million incoherent rays on the headline
-    mesh.  Returns s x world (1.0 = an even shard)."""
+    rho = 0.10: 12 us of expansion (slot-form records, 3.2 TB/s) against 137 us of tracing per million
+    incoherent rays on the headline mesh, and small shards trace less efficiently than large ones
+    (emulated at 8 ranks: share 0.54 -> 2.13 ms on rank 0 against 1.94 on a peer, 0.35 -> 1.80 against 1.92:
+    DESIGN.md 6).  Returns s x world (1.0 = an even shard)."""
     if world < 2:
         return 1.0
     inv = 1.0 / (world - 1)
