@@ -2377,7 +2377,10 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
                 const int need = 7 * ((bvh->depth + 2) / 3) + 9;
                 const int lds_cap = opt.wide_stack < TR_WSTACK ? opt.wide_stack : TR_WSTACK;
                 const int spill_cap = need > lds_cap ? need - lds_cap : 0;
-                int32_t* spill = spill_cap > 0 ? wide_spill(bvh, stream, (size_t)nslots * 128 * (size_t)spill_cap) : nullptr;
+                // (one spill row per lane of the GRID: above 1 GiB -- tens of millions of rays on a deep hierarchy -- the launch
+                // keeps the binary shapes, whose state needs no memory)
+                const size_t spill_elems = (size_t)nslots * 128 * (size_t)spill_cap;
+                int32_t* spill = (spill_cap > 0 && spill_elems <= ((size_t)1 << 28)) ? wide_spill(bvh, stream, spill_elems) : nullptr;
                 if (spill_cap == 0 || spill) {
                     const tr_wide_args wa = {wn, spill, spill_cap, lds_cap};
                     hipLaunchKernelGGL((k_query_direct_wide<Q, STATS>), dim3((unsigned)nslots), dim3(128), 0, stream, view, rf, out,
