@@ -2005,8 +2005,13 @@ bool sched_acquire(const tr_bvh* bvh, const tr_options& opt, hipStream_t stream,
             uint32_t* prev = slot->buf + TR_SCHED_PREV;
             hipLaunchKernelGGL(k_sched_rescale, dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, stream, prev, slot->prev_nblocks,
                                slot->prev_w, slot->prev_h, slot->prev_lgh, slot->buf, nblocks, use->w, use->h, use->lgh);
+            // borrowed costs only ORDER the launch: no block is split on their word (outlier threshold out of reach: the
+            // extra launch slots stay sentinels).  The split set is sticky by design -- a split block records its cost
+            // doubled so that it stays split -- and a set chosen from resampled costs stayed, and cost the terrain 18 %
+            // and the shells 4 % for good (profiles/r04_first_launch_policy_debug.txt); the sort behind THIS launch picks
+            // it from costs measured on this launch's own blocks.
             hipLaunchKernelGGL(k_sched_sort, dim3(1), dim3(1024), 0, stream, slot->buf, slot->buf + TR_SCHED_MAX, (int)nblocks, use->xc,
-                               (int)use->split, (int)use->split4, use->outlier8, use->floor_ticks, (const int*)nullptr, (uint32_t*)nullptr);
+                               (int)use->split, (int)use->split4, 1 << 20, use->floor_ticks, (const int*)nullptr, (uint32_t*)nullptr);
             if (hipGetLastError() == hipSuccess) *order = slot->buf + TR_SCHED_MAX;
         }
         slot->prev_valid = false;      // (the costs kept are used up; the sort behind this launch keeps new ones)
