@@ -135,6 +135,31 @@ int main(void) {
     EXPECT(htri[0] == 1 && htri[1] == 0 && htri[2] == 0 && htri[3] == 1);      /* nearest first */
     EXPECT(feq(hloc[2], -1.f) && feq(hloc[5], 0.f) && feq(hloc[8], 0.f) && feq(hloc[11], -1.f));
 
+    /* closest hit as 12-byte records and back (ABI 6 face form, ABI 7 slot form): what a ray-sharded run exchanges */
+    {
+        tr_packed_hit *d_rec = (tr_packed_hit *)device_zeros(2 * sizeof(tr_packed_hit)), rec[2];
+        float *d_v2 = (float *)to_device(verts, sizeof verts);        /* (the mesh arrays were zeroed above) */
+        int32_t *d_f2 = (int32_t *)to_device(faces, sizeof faces);
+        int form;
+        for (form = 0; form < 3; form++) {
+            CHECK_HIP(hipMemset(d_hit, 7, 2)); CHECK_HIP(hipMemset(d_loc, 0xff, 24));
+            if (form == 0) {
+                CHECK_TR(tr_intersects_closest_packed(bvh, &rays, d_rec, NULL));
+                CHECK_TR(tr_closest_expand(d_rec, 2, d_v2, 6, d_f2, 2, d_hit, d_front, d_tri, d_loc, d_uv, NULL));
+            } else {
+                CHECK_TR(tr_intersects_closest_packed_slots(bvh, &rays, d_rec, NULL));
+                if (form == 1) CHECK_TR(tr_closest_expand_slots(bvh, d_rec, 2, d_hit, d_front, d_tri, d_loc, d_uv, NULL));
+                else CHECK_TR(tr_closest_expand_slots_rows(bvh, d_rec, 2, 2, d_hit, d_front, d_tri, d_loc, d_uv, NULL));
+            }
+            to_host(rec, d_rec, sizeof rec);
+            EXPECT((rec[0].tri & 0x80000000u) == 0 && ((rec[0].tri >> 30) & 1u) == 0 && ((rec[1].tri >> 30) & 1u) == 1);
+            to_host(hit, d_hit, 2); to_host(front, d_front, 2); to_host(tri, d_tri, 8); to_host(loc, d_loc, 24); to_host(uv, d_uv, 16);
+            EXPECT(hit[0] == 1 && front[0] == 0 && tri[0] == 1 && hit[1] == 1 && front[1] == 1 && tri[1] == 0);
+            EXPECT(feq(loc[2], -1.f) && feq(uv[0], 0.25f) && feq(uv[1], 0.5f) && feq(loc[4], 0.1f) && feq(uv[2], 0.2f) && feq(uv[3], 0.6f));
+        }
+        CHECK_HIP(hipFree(d_rec)); CHECK_HIP(hipFree(d_v2)); CHECK_HIP(hipFree(d_f2));
+    }
+
     /* T1 (test/test.py:6-13) through update: one triangle, a hit and a miss; broadcast origin on the second call */
     {
         const float v1[9] = {0.5f, -0.5f, 0.f, 0.f, 0.5f, 0.f, -0.5f, -0.5f, 0.f};

@@ -479,7 +479,7 @@ class ShardedRayMeshIntersector:
                             merged.append((ra, rz))
                     for ra, rz in merged:
                         if self.slots:
-                            # (rows of an image: the expansion takes 8x8 pixel tiles per wave)
+                            # (rows of an image: a wave expands a block of 8 rows x 32 pixels)
                             self.local.closest_expand(packed_all[ra:rz], outs=tuple(x[ra:rz] for x in flat_outs), slots=True,
                                                       row_length=per_row if per_row > 1 else 0)
                         else:
