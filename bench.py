@@ -74,6 +74,9 @@ def parse(argv=None):
                     help="ONE GPU: the destination rank's side of an N-rank run (own trace + N-1 chunks of records arriving as "
                          "device copies + their expansion; triro.ray.sharded.EmulatedWorld) -- a bound, not a measurement")
     ap.add_argument("--arrival-priority", action="store_true", help="--emulate-world: expansion stream at high priority")
+    ap.add_argument("--trace-priority", action="store_true",
+                    help="N > 1 / --emulate-world: the step loop (the traces) runs on a HIGH-priority stream, so that the expansion on "
+                         "the side stream only takes the wave slots the trace leaves free")
     ap.add_argument("--arrival", choices=["copy", "none"], default="copy",
                     help="--emulate-world: how the peers' records arrive: device copies on a copy stream (pessimistic: blit "
                          "kernels) or not at all (they are simply there: expansion cost only)")
@@ -832,6 +835,13 @@ def run_emulation(args):
 
     # ---- rank 0's step in the pretended world --------------------------------------------------------
     pending = []
+    import contextlib
+    hp = torch.cuda.Stream(device=dev, priority=-1) if args.trace_priority else None
+    if hp is not None:
+        hp.wait_stream(torch.cuda.current_stream(dev))
+
+    def trace_ctx():
+        return torch.cuda.stream(hp) if hp is not None else contextlib.nullcontext()
 
     def step():
         pending.append(E.closest_of_shard_async(o0, d0, n_total, batch_shape=bshape, dst=0, chunks=args.chunks or None,
@@ -844,17 +854,18 @@ def run_emulation(args):
             out_ = pending.pop(0).wait()
         return out_
     out = None
-    for _ in range(warm):
-        step()
-    drain()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        o_k = step()
-        out = o_k if o_k is not None else out
-    out = drain() or out
-    sync()
-    rank0_ms = (time.perf_counter() - t0) / steps * 1e3
+    with trace_ctx():
+        for _ in range(warm):
+            step()
+        drain()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            o_k = step()
+            out = o_k if o_k is not None else out
+        out = drain() or out
+        sync()
+        rank0_ms = (time.perf_counter() - t0) / steps * 1e3
     # the same without the peers (own shard only, dense): what the arrivals + expansions add
     for _ in range(warm):
         r.intersects_closest(o0, d0)
@@ -905,7 +916,7 @@ def run_emulation(args):
                                f"({args.rays if args.workload == 'c5i' else 'hash'} rays), headline mesh {len(f)} tris",
                    "rays_total": n_total, "rays_rank0": bounds[0][1] - bounds[0][0], "rays_peer": bounds[1][1] - bounds[1][0],
                    "dst_share": share, "chunks": args.chunks or "auto", "arrival_priority": bool(args.arrival_priority),
-                   "arrival": args.arrival, "opts": list(args.opt), "record_form": "slot" if slots else "face"},
+                   "arrival": args.arrival, "trace_priority": bool(args.trace_priority), "opts": list(args.opt), "record_form": "slot" if slots else "face"},
         "emulation": {"plain_1gpu_ms_per_step": round(plain_ms, 4), "plain_1gpu_rays": plain_n,
                       "rank0_ms_per_step": round(rank0_ms, 4), "rank0_own_trace_only_ms": round(own_ms, 4),
                       "peer_trace_ms_per_step": round(peer_ms, 4), "expansion_alone_ms": round(expand_ms, 4),
