@@ -152,3 +152,36 @@ def test_direct_launch_on_wide_nodes_matches_the_oracle(device, opts, wide_stack
         # flat, ragged batch (no tiles) and a tiny one
         for m in (1, 63, 5001):
             _check_all(r, R, o.reshape(-1, 3)[:m].contiguous(), d.reshape(-1, 3)[:m].contiguous(), (name, "flat", m))
+
+
+def test_graph_replay_of_a_wide_launch_follows_a_refit(device, opts):
+    """a HIP graph that captured a launch on the 8-wide nodes must see the geometry of a later refit: the wide nodes of a
+    handle that has them are rebuilt by refit / update_raw themselves (same buffer), not lazily by the next query"""
+    opts(stream=2, wide=1)
+    v, f = W.headline_mesh(5)
+    r = _mk(v, f, device)
+    lo, hi = v.min(0) * 1.5, v.max(0) * 1.5
+    o, d = W.hash_rays_torch(200_000, 7, lo, hi, device=device)
+    gs = torch.cuda.Stream(device)
+    gs.wait_stream(torch.cuda.current_stream(device))
+    with torch.cuda.stream(gs):
+        for _ in range(3):
+            r.intersects_closest(o, d)          # builds the wide nodes, sizes every buffer
+    torch.cuda.current_stream(device).wait_stream(gs)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=gs):
+        out = r.intersects_closest(o, d)
+    graph.replay()
+    torch.cuda.synchronize()
+    R = OracleIntersector(v, f, mode=1)
+    e = R.intersects_closest(o.cpu().numpy(), d.cpu().numpy())
+    assert np.array_equal(out[2].cpu().numpy(), e[2]) and np.array_equal(out[3].cpu().numpy(), e[3])
+    v2 = W.displaced(v, seed=3, amplitude=0.1)
+    r.refit(torch.from_numpy(v2).to(device))
+    graph.replay()
+    torch.cuda.synchronize()
+    e2 = OracleIntersector(v2, f, mode=1).intersects_closest(o.cpu().numpy(), d.cpu().numpy())
+    assert not np.array_equal(e2[2], e[2])
+    assert np.array_equal(out[0].cpu().numpy(), e2[0]) and np.array_equal(out[2].cpu().numpy(), e2[2])
+    assert np.array_equal(out[3].cpu().numpy(), e2[3]) and np.array_equal(out[4].cpu().numpy(), e2[4])

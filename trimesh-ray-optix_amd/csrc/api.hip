@@ -186,7 +186,11 @@ int tr_bvh_update(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_
     if (!bvh) return tr_fail(TR_ERR_INVALID_ARG, "bvh == NULL");
     tr_device_guard g;
     if (g.enter(bvh->device) != TR_OK) return tr_fail(TR_ERR_NO_DEVICE, "hipSetDevice failed");
-    return tr_build_impl(bvh, d_vertices, nv, d_faces, nf, (hipStream_t)stream);
+    const int s = tr_build_impl(bvh, d_vertices, nv, d_faces, nf, (hipStream_t)stream);
+    // a handle that has walked 8-wide nodes gets them rebuilt at once, in place where they fit: a HIP graph that
+    // captured a wide launch keeps reading current geometry (as it does with the arena's nodes)
+    if (s == TR_OK) tr_wide_rebuild(bvh, (hipStream_t)stream);
+    return s;
 }
 
 int tr_bvh_refit(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_t* d_faces,
@@ -194,7 +198,9 @@ int tr_bvh_refit(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_t
     if (!bvh) return tr_fail(TR_ERR_INVALID_ARG, "bvh == NULL");
     tr_device_guard g;
     if (g.enter(bvh->device) != TR_OK) return tr_fail(TR_ERR_NO_DEVICE, "hipSetDevice failed");
-    return tr_refit_impl(bvh, d_vertices, nv, d_faces, nf, (hipStream_t)stream);
+    const int s = tr_refit_impl(bvh, d_vertices, nv, d_faces, nf, (hipStream_t)stream);
+    if (s == TR_OK) tr_wide_rebuild(bvh, (hipStream_t)stream);       // (same topology: same records, new boxes, same buffer)
+    return s;
 }
 
 // ---- (de)serialisation: header + the arena, byte for byte -------------------------------------

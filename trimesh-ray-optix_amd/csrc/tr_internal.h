@@ -139,6 +139,9 @@ int64_t tr_arena_used_bytes(int64_t nf);
 void tr_bvh_reset(tr_bvh* bvh);
 int tr_refit_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_t* d_faces,
                   int64_t nf, hipStream_t stream);
+// the 8-wide nodes of a handle that already has them (bvh->wnodes != NULL) again, now, on `stream` (after update / refit);
+// a handle that never walked them builds them on first use (traverse.hip: ensure_wide)
+void tr_wide_rebuild(tr_bvh* bvh, hipStream_t stream);
 // (re)derive the heap-ordered table of the top levels from the grid nodes (after build, refit, upload)
 int tr_top_table_update(tr_bvh* bvh, hipStream_t stream);
 

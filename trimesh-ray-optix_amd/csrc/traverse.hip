@@ -2616,6 +2616,10 @@ int32_t* wide_spill(const tr_bvh* cbvh, hipStream_t stream, size_t elems) {
 
 }  // namespace
 
+void tr_wide_rebuild(tr_bvh* bvh, hipStream_t stream) {
+    if (bvh && bvh->wnodes && !bvh->wide_valid && bvh->num_tris >= 2) (void)ensure_wide(bvh, stream);
+}
+
 extern "C" {
 
 int tr_intersects_any(const tr_bvh* bvh, const tr_rays* rays, uint8_t* d_hit, void* stream) {
