@@ -264,8 +264,9 @@ int tr_trace_stats_query(const tr_bvh *bvh, const tr_rays *rays, int query, tr_t
  *    "lds_top" (0 off / 1 at 128-thread blocks / 2 at 256-thread blocks: closest and first launches that
  *    steal read the grid nodes of the top 7 levels of the hierarchy from a 4-KiB table staged in LDS
  *    while a wave descends them in lockstep -- the north_star's "LDS-staged node packets"),
- *    "occ8" (0 never / 1 from 2 M rays on / 2 always: stealing closest / first launches on the grid nodes run at 8
- *    instead of 7 waves per SIMD: 64 registers and a hand-over that needs half the LDS scratch).
+ *    "occ8" (0 never -- the default since round 4 -- / 1 from 2 M rays on / 2 always: stealing closest / first launches on
+ *    the grid nodes take the hand-over that needs half the LDS scratch; round 3 also capped them at 64 registers for an
+ *    eighth wave per SIMD, which the sign-selected slab test of round 4 no longer fits and outweighs).
  *    "grid_nodes" (0 never / 1 measured on the first launches of a batch size / 2 always: closest and first launches that steal walk the
  *    32-byte grid nodes -- two 16-byte loads per visit -- instead of the exact 64-byte nodes).
  *    "order_transfer" (0/1: the first launch of a new image resolution on a (handle, stream) starts from the block costs

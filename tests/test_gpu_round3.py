@@ -14,7 +14,7 @@ from oracle.oracle import OracleIntersector
 
 pytestmark = pytest.mark.gpu
 LAUNCHES = 14
-OCC8_DEFAULT = 1       # the library's default of option occ8 (tests that flip it restore this)
+OCC8_DEFAULT = 0       # the library's default of option occ8 (tests that flip it restore this)
 
 
 def T(x, dev):

@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.join(ROOT, "scripts"))
 
 def test_no_query_kernel_of_the_shipped_library_spills():
     """VERDICT r03 #7a: every k_query_* instantiation in the shipped code object has vgpr_spill_count 0 (the
-    occupancy attributes are only applied where the kernel was measured to fit) and uses no scratch"""
+    no occupancy attribute forces a register budget a kernel does not fit) and uses no scratch"""
     import code_object_notes as con
     so = os.path.join(ROOT, "trimesh-ray-optix_amd", "lib", "libtriro_hip.so")
     if not os.path.exists(so) or not os.path.exists(con.READELF):
@@ -20,10 +20,10 @@ def test_no_query_kernel_of_the_shipped_library_spills():
     assert len(ks) > 50
     bad = [(k["name"], k["vgpr_spill"], k["scratch"]) for k in ks if k["vgpr_spill"] != 0 or k["scratch"] != 0]
     assert not bad, bad
-    # the 8-waves-per-SIMD variants really fit 64 registers
+    # the stealing closest launch of the headline stays within 7 waves per SIMD (72 registers)
     for k in ks:
-        if "occ8" in k["name"]:
-            assert k["vgpr"] <= 64, k
+        if k["name"].startswith("void k_query_direct<2, false, true, 128, 1, false, true, false>"):
+            assert k["vgpr"] <= 72, k
 
 
 def test_cpu_baseline_scales_with_threads():

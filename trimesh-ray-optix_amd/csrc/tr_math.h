@@ -43,6 +43,9 @@ struct tr_ray {
     float ox, oy, oz;
     float dx, dy, dz;
     float ix, iy, iz;   // clamped reciprocals
+    // byte selectors (v_perm_b32) that pick, from a grid node's 16-bit plane pairs, the planes this ray ENTERS a box
+    // through (lo where its direction is positive, hi where negative) and the ones it leaves through (tr_qnode_slabs)
+    uint32_t sel_n, sel_f, sel_z;
 };
 
 TR_HD uint32_t tr_f2u(float f) { union { float f; uint32_t u; } c; c.f = f; return c.u; }
@@ -61,6 +64,13 @@ TR_HD bool tr_ray_setup(tr_ray& r, float ox, float oy, float oz, float dx, float
     r.ox = ox; r.oy = oy; r.oz = oz;
     r.dx = dx; r.dy = dy; r.dz = dz;
     r.ix = tr_inv(dx); r.iy = tr_inv(dy); r.iz = tr_inv(dz);
+    {
+        const bool nx = r.ix < 0.f, ny = r.iy < 0.f, nz = r.iz < 0.f;
+        // v_perm_b32(hi_pair, lo_pair, sel): selector bytes 0-3 pick bytes of lo_pair, 4-7 of hi_pair
+        r.sel_n = ((ny ? 0x0706u : 0x0302u) << 16) | (nx ? 0x0504u : 0x0100u);
+        r.sel_f = ((ny ? 0x0302u : 0x0706u) << 16) | (nx ? 0x0100u : 0x0504u);
+        r.sel_z = nz ? 0x01000302u : 0x03020100u;
+    }
     return tr_finite(ox) && tr_finite(oy) && tr_finite(oz) && tr_finite(dx) && tr_finite(dy) &&
            tr_finite(dz);
 }

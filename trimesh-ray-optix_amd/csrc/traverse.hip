@@ -389,6 +389,8 @@ __device__ __forceinline__ bool wave_traverse_steal(const tr_bvh_view& b, tr_ray
                 r.ox = __shfl(r.ox, src); r.oy = __shfl(r.oy, src); r.oz = __shfl(r.oz, src);
                 r.dx = __shfl(r.dx, src); r.dy = __shfl(r.dy, src); r.dz = __shfl(r.dz, src);
                 r.ix = __shfl(r.ix, src); r.iy = __shfl(r.iy, src); r.iz = __shfl(r.iz, src);
+        r.sel_n = (uint32_t)__shfl((int)r.sel_n, src); r.sel_f = (uint32_t)__shfl((int)r.sel_f, src); r.sel_z = (uint32_t)__shfl((int)r.sel_z, src);
+                r.sel_n = (uint32_t)__shfl((int)r.sel_n, src); r.sel_f = (uint32_t)__shfl((int)r.sel_f, src); r.sel_z = (uint32_t)__shfl((int)r.sel_z, src);
                 const int own2 = __shfl(owner, src);
                 const float bt = __shfl(res.best_t, src);
                 const int n2 = SLIM ? __shfl(gnode, src) : 0, d2 = SLIM ? __shfl(gdepth, src) : 0;
@@ -608,6 +610,7 @@ __device__ __forceinline__ int wave_count_unordered_steal(const tr_bvh_view& b, 
         r.ox = __shfl(r.ox, src); r.oy = __shfl(r.oy, src); r.oz = __shfl(r.oz, src);
         r.dx = __shfl(r.dx, src); r.dy = __shfl(r.dy, src); r.dz = __shfl(r.dz, src);
         r.ix = __shfl(r.ix, src); r.iy = __shfl(r.iy, src); r.iz = __shfl(r.iz, src);
+        r.sel_n = (uint32_t)__shfl((int)r.sel_n, src); r.sel_f = (uint32_t)__shfl((int)r.sel_f, src); r.sel_z = (uint32_t)__shfl((int)r.sel_z, src);
         const int own2 = __shfl(owner, src), n2 = __shfl(gnode, src), d2 = __shfl(gdepth, src);
         if (take) {
             owner = own2;
@@ -857,8 +860,11 @@ __global__ __launch_bounds__(BS) void k_query_direct(tr_bvh_view b, RayFetch rf,
 // slim hand-over, wave_traverse_steal<..., SLIM>).  Pays where the launch is large -- 4 M rays -3.8 % --
 // and costs where it is small or the waves share lines (262 k ... 590 k rays +1...+8 %, C2 / C4 / interior on
 // forced grid nodes +4...+6 %: profiles/r03_ab_occ8.txt).  Option occ8: 0 never, 1 from 2 M rays on, 2 always.
+// (Round 4: the 64-register cap is gone -- the sign-selected slab test of tr_qnode_slabs needs three more registers than
+// it allowed, and pays more than the eighth wave did; what remains is the slim hand-over at the natural register count,
+// option occ8 default 0.)
 template <int Q>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(8, 8)))
+__global__ __launch_bounds__(128)
 void k_query_direct_occ8(tr_bvh_view b, RayFetch rf, QueryOut out, int xcd_map, int scramble, int tile_w, int steal_min,
                          const uint32_t* __restrict__ order, int order_split, uint32_t* __restrict__ cost,
                          unsigned long long* stats, const int* __restrict__ sel) {
@@ -1102,14 +1108,6 @@ __global__ __launch_bounds__(256) void k_probe_coherence(RayFetch rf, float scen
     }
 }
 
-// The streaming launch is latency-bound (incoherent rays: 62 % of the wave cycles wait on memory,
-// profiles/r03_c5s_summary.md), and its closest-hit instantiation needs 65-67 registers -- one to three
-// more than the 64 that allow 8 instead of 7 waves per SIMD.  Ask the compiler for 8: the compact
-// instantiations fit without a spill (C3 first -7 %, count -5 %, closest / any -2.5 %, C5(ii) shard -2 %:
-// profiles/r03_ab_stream_8waves.jsonl).
-#ifndef TR_STREAM_OCC
-#define TR_STREAM_OCC __attribute__((amdgpu_waves_per_eu(8, 8)))
-#endif
 template <int Q, bool STATS, bool COMPACT, int BS, bool DEEP>
 __device__ __forceinline__ void query_stream_body(const tr_bvh_view& b, const RayFetch& rf, const QueryOut& out,
                                                   int rays_per_wave, int refill_min, int xcd_map,
@@ -1231,10 +1229,9 @@ __device__ __forceinline__ void query_stream_body(const tr_bvh_view& b, const Ra
 #endif
     flush_stats<STATS>(cnt, stats);
 }
-// 8 waves per SIMD are asked for only where the kernel was measured to fit 64 registers without a spill: the
-// compact instantiations (32-bit offsets and trail words) without counters.  The deep / 64-bit / instrumented
-// ones keep the compiler's own register budget (round 3 forced 64 registers on all of them: 1-2 spilled
-// registers and scratch traffic in the inner loop for every mesh of more than 32 levels).
+// (Round 3 ran the compact instantiations at 8 waves per SIMD, 64 registers: -2...-7 %.  Round 4's sign-selected slab
+// test needs three registers more and is worth about as much on these fabric-bound launches -- C3 any -1.7 %, C5(ii)
+// shard -1 %, count +1.5 % at 7 waves: profiles/r04_ab_qsign.txt -- so every instantiation keeps the compiler's budget.)
 template <int Q, bool STATS, bool COMPACT, int BS, bool DEEP = false>
 __global__ __launch_bounds__(BS) void k_query_stream(tr_bvh_view b, RayFetch rf, QueryOut out,
                                                      int rays_per_wave, int refill_min, int xcd_map,
@@ -1242,14 +1239,6 @@ __global__ __launch_bounds__(BS) void k_query_stream(tr_bvh_view b, RayFetch rf,
                                                      unsigned long long* work) {
     query_stream_body<Q, STATS, COMPACT, BS, DEEP>(b, rf, out, rays_per_wave, refill_min, xcd_map, stats, sel, work);
 }
-template <int Q>
-__global__ __launch_bounds__(128) TR_STREAM_OCC void k_query_stream_occ8(tr_bvh_view b, RayFetch rf, QueryOut out,
-                                                     int rays_per_wave, int refill_min, int xcd_map,
-                                                     unsigned long long* stats, const int* __restrict__ sel,
-                                                     unsigned long long* work) {
-    query_stream_body<Q, false, true, 128, false>(b, rf, out, rays_per_wave, refill_min, xcd_map, stats, sel, work);
-}
-
 // ---- multi-hit second pass (shaders.cu:196-246) ----------------------------------------------
 template <int K>
 __global__ __launch_bounds__(256) void k_location(tr_bvh_view b, RayFetch rf, int32_t cap,
@@ -2222,10 +2211,7 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
                     }
                 }
                 if (wide_launched) {
-                } else if (compact && !STATS)
-                    hipLaunchKernelGGL((k_query_stream_occ8<Q>), dim3(grid), dim3(128), 0, stream,
-                                       view, rf, out, rpw, opt.stream_refill, sxc, d_stats, sel, work);
-                else if (compact)
+                } else if (compact)
                     hipLaunchKernelGGL((k_query_stream<Q, STATS, true, 128>), dim3(grid), dim3(128), 0, stream,
                                        view, rf, out, rpw, opt.stream_refill, sxc, d_stats, sel, work);
                 else if (addr32)
