@@ -38,6 +38,23 @@ sys.path.insert(0, os.path.join(ROOT, "trimesh-ray-optix_amd"))
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s spec (6.29 TB/s achievable)
 BYTES_PER_RAY_CLOSEST = 50      # 24 B in + 26 B out
+# --dst-share auto: what finishing one ray somebody else traced costs the destination rank, in units of tracing one ray
+# (expansion alone / trace, measured on one MI355X: profiles/r04_emulate_records.jsonl, + a margin for the receive):
+# c5i: 0.2 ms per M pinhole rays against 0.0127 (4-byte records + the ray) / 0.0092 (12-byte records) ms per M records;
+# c5ii: 0.137 ms per M incoherent rays against 0.0150 / 0.0132
+AUTO_RHO = {("c5i", "slot"): 0.08, ("c5i", "packed"): 0.06, ("c5ii", "slot"): 0.11, ("c5ii", "packed"): 0.10}
+
+
+def resolve_share(args, world):
+    """--dst-share as a number (None = even shards)"""
+    share = args.dst_share
+    if world < 2 or share is None:
+        return None
+    if share == "auto":
+        from triro.ray.sharded import auto_dst_share
+        return round(auto_dst_share(world, AUTO_RHO[(args.workload, args.records)]), 3)
+    share = float(share)
+    return None if share >= 1.0 else share
 C5II_RAYS = 100_000_000
 
 
@@ -55,7 +72,11 @@ def parse(argv=None):
                     help="c5i with N > 1: weak = one res x res batch per GPU (default), strong = ONE res x res batch cut into N row bands")
     ap.add_argument("--gather", action="store_true", help="(default for N > 1) results are gathered to rank 0 inside the timed region")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: leave every rank's results on its own GPU (no exchange)")
-    ap.add_argument("--chunks", type=int, default=0, help="N > 1: chunks per shard of the trace / gather pipeline (0 = auto)")
+    ap.add_argument("--chunks", type=int, default=1,
+                    help="N > 1: chunks per shard of the trace / gather pipeline (0 = the library's rule for ONE call, "
+                         "triro.ray.sharded.default_chunks: ~3 M rays per chunk so that the exchange overlaps the trace inside "
+                         "the call).  Default 1: bench.py keeps two steps in flight, step k's exchange already overlaps step "
+                         "k+1's trace, and whole shards trace faster than pieces (emulated c5ii at 8 ranks: 1.91 against 2.47 ms)")
     ap.add_argument("--force-gather", action="store_true",
                     help="test aid: run the N > 1 result pipeline (packed trace, RCCL exchange, expansion on a side stream, "
                          "double buffering) in a communicator of ONE rank -- what a single-GPU box can check of it; the line is labelled")
@@ -67,9 +88,11 @@ def parse(argv=None):
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo = FUNCTIONAL runs (measure nothing): with --stub the launcher/sharding self-test on CPU; without, "
                          "the real tracer with N ranks sharing the visible GPU(s), device tensors staged through the host")
-    ap.add_argument("--dst-share", default=None,
-                    help="strong-scaling runs: the destination rank traces this fraction of an even shard (float, or 'auto' = "
-                         "triro.ray.sharded.auto_dst_share); default even shards")
+    ap.add_argument("--dst-share", default="auto",
+                    help="N > 1: the destination rank of the gather (it also finishes everybody else's rays) traces this fraction "
+                         "of an even shard: a float (1 = even shards), or 'auto' (default) = triro.ray.sharded.auto_dst_share with "
+                         "the measured cost ratio of the workload and record form (AUTO_RHO).  Weak scaling: the stack of N "
+                         "batches is cut at whole rows, rank 0 takes fewer of them")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="ONE GPU: the destination rank's side of an N-rank run (own trace + N-1 chunks of records arriving as "
                          "device copies + their expansion; triro.ray.sharded.EmulatedWorld) -- a bound, not a measurement")
@@ -77,6 +100,9 @@ def parse(argv=None):
     ap.add_argument("--trace-priority", action="store_true",
                     help="N > 1 / --emulate-world: the step loop (the traces) runs on a HIGH-priority stream, so that the expansion on "
                          "the side stream only takes the wave slots the trace leaves free")
+    ap.add_argument("--records", choices=["slot", "packed"], default="slot",
+                    help="N > 1, closest-hit gather: 'slot' = 4-byte records, rank 0 holds the rays of the whole batch and "
+                         "finishes the query from (ray, slot); 'packed' = 12-byte {slot, u, v} records, rank 0 needs no rays")
     ap.add_argument("--arrival", choices=["copy", "none"], default="copy",
                     help="--emulate-world: how the peers' records arrive: device copies on a copy stream (pessimistic: blit "
                          "kernels) or not at all (they are simply there: expansion cost only)")
@@ -193,6 +219,21 @@ def rotate_y(x, deg):
     return out
 
 
+def stacked_rows(img, world_rows, a, z, roll=7):
+    """rows [a, z) of the weak-scaling batch: `world` images stacked, image k = `img` rolled by k * roll rows
+    (every rank's camera sees the same scene, shifted, so the shards differ).  img: [res, W, 3]."""
+    import numpy as np
+    res = img.shape[0]
+    parts = []
+    g = a
+    while g < z:
+        k, j = divmod(g, res)
+        take = min(res - j, z - g)
+        parts.append(np.roll(img, k * roll, axis=0)[j:j + take])
+        g += take
+    return np.concatenate(parts, axis=0) if parts else img[:0]
+
+
 def run_rank(args):
     import numpy as np
     import torch
@@ -254,9 +295,7 @@ def run_rank(args):
     bshape = None                      # shape of the gathered batch on rank 0
     # strong scaling: with --dst-share rank 0 (the destination of the gather, which also expands everybody
     # else's records) takes a smaller shard
-    share = args.dst_share
-    if isinstance(share, str):
-        share = auto_dst_share(world) if share == "auto" else float(share)
+    share = resolve_share(args, world)
 
     def split_batch(n_rays, quantum):
         if share is not None and share < 1.0 and world > 1:
@@ -284,20 +323,24 @@ def run_rank(args):
             lo, hi = v.min(0) * 1.5, v.max(0) * 1.5
             origins, dirs = W.hash_rays_torch(n, 99, lo, hi, start=lo_ray, device=dev)
     elif args.workload == "c5i":
+        # weak scaling: the job is `world` batches of res x res rays (stacked: [world * res, res]); with even
+        # shards every rank traces one of them, with --dst-share the destination rank takes fewer ROWS of the
+        # stack and the others more (same total, cut at whole rows)
         n_total = args.res * args.res * world
-        n = args.res * args.res
-        lo_ray = rank * n
-        bounds_all = [(k * n, (k + 1) * n) for k in range(world)]
+        bounds_all = split_batch(n_total, args.res if args.rays == "pinhole" else 1)
+        lo_ray, hi_ray = bounds_all[rank]
+        n = hi_ray - lo_ray
         bshape = (world * args.res, args.res) if args.rays == "pinhole" else (n_total,)
         if args.rays == "pinhole":
             o_np, d_np = W.pinhole_grid(args.res, args.res, distance=2.5 * rad)
-            # every rank traces its own batch: same camera, rolled by `rank` rows so shards differ
-            d_np = np.roll(d_np, rank * 7, axis=0)
+            # image k of the stack: same camera, rolled by k rows x 7 so shards differ
+            d_np = stacked_rows(d_np, world, lo_ray // args.res, hi_ray // args.res)
+            o_np = stacked_rows(np.broadcast_to(o_np, (args.res, args.res, 3)), world, lo_ray // args.res, hi_ray // args.res, roll=0)
             origins = torch.from_numpy(np.ascontiguousarray(o_np)).to(dev)
             dirs = torch.from_numpy(np.ascontiguousarray(d_np)).to(dev)
         else:
             lo, hi = v.min(0) * 1.5, v.max(0) * 1.5
-            origins, dirs = W.hash_rays_torch(n, 99, lo, hi, start=rank * n, device=dev)
+            origins, dirs = W.hash_rays_torch(n, 99, lo, hi, start=lo_ray, device=dev)
     else:
         n_total = args.total_rays
         bounds_all = split_batch(n_total, 1)
@@ -323,9 +366,33 @@ def run_rank(args):
     info = r.bvh_info()
 
     gather_on = dist_on and (world > 1 or args.force_gather) and not args.no_gather
-    S = ShardedRayMeshIntersector(r, force_collectives=args.force_gather, dst_share=args.dst_share) if dist_on else None
+    S = ShardedRayMeshIntersector(r, force_collectives=args.force_gather, dst_share=share) if dist_on else None
     lead = origins.dim() - 1
     packed_ok = gather_on and S._can_pack()       # the real tracer; stand-ins take the per-output exchange
+    # 4-byte records: rank 0 (the caller of the reference's API: it hands in the whole batch) holds ALL rays and finishes
+    # the peers' rays from (ray, slot); resident before the clock starts like every other input
+    slot_rec = packed_ok and args.records == "slot" and S.slot_records
+    all_rays = None
+    if slot_rec and rank == 0:
+        if args.workload == "c5i" and args.rays == "pinhole":
+            o_img, d_img = W.pinhole_grid(args.res, args.res, distance=2.5 * rad)
+            if strong_c5i:
+                ao, ad = np.broadcast_to(o_img, d_img.shape), d_img
+            else:
+                ao = stacked_rows(np.broadcast_to(o_img, d_img.shape), world, 0, world * args.res, roll=0)
+                ad = stacked_rows(d_img, world, 0, world * args.res)
+            all_rays = (torch.from_numpy(np.ascontiguousarray(ao)).to(dev), torch.from_numpy(np.ascontiguousarray(ad)).to(dev))
+            if row_quantum is None:
+                all_rays = (all_rays[0].reshape(-1, 3), all_rays[1].reshape(-1, 3))
+        else:
+            lo_b, hi_b = v.min(0) * 1.5, v.max(0) * 1.5
+            po_, pd_ = [], []
+            for s_ in range(0, n_total, 1 << 23):
+                a_o, a_d = W.hash_rays_torch(min(1 << 23, n_total - s_), 99, lo_b, hi_b, start=s_, device=dev)
+                po_.append(a_o)
+                pd_.append(a_d)
+            all_rays = (torch.cat(po_), torch.cat(pd_))
+            del po_, pd_
     pending = []
 
     def flat(x):
@@ -341,7 +408,8 @@ def run_rank(args):
             # chunks land in slices of rank 0's full-size outputs (c5ii / strong: ONE batch; weak: world x n rows)
             return [S._gather_fixed(flat(x), n_total, 0, bounds_all) for x in out]
         pending.append(S.closest_of_shard_async(origins, dirs, n_total, batch_shape=bshape, dst=0,
-                                                chunks=args.chunks or None, bounds=bounds_all, row_quantum=row_quantum))
+                                                chunks=args.chunks or None, bounds=bounds_all, row_quantum=row_quantum,
+                                                records="slot" if slot_rec else "packed", all_rays=all_rays))
         return pending.pop(0).wait() if len(pending) > 1 else None
 
     def drain():
@@ -477,7 +545,8 @@ def run_rank(args):
             if args.force_gather and world == 1:
                 gather_txt += " [--force-gather: the exchange is a self-gather in a one-rank communicator]"
             if packed_ok:
-                gather_txt += " (12 B/ray packed records over RCCL, expanded on rank 0, exchange of step k overlaps trace of step k+1)"
+                gather_txt += (" (4 B/ray slot records over RCCL, finished on rank 0 from its copy of the rays, " if slot_rec else
+                               " (12 B/ray packed records over RCCL, expanded on rank 0, ") + "exchange of step k overlaps trace of step k+1)"
         metric = "Mrays/s closest-hit, 1M-tri mesh, 1024^2 ray batch"
         kernel_name = "k_query_direct<CLOSEST>"
         if strong_c5i:
@@ -507,7 +576,7 @@ def run_rank(args):
                      if gloo else "synthetic"),
             "verified": verified,
             "config": {"workload": wl, "rays_per_gpu": n, "rays_total": n_total, "triangles": int(len(f)),
-                       "parallelism": par, "warmup_steps_done": w_done,
+                       "parallelism": par, "dst_share": share if world > 1 else None, "warmup_steps_done": w_done,
                        "bvh_depth": info["depth"], "bvh_bytes": int(bvh_bytes), "bvh_build_ms": round(build_ms, 2),
                        "hit_fraction": round(float(hit0.float().mean().item()), 4) if hit0 is not None else None},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -722,9 +791,7 @@ def run_emulation(args):
     v, f = W.headline_mesh(args.subdiv)
     rad = float(np.linalg.norm(v, axis=1).max())
     r = RayMeshIntersector(vertices=torch.from_numpy(v).to(dev), faces=torch.from_numpy(f).to(dev))
-    share = args.dst_share
-    if isinstance(share, str):
-        share = auto_dst_share(N) if share == "auto" else float(share)
+    share = resolve_share(args, N)
     res_ = args.res
     lo_box, hi_box = v.min(0) * 1.5, v.max(0) * 1.5
     weak = args.workload == "c5i" and args.scaling == "weak"
@@ -744,18 +811,24 @@ def run_emulation(args):
     if weak:
         n = res_ * res_
         n_total = N * n
-        bounds = [(k * n, (k + 1) * n) for k in range(N)]
+        if share is not None and share < 1.0:
+            bounds = weighted_bounds(n_total, [share] + [1.0] * (N - 1), res_ if pinhole else 1)
+        else:
+            bounds = [(k * n, (k + 1) * n) for k in range(N)]
         bshape = (N * res_, res_) if pinhole else (n_total,)
         if pinhole:
             o_np, d_np = W.pinhole_grid(res_, res_, distance=2.5 * rad)
-            o_t = torch.from_numpy(np.ascontiguousarray(o_np)).to(dev)
+            o_img = np.broadcast_to(o_np, (res_, res_, 3))
 
             def rays_of(k):
-                return o_t, torch.from_numpy(np.roll(d_np, k * 7, axis=0)).to(dev)
+                a, z = bounds[k]
+                return (torch.from_numpy(np.ascontiguousarray(stacked_rows(o_img, N, a // res_, z // res_, roll=0))).to(dev),
+                        torch.from_numpy(np.ascontiguousarray(stacked_rows(d_np, N, a // res_, z // res_))).to(dev))
+            plain_rays = (torch.from_numpy(np.ascontiguousarray(o_img)).to(dev), torch.from_numpy(np.ascontiguousarray(d_np)).to(dev))
         else:
             def rays_of(k):
-                return hash_rays(k * n, (k + 1) * n)
-        plain_rays = rays_of(0)
+                return hash_rays(*bounds[k])
+            plain_rays = hash_rays(0, n)
         plain_n = n
     else:
         n_total = res_ * res_ if args.workload == "c5i" else args.total_rays
@@ -791,8 +864,26 @@ def run_emulation(args):
         torch.cuda.synchronize()
 
     # ---- the peers' records and the expected dense results, outside the clock ----------------------
-    peer_records = torch.empty((n_total, 3), dtype=torch.int32, device=dev)
+    slot_rec = args.records == "slot"            # 4-byte records: rank 0 holds the rays of the whole batch
+    peer_records = torch.empty((n_total,) if slot_rec else (n_total, 3), dtype=torch.int32, device=dev)
     slots = os.environ.get("TRIRO_PACKED_SLOTS", "1") != "0"      # the record form ShardedRayMeshIntersector will expand
+
+    def trace_records(ok_, dk_, out_):
+        if slot_rec:
+            r.intersects_closest_slots(ok_, dk_, out=out_)
+        else:
+            r.intersects_closest_packed(ok_, dk_, out=out_, slots=slots)
+    all_rays = None
+    if slot_rec:
+        if weak and pinhole:
+            all_rays = (torch.from_numpy(np.ascontiguousarray(stacked_rows(o_img, N, 0, N * res_, roll=0))).to(dev),
+                        torch.from_numpy(np.ascontiguousarray(stacked_rows(d_np, N, 0, N * res_))).to(dev))
+        elif weak:
+            all_rays = hash_rays(0, n_total)
+        else:
+            all_rays = plain_rays
+        if row_quantum is None:
+            all_rays = (all_rays[0].reshape(-1, 3), all_rays[1].reshape(-1, 3))
     expected = []
     peer_ms = 0.0
     for k in range(N):
@@ -803,15 +894,15 @@ def run_emulation(args):
             continue
         if k > 0:
             for _ in range(3):
-                r.intersects_closest_packed(ok_, dk_, out=peer_records[a:z], slots=slots)
+                trace_records(ok_, dk_, peer_records[a:z])
             if k == 1:      # what a peer's step costs (its trace into records; it sends them asynchronously)
                 reps = 20 if z - a < (1 << 22) else 5
                 for _ in range(reps if z - a < (1 << 22) else 2):
-                    r.intersects_closest_packed(ok_, dk_, out=peer_records[a:z], slots=slots)
+                    trace_records(ok_, dk_, peer_records[a:z])
                 sync()
                 t0 = time.perf_counter()
                 for _ in range(reps):
-                    r.intersects_closest_packed(ok_, dk_, out=peer_records[a:z], slots=slots)
+                    trace_records(ok_, dk_, peer_records[a:z])
                 sync()
                 peer_ms = (time.perf_counter() - t0) / reps * 1e3
         expected.append([x.reshape(z - a, *x.shape[ok_.dim() - 1:]).clone() for x in r.intersects_closest(ok_, dk_)])
@@ -845,7 +936,7 @@ def run_emulation(args):
 
     def step():
         pending.append(E.closest_of_shard_async(o0, d0, n_total, batch_shape=bshape, dst=0, chunks=args.chunks or None,
-                                                bounds=bounds, row_quantum=row_quantum))
+                                                bounds=bounds, row_quantum=row_quantum, records=args.records, all_rays=all_rays))
         return pending.pop(0).wait() if len(pending) > 1 else None
 
     def drain():
@@ -879,18 +970,28 @@ def run_emulation(args):
     flat = [x.reshape(n_total, *x.shape[len(bshape):]) for x in out]
     pa, pz = bounds[1][0], bounds[-1][1]
     rl = {"row_length": row_quantum} if (slots and row_quantum) else {}
+
+    def expand_all():
+        if slot_rec:
+            if row_quantum:
+                ro, rd = all_rays[0][pa // row_quantum:pz // row_quantum], all_rays[1][pa // row_quantum:pz // row_quantum]
+            else:
+                ro, rd = all_rays[0][pa:pz], all_rays[1][pa:pz]
+            r.closest_from_slots(ro, rd, peer_records[pa:pz], outs=tuple(x[pa:pz] for x in flat), row_length=row_quantum or 0)
+        else:
+            r.closest_expand(peer_records[pa:pz], outs=tuple(x[pa:pz] for x in flat), slots=slots, **rl)
     for _ in range(5):
-        r.closest_expand(peer_records[pa:pz], outs=tuple(x[pa:pz] for x in flat), slots=slots, **rl)
+        expand_all()
     sync()
     t0 = time.perf_counter()
     for _ in range(20):
-        r.closest_expand(peer_records[pa:pz], outs=tuple(x[pa:pz] for x in flat), slots=slots, **rl)
+        expand_all()
     sync()
     expand_ms = (time.perf_counter() - t0) / 20 * 1e3
     # ---- verification: every row against a dense trace of that rank's rays ---------------------------
     verified = True
     out = E.closest_of_shard_async(o0, d0, n_total, batch_shape=bshape, dst=0, chunks=args.chunks or None,
-                                   bounds=bounds, row_quantum=row_quantum).wait()
+                                   bounds=bounds, row_quantum=row_quantum, records=args.records, all_rays=all_rays).wait()
     sync()
     flat = [x.reshape(n_total, *x.shape[len(bshape):]) for x in out]
     for k in range(N):
@@ -916,16 +1017,17 @@ def run_emulation(args):
                                f"({args.rays if args.workload == 'c5i' else 'hash'} rays), headline mesh {len(f)} tris",
                    "rays_total": n_total, "rays_rank0": bounds[0][1] - bounds[0][0], "rays_peer": bounds[1][1] - bounds[1][0],
                    "dst_share": share, "chunks": args.chunks or "auto", "arrival_priority": bool(args.arrival_priority),
-                   "arrival": args.arrival, "trace_priority": bool(args.trace_priority), "opts": list(args.opt), "record_form": "slot" if slots else "face"},
+                   "arrival": args.arrival, "trace_priority": bool(args.trace_priority), "opts": list(args.opt), "record_form": "slot only, 4 B" if slot_rec else ("slot, u, v: 12 B" if slots else "face, u, v: 12 B")},
         "emulation": {"plain_1gpu_ms_per_step": round(plain_ms, 4), "plain_1gpu_rays": plain_n,
                       "rank0_ms_per_step": round(rank0_ms, 4), "rank0_own_trace_only_ms": round(own_ms, 4),
                       "peer_trace_ms_per_step": round(peer_ms, 4), "expansion_alone_ms": round(expand_ms, 4),
                       "expansion_rays": pz - pa,
-                      "expansion_GBps": round((pz - pa) * 38 / (expand_ms * 1e-3) / 1e9, 1) if expand_ms > 0 else None,
+                      "expansion_GBps": round((pz - pa) * (54 if slot_rec else 38) / (expand_ms * 1e-3) / 1e9, 1) if expand_ms > 0 else None,
                       "implied_scaling_vs_1gpu": round(implied, 3),
                       "note": "implied = N x plain / max(rank0, peer) for weak scaling, plain / max(rank0, peer) for strong; "
                               "arrival = device-to-device copies (read + write; an xGMI receive only writes); link time is not "
-                              "modelled (12 B/ray: 12.6 MB per peer and 1 M rays = 0.1 ms at 120 GB/s, overlapped)"},
+                              "modelled (12-byte records: 12.6 MB per peer and 1 M rays = 0.2 ms on one 76.8 GB/s link direction at 80 %; "
+                              "4-byte records: 0.07 ms); expansion_GBps counts 38 B/ray (12-byte records) or 54 B/ray (4-byte records + the ray)"},
     }
     print(json.dumps(res), flush=True)
     return 0 if verified else 3

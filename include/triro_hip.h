@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define TR_ABI_VERSION 7
+#define TR_ABI_VERSION 8
 #define TR_MAX_ANYHIT_SIZE 8 /* LaunchParams.h:8  (per-ray cap of intersects_location) */
 #define TR_MAX_SIZE_LENGTH 4 /* LaunchParams.h:9  (ray tensors have <= 4 dims)         */
 #define TR_MAX_HITS_CAP 32   /* largest `cap` tr_intersects_location_fill accepts      */
@@ -179,12 +179,24 @@ int tr_intersects_closest_packed_slots(const tr_bvh *bvh, const tr_rays *rays, t
                                        void *stream);
 int tr_closest_expand_slots(const tr_bvh *bvh, const tr_packed_hit *d_packed, int64_t n, uint8_t *d_hit,
                             uint8_t *d_front, int32_t *d_tri, float *d_loc3, float *d_uv2, void *stream);
-/* ... for records that are ROWS OF AN IMAGE (row_length pixels each; n a multiple of 8 rows, row_length of 32): a wave
- *    expands 8x8 pixel tiles, so that the neighbouring rays that hit the same triangle read its record once.  Any
- *    other shape (row_length 0 included) takes the linear kernel.  Same outputs.                              */
+/* ... for records that are ROWS OF AN IMAGE (row_length pixels each, a multiple of 32; a multiple of 8 rows, or any
+ *    number from 64 rows on): a wave expands blocks of 8 rows x 32 pixels, so that the neighbouring rays that hit the
+ *    same triangle read its record once.  Any other shape (row_length 0 included) takes the linear kernel.  Same outputs. */
 int tr_closest_expand_slots_rows(const tr_bvh *bvh, const tr_packed_hit *d_packed, int64_t n, int64_t row_length,
                                  uint8_t *d_hit, uint8_t *d_front, int32_t *d_tri, float *d_loc3, float *d_uv2,
                                  void *stream);
+
+/* ... and the 4-BYTE record (ABI 8), for a destination that HOLDS THE RAYS (the reference's call hands the whole batch
+ *    to one process: ray_optix.py:121-146; a sharded front end sees it on every rank): the traversal writes only the
+ *    arena slot of the nearest triangle, -1 for a miss (tr_intersects_closest_slots: d_slot[nray] int32), and
+ *    tr_closest_from_slots finishes the query from (ray, slot) exactly as the dense call does at its end -- (det, U, V)
+ *    of the ray against that one triangle, then the barycentric outputs (shaders.cu:139-151) -- so hit / front / tri /
+ *    loc / uv are the dense call's bits.  `rays` describes the rays the slots belong to, in the same order (any
+ *    strides, nray = number of slots); row_length as for tr_closest_expand_slots_rows (0 = no image rows).  Same
+ *    replica rule as the slot form above.  4 B per ray cross the links instead of 12.                      */
+int tr_intersects_closest_slots(const tr_bvh *bvh, const tr_rays *rays, int32_t *d_slot, void *stream);
+int tr_closest_from_slots(const tr_bvh *bvh, const tr_rays *rays, const int32_t *d_slot, int64_t row_length,
+                          uint8_t *d_hit, uint8_t *d_front, int32_t *d_tri, float *d_loc3, float *d_uv2, void *stream);
 
 /* -- multi-hit (intersectsLocation, ray.cpp:324-378):
  *    tr_hits_scan replaces the torch glue of ray.cpp:333-342: d_offsets[i] = exclusive

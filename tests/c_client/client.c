@@ -159,6 +159,20 @@ int main(void) {
         }
         CHECK_HIP(hipFree(d_rec)); CHECK_HIP(hipFree(d_v2)); CHECK_HIP(hipFree(d_f2));
     }
+    /* ... and as 4-byte records for a destination that holds the rays (ABI 8): the slot, then the end of the query */
+    {
+        int32_t *d_slot = (int32_t *)device_zeros(8), slot[2];
+        CHECK_HIP(hipMemset(d_hit, 7, 2)); CHECK_HIP(hipMemset(d_loc, 0xff, 24));
+        CHECK_TR(tr_intersects_closest_slots(bvh, &rays, d_slot, NULL));
+        to_host(slot, d_slot, 8);
+        EXPECT(slot[0] >= 0 && slot[0] < 2 && slot[1] >= 0 && slot[1] < 2 && slot[0] != slot[1]);
+        CHECK_TR(tr_closest_from_slots(bvh, &rays, d_slot, 0, d_hit, d_front, d_tri, d_loc, d_uv, NULL));
+        to_host(hit, d_hit, 2); to_host(front, d_front, 2); to_host(tri, d_tri, 8); to_host(loc, d_loc, 24); to_host(uv, d_uv, 16);
+        EXPECT(hit[0] == 1 && front[0] == 0 && tri[0] == 1 && hit[1] == 1 && front[1] == 1 && tri[1] == 0);
+        EXPECT(feq(loc[2], -1.f) && feq(uv[0], 0.25f) && feq(uv[1], 0.5f) && feq(loc[4], 0.1f) && feq(uv[2], 0.2f) && feq(uv[3], 0.6f));
+        EXPECT(tr_closest_from_slots(bvh, &rays, NULL, 0, d_hit, d_front, d_tri, d_loc, d_uv, NULL) == TR_ERR_INVALID_ARG);
+        CHECK_HIP(hipFree(d_slot));
+    }
 
     /* T1 (test/test.py:6-13) through update: one triangle, a hit and a miss; broadcast origin on the second call */
     {

@@ -37,10 +37,14 @@ try:
         exp_l = r.intersects_location(bo, bd)
         exp_n = r.intersects_count(bo, bd)
         assert 0.02 < float(exp[0].float().mean()) < 0.95, name
-        for mode in ("packed", "dense"):
+        # "packed": 4-byte slot records (the batch is visible on every rank, the destination holds the rays);
+        # "packed12": the 12-byte {slot, u, v} records of a destination without the rays; "dense": per-output gathers
+        for mode in ("packed", "packed12", "dense"):
             for share in (None, 0.5):
-                S = ShardedRayMeshIntersector(r, gather_mode=mode, dst_share=share)
-                assert S._stage and S.world == world
+                S = ShardedRayMeshIntersector(r, gather_mode=mode.rstrip("12"), dst_share=share)
+                if mode == "packed12":
+                    S.slot_records = False
+                assert S._stage and S.world == world and (S.slot_records or mode != "packed")
                 for dst in (0, 1 % world, None):
                     for chunks in (1, 3):
                         got = S.intersects_closest(bo, bd, dst=dst, chunks=chunks)
@@ -76,6 +80,12 @@ try:
                     if rank == 0:
                         for a, e in zip(g, exp):
                             assert torch.equal(a, e), (name, mode, "own shard only")
+                    if S.slot_records:     # ... whose destination was handed the whole batch: 4-byte records
+                        g = S.closest_of_shard_async(bo[a_:z_].contiguous(), bd[a_:z_].contiguous(), n, dst=0, chunks=3, bounds=bb,
+                                                     records="slot", all_rays=(bo, bd) if rank == 0 else None).wait()
+                        if rank == 0:
+                            for a, e in zip(g, exp):
+                                assert torch.equal(a, e), (name, mode, "own shard only, slot records")
     torch.cuda.synchronize()
     dist.barrier()
     print("OK")

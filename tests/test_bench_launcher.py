@@ -25,7 +25,7 @@ def run_bench(*args, timeout=240):
 @pytest.mark.timeout(300)
 def test_gpus2_launches_two_ranks_strong_scaling_c5ii():
     p = run_bench("--gpus", "2", "--backend", "gloo", "--stub", "bench_stub:make", "--workload", "c5ii",
-                  "--total-rays", "10001", "--subdiv", "2", "--steps", "3", "--warmup", "1", "--min-warmup-ms", "0")
+                  "--total-rays", "10001", "--subdiv", "2", "--steps", "3", "--warmup", "1", "--min-warmup-ms", "0", "--dst-share", "1")
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, "exactly one JSON line on stdout"
@@ -40,11 +40,25 @@ def test_gpus2_launches_two_ranks_strong_scaling_c5ii():
 @pytest.mark.timeout(300)
 def test_gpus2_weak_scaling_default_workload():
     p = run_bench("--gpus", "2", "--backend", "gloo", "--stub", "bench_stub:make", "--subdiv", "2", "--res", "64",
-                  "--steps", "2", "--warmup", "1", "--min-warmup-ms", "0", "--gather")
+                  "--steps", "2", "--warmup", "1", "--min-warmup-ms", "0", "--gather", "--dst-share", "1")
     assert p.returncode == 0, p.stderr[-2000:]
     r = json.loads(p.stdout.strip().splitlines()[-1])
     assert r["n_gpus"] == 2 and r["scaling"] == "weak"
-    assert r["config"]["rays_per_gpu"] == 64 * 64 and r["config"]["rays_total"] == 2 * 64 * 64
+    assert r["config"]["rays_per_gpu"] == 64 * 64 and r["config"]["rays_total"] == 2 * 64 * 64 and r["config"]["dst_share"] is None
+    # the default: rank 0 (which also finishes the other rank's rays) takes a little less than an even shard
+    p = run_bench("--gpus", "2", "--backend", "gloo", "--stub", "bench_stub:make", "--subdiv", "2", "--res", "64",
+                  "--steps", "2", "--warmup", "1", "--min-warmup-ms", "0")
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads(p.stdout.strip().splitlines()[-1])
+    assert r["scaling"] == "weak" and r["config"]["rays_total"] == 2 * 64 * 64 and r["verified"] is True
+    assert 0.8 < r["config"]["dst_share"] < 1.0 and 0.4 * 2 * 64 * 64 < r["config"]["rays_per_gpu"] < 64 * 64
+    # weighted shards of the weak-scaling stack: rank 0 takes fewer ROWS of the [2 x 64, 64] batch, same total
+    p = run_bench("--gpus", "2", "--backend", "gloo", "--stub", "bench_stub:make", "--subdiv", "2", "--res", "64",
+                  "--steps", "3", "--warmup", "1", "--min-warmup-ms", "0", "--dst-share", "0.5")
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads(p.stdout.strip().splitlines()[-1])
+    assert r["scaling"] == "weak" and r["config"]["rays_total"] == 2 * 64 * 64 and r["verified"] is True
+    assert r["config"]["rays_per_gpu"] == 43 * 64          # round(128 rows x 0.5 / 1.5) = 43 rows on rank 0
 
 
 @pytest.mark.timeout(300)
@@ -62,7 +76,7 @@ def test_gpus2_gathers_by_default_and_strong_scaling_of_one_image():
     p = run_bench(*common, "--scaling", "strong")
     assert p.returncode == 0, p.stderr[-2000:]
     r = json.loads(p.stdout.strip().splitlines()[-1])
-    assert r["scaling"] == "strong" and r["config"]["rays_total"] == 64 * 64 and r["config"]["rays_per_gpu"] == 32 * 64
+    assert r["scaling"] == "strong" and r["config"]["rays_total"] == 64 * 64 and 24 * 64 <= r["config"]["rays_per_gpu"] <= 32 * 64
     assert r["verified"] is True and "row bands" in r["config"]["workload"]
     p = run_bench(*common, "--no-gather")
     assert p.returncode == 0, p.stderr[-2000:]

@@ -292,7 +292,9 @@ def test_bench_result_pipeline_on_rccl_one_rank():
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     for extra in (["--workload", "c5i"], ["--workload", "c5i", "--scaling", "strong"],
-                  ["--workload", "c5ii", "--total-rays", "7000001", "--chunks", "3"]):
+                  ["--workload", "c5ii", "--total-rays", "7000001", "--chunks", "3"],
+                  ["--workload", "c5i", "--records", "packed"],
+                  ["--workload", "c5ii", "--total-rays", "7000001", "--chunks", "3", "--records", "packed"]):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
                "--master-port", str(29700 + os.getpid() % 200), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "6",
                "--warmup", "2", "--min-warmup-ms", "0", "--no-cpu-baseline", "--no-companions", "--force-gather"] + extra
@@ -301,7 +303,8 @@ def test_bench_result_pipeline_on_rccl_one_rank():
         line = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')][-1]
         r = json.loads(line)
         assert r["verified"] is True and r["n_gpus"] == 1 and r["value"] > 100
-        assert "12 B/ray packed" in r["config"]["parallelism"] and "--force-gather" in r["config"]["parallelism"]
+        want = "12 B/ray packed" if "packed" in extra else "4 B/ray slot"       # (round 4: rank 0 holds the rays by default)
+        assert want in r["config"]["parallelism"] and "--force-gather" in r["config"]["parallelism"]
 
 
 def test_packed_closest_edge_cases(device):

@@ -44,12 +44,14 @@ def test_two_ranks_share_one_gpu_real_tracer():
 
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("extra", [
-    [],                                                            # c5i weak: one 256^2 batch per rank
+    [],                                                            # c5i weak: the stack of batches cut at weighted rows
+    ["--dst-share", "1"],                                          # ... one 256^2 batch per rank (even shards)
+    ["--records", "packed"],                                       # ... 12-byte records (rank 0 without the rays)
     ["--scaling", "strong"],                                       # ONE batch in two row bands
     ["--scaling", "strong", "--dst-share", "0.5"],                 # ... rank 0 takes a smaller band
     ["--workload", "c5ii", "--total-rays", "300001"],              # ragged shards of one flat batch
     ["--workload", "c5ii", "--total-rays", "300001", "--dst-share", "auto", "--chunks", "3"],
-], ids=["weak", "strong", "strong-weighted", "c5ii-ragged", "c5ii-weighted-chunks"])
+], ids=["weak", "weak-even", "weak-packed12", "strong", "strong-weighted", "c5ii-ragged", "c5ii-weighted-chunks"])
 def test_bench_two_ranks_on_one_gpu_over_gloo(extra):
     """bench.py --gpus 2 --backend gloo with the REAL tracer (both ranks on cuda:0): the launcher, the pipeline and
     the self-verification (last timed step == cold first call) with two ranks and device tensors"""
@@ -62,11 +64,13 @@ def test_bench_two_ranks_on_one_gpu_over_gloo(extra):
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("extra", [
     ["--emulate-world", "8"],
+    ["--emulate-world", "8", "--dst-share", "1"],
+    ["--emulate-world", "8", "--records", "packed"],
     ["--emulate-world", "4", "--scaling", "strong", "--dst-share", "auto"],
     ["--emulate-world", "8", "--workload", "c5ii", "--total-rays", "2000003", "--dst-share", "auto", "--chunks", "2"],
-    ["--emulate-world", "3", "--workload", "c5ii", "--total-rays", "500000", "--arrival-priority"],
+    ["--emulate-world", "3", "--workload", "c5ii", "--total-rays", "500000", "--arrival-priority", "--records", "packed"],
     ["--emulate-world", "8", "--arrival", "none", "--opt", "expand4=3"],
-], ids=["weak8", "strong4-weighted", "c5ii8-weighted", "c5ii3-priority", "weak8-no-arrival-tiles"])
+], ids=["weak8", "weak8-even", "weak8-packed12", "strong4-weighted", "c5ii8-weighted", "c5ii3-priority", "weak8-no-arrival-tiles"])
 def test_emulated_destination_rank_is_bit_exact(extra):
     """bench.py --emulate-world: rank 0's step with N-1 chunks of records arriving as device copies and expanded on
     the side stream; every row of the gathered outputs == a dense trace of that rank's rays"""
@@ -260,3 +264,106 @@ def test_learned_order_survives_a_change_of_resolution(device):
             assert np.array_equal(hit.cpu().numpy(), eh.reshape(-1))
     finally:
         hops.set_option("order_transfer", 1)
+
+
+def test_image_batches_with_a_ragged_last_tile_row(device):
+    """Image-shaped batches whose row count is NOT a multiple of 8 (from 64 rows on) keep the tile launch shapes: the
+    block -> ray map is laid over the batch padded to whole 8-row tiles and the padding is out of range.  Every query
+    over 14 launches (plain first launch, learned order, split slots) == the oracle; the slot-form expansion in
+    8 x 32 blocks with a partial last row of blocks == the dense trace, and writes nothing outside its rows."""
+    from triro.ray.ray_optix import RayMeshIntersector
+    v, f = W.headline_mesh(6)
+    R = OracleIntersector(v, f, mode=1)
+    r = RayMeshIntersector(vertices=torch.from_numpy(v).to(device), faces=torch.from_numpy(f).to(device))
+    rad = float(np.linalg.norm(v, axis=1).max())
+    for H, Wd in ((203, 352), (69, 1024), (1050, 96)):
+        o_np, d_np = W.pinhole_grid(Wd, H, distance=2.5 * rad)
+        o = torch.from_numpy(np.ascontiguousarray(o_np)).to(device)
+        d = torch.from_numpy(d_np).to(device)
+        eh, ef, et, el, eu = R.intersects_closest(o_np, d_np)
+        ec = R.intersects_count(o_np, d_np)
+        assert 0.05 < eh.mean() and (eh.mean() < 0.98 or Wd < 128)       # (the narrow band sees only the mesh)
+        for k in range(14):
+            hit, front, tri, loc, uv = r.intersects_closest(o, d)
+            assert np.array_equal(hit.cpu().numpy(), eh) and np.array_equal(front.cpu().numpy(), ef), (H, Wd, k)
+            assert np.array_equal(tri.cpu().numpy(), et) and np.array_equal(loc.cpu().numpy(), el), (H, Wd, k)
+            assert np.array_equal(uv.cpu().numpy(), eu), (H, Wd, k)
+            if k % 4 == 0:
+                assert np.array_equal(r.intersects_count(o, d).cpu().numpy(), ec), (H, Wd, k)
+                assert np.array_equal(r.intersects_first(o, d).cpu().numpy(), et), (H, Wd, k)
+                assert np.array_equal(r.intersects_any(o, d).cpu().numpy(), eh), (H, Wd, k)
+        assert r.as_wrapper.last_launch()["tile_rows_lg"] > 0, (H, Wd)          # a tile shape, not rows of 64 pixels
+        loc_l, ray_l, tri_l = r.intersects_location(o, d)
+        e_loc, e_ray, e_tri = R.intersects_location(o_np, d_np)
+        assert np.array_equal(ray_l.cpu().numpy(), e_ray) and np.array_equal(tri_l.cpu().numpy(), e_tri)
+        assert np.array_equal(loc_l.cpu().numpy(), e_loc)
+        # expansion of a row range with a ragged number of rows into slices of full-size outputs
+        n = H * Wd
+        rec = r.intersects_closest_packed(o, d, slots=True)
+        exp = [torch.from_numpy(x.reshape(n, *x.shape[2:])).to(device) for x in (eh, ef, et, el, eu)]
+        for rows in ((0, H), (3, H - 2), (8, 8 + 65)):
+            a_, z_ = rows[0] * Wd, rows[1] * Wd
+            outs = (torch.zeros(n, dtype=torch.bool, device=device), torch.zeros(n, dtype=torch.bool, device=device),
+                    torch.full((n,), -7, dtype=torch.int32, device=device), torch.full((n, 3), 9.0, device=device),
+                    torch.full((n, 2), 9.0, device=device))
+            r.closest_expand(rec[a_:z_], outs=tuple(x[a_:z_] for x in outs), slots=True, row_length=Wd)
+            for a, e in zip(outs, exp):
+                assert torch.equal(a[a_:z_], e[a_:z_]), (H, Wd, rows)
+            assert int((outs[2][:a_] != -7).sum()) == 0 and int((outs[2][z_:] != -7).sum()) == 0
+            assert int((outs[3][:a_] != 9.0).sum()) == 0 and int((outs[3][z_:] != 9.0).sum()) == 0
+
+
+def test_four_byte_slot_records_finish_to_the_dense_outputs(device):
+    """tr_intersects_closest_slots (4 B/ray: the arena slot of the nearest triangle) + tr_closest_from_slots (the end of
+    a dense trace, from the ray and that one triangle) == tr_intersects_closest bit for bit: image and incoherent
+    batches, strided and stride-0 rays, a replica's records, row ranges into slices of full-size outputs in both
+    kernel shapes (blocks of 8 x 32 pixels / linear), small ranges, misses, corrupt slots."""
+    from triro.ray.ray_optix import RayMeshIntersector
+    v, f = W.headline_mesh(6)
+    mk = lambda: RayMeshIntersector(vertices=torch.from_numpy(v).to(device), faces=torch.from_numpy(f).to(device))  # noqa: E731
+    r, replica = mk(), mk()
+    rad = float(np.linalg.norm(v, axis=1).max())
+    H, Wd = 203, 352
+    o_np, d_np = W.pinhole_grid(Wd, H, distance=2.5 * rad)
+    o = torch.from_numpy(o_np[:1, :1].copy()).to(device).expand(H, Wd, 3)            # the README's stride-0 origin
+    d = torch.from_numpy(d_np).to(device)
+    lo, hi = v.min(0) * 1.5, v.max(0) * 1.5
+    ho, hd = W.hash_rays_torch(3_000_001, 99, lo, hi, device=device)                 # the streaming launch
+    # a non-contiguous view: every second ray of a twice as long batch
+    so, sd = W.hash_rays_torch(200_000, 7, lo, hi, device=device)
+    so, sd = so[::2], sd[::2]
+    for name, (oo, dd) in {"image": (o, d), "hash": (ho, hd), "strided": (so, sd)}.items():
+        exp = r.intersects_closest(oo, dd)
+        assert 0.02 < float(exp[0].float().mean()) < 0.98, name
+        for k in range(3):          # cold, learned order, split slots
+            sl = replica.intersects_closest_slots(oo, dd)
+        assert sl.dtype == torch.int32 and tuple(sl.shape) == (oo.numel() // 3,)
+        assert torch.equal(sl.reshape(exp[0].shape) >= 0, exp[0]), name
+        # against the 12-byte slot form
+        rec = r.intersects_closest_packed(oo, dd, slots=True)
+        assert torch.equal(torch.where(rec[:, 0] >= 0, rec[:, 0] & 0x3fffffff, torch.full_like(rec[:, 0], -1)), sl), name
+        got = r.closest_from_slots(oo, dd, sl, row_length=Wd if name == "image" else 0)
+        for a, e in zip(got, exp):
+            assert torch.equal(a, e), name
+        n = sl.shape[0]
+        flat = [x.reshape(n, *x.shape[oo.dim() - 1:]) for x in exp]
+        fo, fd = oo.reshape(-1, 3) if name != "image" else None, dd.reshape(-1, 3) if name != "image" else None
+        ranges = ((0, 5), (3, 4000), (7, 5000 + 7), (1001, n - 3)) if name != "image" else ((0, H), (3, H - 2), (8, 8 + 65), (16, 24))
+        for a_, z_ in ranges:
+            if name == "image":
+                ro, rd, rl = oo[a_:z_], dd[a_:z_], Wd
+                a_, z_ = a_ * Wd, z_ * Wd
+            else:
+                ro, rd, rl = fo[a_:z_], fd[a_:z_], 0
+            outs = (torch.zeros(n, dtype=torch.bool, device=device), torch.zeros(n, dtype=torch.bool, device=device),
+                    torch.full((n,), -7, dtype=torch.int32, device=device), torch.full((n, 3), 9.0, device=device),
+                    torch.full((n, 2), 9.0, device=device))
+            r.closest_from_slots(ro, rd, sl[a_:z_], outs=tuple(x[a_:z_] for x in outs), row_length=rl)
+            for a, e in zip(outs, flat):
+                assert torch.equal(a[a_:z_], e[a_:z_]), (name, a_, z_)
+            assert int((outs[2][:a_] != -7).sum()) == 0 and int((outs[2][z_:] != -7).sum()) == 0
+        bad = sl.clone()
+        bad[::5] = 0x3fffffff           # beyond the arena: a miss, no memory access
+        assert not bool(r.closest_from_slots(oo, dd, bad)[0].reshape(-1)[::5].any())
+    with pytest.raises(ValueError):
+        r.closest_from_slots(ho, hd, sl[:5])

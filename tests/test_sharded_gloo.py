@@ -101,6 +101,42 @@ class CpuLocalInto(CpuLocal):
         return outs
 
 
+class CpuLocalSlots(CpuLocalInto):
+    """... and with the slot forms of the records (RayMeshIntersector.packed_slots / slot_records).  The stand-in's "slot"
+    is the face index; closest_from_slots re-traces the rays it is handed and CHECKS that they are the rays the slots
+    belong to -- the pairing of ray rows and record rows on the destination is what this exercises."""
+    packed_slots = True
+    slot_records = True
+
+    def __init__(self, v, f):
+        super().__init__(v, f)
+        self.slot_calls, self.from_calls = [], []
+
+    def intersects_closest_packed(self, o, d, out=None, slots=False):
+        return CpuLocal.intersects_closest_packed(self, o, d, out)
+
+    def closest_expand(self, packed, batch_shape=None, outs=None, slots=False, row_length=0):
+        return CpuLocal.closest_expand(self, packed, batch_shape, outs)
+
+    def intersects_closest_slots(self, o, d, out=None):
+        self.slot_calls.append((o.numel() // 3, tuple(o.shape)))
+        rec = CpuLocal.intersects_closest_packed(self, o, d)
+        self.packed_calls.pop()
+        t = torch.where(rec[:, 0] >= 0, rec[:, 0] & 0x3fffffff, torch.full_like(rec[:, 0], -1)).to(torch.int32)
+        if out is None:
+            return t
+        out.copy_(t)
+        return out
+
+    def closest_from_slots(self, o, d, slots, outs=None, row_length=0):
+        self.from_calls.append((o.numel() // 3, tuple(o.shape), int(row_length)))
+        rec = CpuLocal.intersects_closest_packed(self, o.contiguous(), d.contiguous())
+        self.packed_calls.pop()
+        mine = torch.where(rec[:, 0] >= 0, rec[:, 0] & 0x3fffffff, torch.full_like(rec[:, 0], -1)).to(torch.int32)
+        assert torch.equal(mine, slots.reshape(-1)), "the destination paired record rows with the wrong rays"
+        return CpuLocal.closest_expand(self, rec, batch_shape=o.shape[:-1], outs=outs)
+
+
 def _worker(rank, world, port, q):
     for p in (ROOT, os.path.join(ROOT, "trimesh-ray-optix_amd")):
         if p not in sys.path:
@@ -263,6 +299,46 @@ def _worker(rank, world, port, q):
                 c8 = D.intersects_closest(o, d, stream_compaction=True, dst=None)
                 for a, e in zip(c8, ref.intersects_closest(fo, fd, stream_compaction=True)):
                     ok &= torch.equal(a.reshape(e.shape), e)
+        # ---- 4-byte records: the batch is visible on every rank, so the destination holds the rays -------------
+        for stage in (False, True):
+            for share in (None, 0.5):
+                Z = ShardedRayMeshIntersector(CpuLocalSlots(v, f), dst_share=share, stage_through_host=stage or None)
+                ok &= Z.slot_records
+                for dst_, ch in ((0, 3), (1, 1), (None, 2)):
+                    for lst in (Z.local.into_calls, Z.local.packed_calls, Z.local.slot_calls, Z.local.from_calls):
+                        lst.clear()
+                    g9 = Z.intersects_closest(o, d, dst=dst_, chunks=ch)
+                    bb = Z.bounds(851, dst_, 37, weighted=True)
+                    mine_rays = bb[rank][1] - bb[rank][0]
+                    if dst_ is None or dst_ == rank:
+                        for a, e in zip(g9, exp):
+                            ok &= torch.equal(a.reshape(e.shape), e)
+                        # the destination finished (only) the rays somebody else traced -- all of them with dst=None
+                        ok &= sum(c[0] for c in Z.local.from_calls) == (851 if dst_ is None else 851 - mine_rays)
+                    else:
+                        ok &= g9 is None and not Z.local.from_calls
+                    ok &= not Z.local.packed_calls               # no 12-byte record anywhere
+                    if dst_ == rank:
+                        ok &= sum(c[0] for c in Z.local.into_calls) == mine_rays and not Z.local.slot_calls
+                    else:
+                        ok &= sum(c[0] for c in Z.local.slot_calls) == mine_rays and not Z.local.into_calls
+                # image batch with a stride-0 origin (the README's camera): rows stay views, row_length is handed on
+                Z.local.from_calls.clear()
+                ob = o3[:1, :1].expand(24, 37, 3)
+                g10 = Z.intersects_closest(ob, d3, dst=0, chunks=2)
+                e10 = ref.intersects_closest(ob.reshape(-1, 3), d3.reshape(-1, 3))
+                if rank == 0:
+                    for a, e in zip(g10, e10):
+                        ok &= torch.equal(a.reshape(e.shape), e)
+                    ok &= all(c[2] == 37 and len(c[1]) == 3 for c in Z.local.from_calls) and len(Z.local.from_calls) > 0
+                # a rank that holds only its shard hands all_rays in on the destination
+                bb = Z.bounds(851, 0, 1, weighted=True)
+                h = Z.closest_of_shard_async(fo[bb[rank][0]:bb[rank][1]], fd[bb[rank][0]:bb[rank][1]], 851, dst=0, chunks=2,
+                                             bounds=bb, records="slot", all_rays=(fo, fd) if rank == 0 else None)
+                g11 = h.wait()
+                if rank == 0:
+                    for a, e in zip(g11, exp):
+                        ok &= torch.equal(a.reshape(e.shape), e)
         ok &= 0.0 < auto_dst_share(8) < 1.0 and auto_dst_share(1) == 1.0
         # round 1's padded exchange stays selectable (fallback until the in-place path has run on RCCL)
         Q = ShardedRayMeshIntersector(CpuLocal(v, f), gather_mode="padded")

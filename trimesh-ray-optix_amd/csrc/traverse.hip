@@ -80,6 +80,10 @@ __device__ __forceinline__ void write_result(const tr_bvh_view& b, const QueryOu
     } else if (Q == TR_Q_CLOSEST) {
         float loc[3] = {0.f, 0.f, 0.f}, uv[2] = {0.f, 0.f};
         uint8_t hit = 0, front = 0;
+        if (out.packed && out.packed_slots == 2) {      // tr_intersects_closest_slots: the slot and nothing else
+            reinterpret_cast<int32_t*>(out.packed)[i] = res.best_face >= 0 ? res.best_slot : -1;
+            return;
+        }
         if (out.packed) {
             // packed form (tr_intersects_closest_packed): {face | front << 30, u, v}; tr_closest_expand
             // applies tr_bary_outputs to the same (u, v) and the same vertices -> the same bits
@@ -389,7 +393,6 @@ __device__ __forceinline__ bool wave_traverse_steal(const tr_bvh_view& b, tr_ray
                 r.ox = __shfl(r.ox, src); r.oy = __shfl(r.oy, src); r.oz = __shfl(r.oz, src);
                 r.dx = __shfl(r.dx, src); r.dy = __shfl(r.dy, src); r.dz = __shfl(r.dz, src);
                 r.ix = __shfl(r.ix, src); r.iy = __shfl(r.iy, src); r.iz = __shfl(r.iz, src);
-        r.sel_n = (uint32_t)__shfl((int)r.sel_n, src); r.sel_f = (uint32_t)__shfl((int)r.sel_f, src); r.sel_z = (uint32_t)__shfl((int)r.sel_z, src);
                 r.sel_n = (uint32_t)__shfl((int)r.sel_n, src); r.sel_f = (uint32_t)__shfl((int)r.sel_f, src); r.sel_z = (uint32_t)__shfl((int)r.sel_z, src);
                 const int own2 = __shfl(owner, src);
                 const float bt = __shfl(res.best_t, src);
@@ -1562,12 +1565,45 @@ __global__ __launch_bounds__(256) void k_closest_expand_buf(const tr_packed_hit*
 
 // Slot form (tr_closest_expand_slots): the record names the arena slot of the triangle; ONE 48-byte triangle record
 // (three 16-byte buffer loads, out of range = a miss = no memory access) holds the vertices and the face index.
-template <int R>
-__global__ __launch_bounds__(256) void k_closest_expand_slots(const tr_packed_hit* __restrict__ packed, int64_t n,
+// RAYS (tr_closest_from_slots): the record is ONLY the slot (4 bytes, negative = miss) and the kernel has the rays: it
+// finishes the query the way write_result does -- (det, U, V) from the ray and the winning triangle (tr_tri_duv), then
+// tr_hit_outputs -- so the bits are those of a dense trace by construction; 4 instead of 12 bytes per ray cross the links.
+template <bool RAYS>
+__device__ __forceinline__ tr_packed_hit tr_expand_record(const void* __restrict__ rec, int64_t i) {
+    if constexpr (RAYS) {
+        const int32_t sl = reinterpret_cast<const int32_t*>(rec)[i];
+        return tr_packed_hit{sl < 0 ? 0x80000000u : (uint32_t)sl, 0.f, 0.f};
+    } else {
+        return reinterpret_cast<const tr_packed_hit*>(rec)[i];
+    }
+}
+// outputs of ray i from its record and its triangle record (q0 q1 q2: ax ay az bx | by bz cx cy | cz face . .)
+template <bool RAYS, typename V4>
+__device__ __forceinline__ void tr_expand_outputs(const RayFetch& rf, int64_t i, const tr_packed_hit& ph, const V4& q0, const V4& q1,
+                                                  const V4& q2, float* l3, float* u2, uint8_t& fr) {
+    const float ax = __int_as_float(q0.x), ay = __int_as_float(q0.y), az = __int_as_float(q0.z), bx = __int_as_float(q0.w);
+    const float by = __int_as_float(q1.x), bz = __int_as_float(q1.y), cx = __int_as_float(q1.z), cy = __int_as_float(q1.w);
+    const float cz = __int_as_float(q2.x);
+    if constexpr (RAYS) {
+        float o[3], d[3];
+        fetch_ray(rf, i, o, d);
+        tr_ray r;
+        r.ox = o[0]; r.oy = o[1]; r.oz = o[2]; r.dx = d[0]; r.dy = d[1]; r.dz = d[2];
+        tr_hit h; h.t = 0.f;
+        tr_tri_duv(r, ax, ay, az, bx, by, bz, cx, cy, cz, h.det, h.U, h.V);
+        tr_hit_outputs(h, ax, ay, az, bx, by, bz, cx, cy, cz, l3, u2);
+        fr = h.det > 0.f ? 1 : 0;
+    } else {
+        tr_bary_outputs(ph.u, ph.v, ax, ay, az, bx, by, bz, cx, cy, cz, l3, u2);
+        fr = (ph.tri >> 30) & 1u;
+    }
+}
+template <int R, bool RAYS = false>
+__global__ __launch_bounds__(256) void k_closest_expand_slots(const void* __restrict__ packed, int64_t n,
                                                               const tr_tri* __restrict__ tris, int64_t nt,
                                                               uint8_t* __restrict__ hit, uint8_t* __restrict__ front,
                                                               int32_t* __restrict__ tri, float* __restrict__ loc,
-                                                              float* __restrict__ uv) {
+                                                              float* __restrict__ uv, RayFetch rf) {
     typedef int tr_v4i __attribute__((ext_vector_type(4)));
     const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc((void*)tris, 0, (int)(nt * (int64_t)sizeof(tr_tri)), 0x00020000);
     for (int64_t i0 = (int64_t)blockIdx.x * (256 * R) + threadIdx.x; i0 < n; i0 += (int64_t)gridDim.x * (256 * R)) {
@@ -1576,7 +1612,7 @@ __global__ __launch_bounds__(256) void k_closest_expand_slots(const tr_packed_hi
 #pragma unroll
         for (int k = 0; k < R; k++) {
             const int64_t i = i0 + 256 * k;
-            ph[k] = packed[i < n ? i : i0];
+            ph[k] = tr_expand_record<RAYS>(packed, i < n ? i : i0);
         }
         tr_v4i q0[R], q1[R], q2[R];
 #pragma unroll
@@ -1596,11 +1632,8 @@ __global__ __launch_bounds__(256) void k_closest_expand_slots(const tr_packed_hi
             uint8_t h = 0, fr = 0;
             int32_t t = -1;
             if (ok[k]) {
-                // record layout (tr_tri): ax ay az bx | by bz cx cy | cz face . .
-                tr_bary_outputs(ph[k].u, ph[k].v, __int_as_float(q0[k].x), __int_as_float(q0[k].y), __int_as_float(q0[k].z),
-                                __int_as_float(q0[k].w), __int_as_float(q1[k].x), __int_as_float(q1[k].y),
-                                __int_as_float(q1[k].z), __int_as_float(q1[k].w), __int_as_float(q2[k].x), l3, u2);
-                h = 1; fr = (ph[k].tri >> 30) & 1u; t = q2[k].y;
+                tr_expand_outputs<RAYS>(rf, i, ph[k], q0[k], q1[k], q2[k], l3, u2, fr);
+                h = 1; t = q2[k].y;
             }
             if (hit) hit[i] = h;
             if (front) front[i] = fr;
@@ -1617,11 +1650,12 @@ __global__ __launch_bounds__(256) void k_closest_expand_slots(const tr_packed_hi
 // workgroups, other XCDs, other L2s: 120 bytes of fabric traffic per hit for a 48-byte record that five rays share);
 // in tile order the rays that share a record sit in the same wave.  Records are read and outputs written in
 // segments of 8 pixels (96 / 8 / 32 / 96 / 64 bytes): partial lines that the L2 merges.
-__global__ __launch_bounds__(256) void k_closest_expand_slots_tiled(const tr_packed_hit* __restrict__ packed, int64_t n, int64_t width,
+template <bool RAYS = false, bool RAGGED = false>
+__global__ __launch_bounds__(256) void k_closest_expand_slots_tiled(const void* __restrict__ packed, int64_t n, int64_t width,
                                                                     const tr_tri* __restrict__ tris, int64_t nt,
                                                                     uint8_t* __restrict__ hit, uint8_t* __restrict__ front,
                                                                     int32_t* __restrict__ tri, float* __restrict__ loc,
-                                                                    float* __restrict__ uv) {
+                                                                    float* __restrict__ uv, RayFetch rf) {
     typedef int tr_v4i __attribute__((ext_vector_type(4)));
     constexpr int R = 4;
     const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc((void*)tris, 0, (int)(nt * (int64_t)sizeof(tr_tri)), 0x00020000);
@@ -1631,7 +1665,8 @@ __global__ __launch_bounds__(256) void k_closest_expand_slots_tiled(const tr_pac
     // each) -- with one 8x8 tile per instruction the runs were 8 pixels long and the pure-stream part of the kernel ran
     // at 0.072 instead of 0.046 ms -- while the block still holds the rays that share triangle records
     const uint32_t gpr = (uint32_t)(width >> 5);                      // blocks per row of blocks (32-bit: images below 2^31 pixels wide)
-    const int64_t ngroups = (n / width >> 3) * (int64_t)gpr;          // n is a multiple of 8 * width
+    const int64_t ngroups = ((n / width + 7) >> 3) * (int64_t)gpr;    // (the last row of blocks may hold fewer than 8 rows:
+                                                                      // strips beyond the batch are skipped, index >= n)
     const int64_t stride = (int64_t)gridDim.x * 4;
     // wave w of the grid takes block w, then the block `stride` further on: a persistent grid (the host sizes it to what
     // is resident -- 28 672 waves of 3 us each, one per 256 rays, kept 3 of a CU's 20 wave slots busy:
@@ -1645,15 +1680,19 @@ __global__ __launch_bounds__(256) void k_closest_expand_slots_tiled(const tr_pac
     if (t0 >= ngroups) return;
     int64_t idx[R];
     tr_packed_hit ph[R];
+    // RAGGED (the row count is not a multiple of 8): a strip beyond the batch reads the last record -- an unconditional
+    // load: a guarded one costs a branch and a full wait per strip --, fetches no triangle and stores nothing.  Its own
+    // instantiation: the extra selects cost the exact shape 18 % (0.068 -> 0.080 ms on 7.3 M records).
+    auto record = [&](int64_t i) { return tr_expand_record<RAYS>(packed, RAGGED && i >= n ? n - 1 : i); };
 #pragma unroll
-    for (int k = 0; k < R; k++) { idx[k] = ray_index(t0, k); ph[k] = packed[idx[k]]; }
+    for (int k = 0; k < R; k++) { idx[k] = ray_index(t0, k); ph[k] = record(idx[k]); }
     for (;;) {
         tr_v4i q0[R], q1[R], q2[R];
         bool ok[R];
 #pragma unroll
         for (int k = 0; k < R; k++) {
             const uint32_t slot = ph[k].tri & 0x3fffffffu;
-            ok[k] = !(ph[k].tri & 0x80000000u) && (int64_t)slot < nt;
+            ok[k] = !(ph[k].tri & 0x80000000u) && (int64_t)slot < nt && (!RAGGED || idx[k] < n);
             const uint32_t off = ok[k] ? slot * (uint32_t)sizeof(tr_tri) : 0xffffffffu;
             q0[k] = __builtin_amdgcn_raw_buffer_load_b128(trs, off, 0, 0);
             q1[k] = __builtin_amdgcn_raw_buffer_load_b128(trs, ok[k] ? off + 16u : 0xffffffffu, 0, 0);
@@ -1666,19 +1705,18 @@ __global__ __launch_bounds__(256) void k_closest_expand_slots_tiled(const tr_pac
         tr_packed_hit nph[R];
         if (more) {
 #pragma unroll
-            for (int k = 0; k < R; k++) { nidx[k] = ray_index(t1, k); nph[k] = packed[nidx[k]]; }
+            for (int k = 0; k < R; k++) { nidx[k] = ray_index(t1, k); nph[k] = record(nidx[k]); }
         }
 #pragma unroll
         for (int k = 0; k < R; k++) {
             const int64_t i = idx[k];
+            if (RAGGED && i >= n) continue;
             float l3[3] = {0.f, 0.f, 0.f}, u2[2] = {0.f, 0.f};
             uint8_t h = 0, fr = 0;
             int32_t t = -1;
             if (ok[k]) {
-                tr_bary_outputs(ph[k].u, ph[k].v, __int_as_float(q0[k].x), __int_as_float(q0[k].y), __int_as_float(q0[k].z),
-                                __int_as_float(q0[k].w), __int_as_float(q1[k].x), __int_as_float(q1[k].y),
-                                __int_as_float(q1[k].z), __int_as_float(q1[k].w), __int_as_float(q2[k].x), l3, u2);
-                h = 1; fr = (ph[k].tri >> 30) & 1u; t = q2[k].y;
+                tr_expand_outputs<RAYS>(rf, i, ph[k], q0[k], q1[k], q2[k], l3, u2, fr);
+                h = 1; t = q2[k].y;
             }
             if (hit) hit[i] = h;
             if (front) front[i] = fr;
@@ -2107,7 +2145,14 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
     const bool lt_query = (Q == TR_Q_CLOSEST || Q == TR_Q_FIRST) && !STATS && opt.lds_top > 0 && bvh->top_table != nullptr &&
                           bvh->num_tris >= 2 && lt_compact && !opt.persistent && (opt.block_size == 128 || opt.lds_top == 2);
     const int bs = (lt_query && opt.lds_top == 2) ? 256 : opt.block_size;
-    const int64_t nblocks_direct = (rf.n + bs - 1) / bs;
+    // Image-shaped batches whose row count is not a multiple of 8 (from 64 rows on): the block -> ray map of the direct
+    // launch is laid over the batch PADDED to whole 8-row tiles -- a tile row beyond the batch maps to ray indices >= n,
+    // which every kernel treats as out of range -- so that such a batch keeps the tile shapes (a 1050-row band of the
+    // headline image: 0.241 ms in rows of 64 pixels, 0.206 in 8x8 tiles)
+    const bool rows_padded = rf.s1 > 1 && rf.s2 % 8 == 0 && rf.s2 >= 8 && rf.s2 < (1 << 28) && rf.n % rf.s2 == 0 &&
+                             rf.n % (8 * rf.s2) != 0 && rf.n >= 64 * rf.s2;
+    const int64_t n_map = rows_padded ? (rf.n / rf.s2 + 7) / 8 * 8 * rf.s2 : rf.n;
+    const int64_t nblocks_direct = (n_map + bs - 1) / bs;
     int64_t pgrid = (int64_t)st->num_cus * opt.blocks_per_cu;
     if (opt.persistent && Q != TR_Q_LOCATION) {   // the multi-hit list query has only the direct shape
         // size the persistent grid by what is actually resident (4 waves per block = 1 per SIMD)
@@ -2241,7 +2286,7 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
         // of a tile costs about the same -- and take tiles at any size: C4 count 1.12 -> 0.93 ms,
         // location 1.38 -> 1.18 ms at 1 M rays (profiles/r02_sweep_c4.jsonl).
         const bool tile_any_size = opt.tile == 2 || ((Q == TR_Q_COUNT || Q == TR_Q_LOCATION) && opt.unordered);
-        if (opt.tile && (tile_any_size || rf.n >= ((int64_t)1 << 22)) && rf.s1 > 1 && rf.s2 % 8 == 0 && rf.s2 >= 8 && rf.s2 < (1 << 28) && rf.n % (8 * rf.s2) == 0)
+        if (opt.tile && (tile_any_size || rf.n >= ((int64_t)1 << 22)) && rf.s1 > 1 && rf.s2 % 8 == 0 && rf.s2 >= 8 && rf.s2 < (1 << 28) && n_map % (8 * rf.s2) == 0)
             tile_w = (int)rf.s2 | (3 << 28);
         // Smaller image-shaped batches of the pruning queries: flatter tiles where the triangles are
         // large on screen (option tile_small: 0 rows, 1 = 2x32, 2 = 4x16, 3 = 8x8, 4 = auto).  Host
@@ -2255,7 +2300,7 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
             int lgh = opt.tile_small;
             if (lgh == 4) lgh = rf.n >= 32 * bvh->num_tris ? 2 : (rf.n >= 8 * bvh->num_tris ? 1 : 0);
             const int w = 64 >> lgh, h = 1 << lgh;
-            if (lgh > 0 && rf.s2 % w == 0 && rf.n % ((int64_t)h * rf.s2) == 0) tile_w = (int)rf.s2 | (lgh << 28);
+            if (lgh > 0 && rf.s2 % w == 0 && n_map % ((int64_t)h * rf.s2) == 0) tile_w = (int)rf.s2 | (lgh << 28);
         }
         // intra-wave work stealing (wave_traverse_steal).  steal = 1 (default): closest / first / any
         // launches of up to 4 M rays, donors from their 64th trip on -- +11 % on the headline, +45 % at
@@ -2293,7 +2338,7 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
         // 0.221 -> 0.2015 ms).  Launch shapes that steal only; the others keep their own learned order
         // (sched_acquire).  Speed only.  split: 0 off, 1 auto, N >= 2: nblocks >> N.
         const bool small_tris = rf.n >= 8 * bvh->num_tris;   // triangles of many pixels: flat tiles, balanced waves
-        const bool can_tile8 = opt.tile && rf.s1 > 1 && rf.s2 % 8 == 0 && rf.s2 >= 8 && rf.s2 < (1 << 28) && rf.n % (8 * rf.s2) == 0;
+        const bool can_tile8 = opt.tile && rf.s1 > 1 && rf.s2 % 8 == 0 && rf.s2 >= 8 && rf.s2 < (1 << 28) && n_map % (8 * rf.s2) == 0;
         int split_shift = 0;
         if ((steal || usteal) && opt.split > 1) split_shift = opt.split;
         else if ((usteal || (steal && Q != TR_Q_COUNT)) && opt.split == 1 && rf.n <= ((int64_t)1 << 22)) {
@@ -2704,39 +2749,78 @@ int tr_intersects_closest_packed_slots(const tr_bvh* bvh, const tr_rays* rays, t
     return launch_query<TR_Q_CLOSEST, false>(bvh, rays, out, nullptr, (hipStream_t)stream);
 }
 
+extern "C++" {
+template <bool RAYS>
+static int expand_slots_impl(const tr_bvh* bvh, const void* d_rec, int64_t n, int64_t row_length, const RayFetch& rf, uint8_t* d_hit,
+                             uint8_t* d_front, int32_t* d_tri, float* d_loc, float* d_uv, void* stream) {
+    if (bvh->num_tris * (int64_t)sizeof(tr_tri) >= ((int64_t)1 << 31)) return tr_fail(TR_ERR_INVALID_ARG, "slot form needs a triangle array below 2 GiB");
+    tr_device_state* st;
+    TR_TRY(tr_get_device_state(bvh->device, &st));
+    const tr_options opt = tr_opts();
+    // image-shaped rows (row_length pixels each): blocks of 8 rows x 32 pixels per wave, so that the rays that share a
+    // triangle record share a wave (option expand_tiles).  A row count that is not a multiple of 8 leaves the last row
+    // of blocks partly empty: taken from 64 rows on.
+    const bool tiled = opt.expand_tiles && row_length >= 32 && row_length % 32 == 0 && n % row_length == 0 && n >= 4096 &&
+                       (n % (8 * row_length) == 0 || n >= 64 * row_length);
+    if (tiled) {
+        const int64_t n_map = (n / row_length + 7) / 8 * 8 * row_length;
+        int64_t blocks = (n_map / 256 + 3) / 4;               // 4 waves per workgroup, one block of 8 x 32 pixels per wave and pass
+        // one wave per block of 8 rows x 32 pixels (expand_cus = N > 0: at most N workgroups per CU, the waves loop;
+        // measured on 7.3 M records of the headline image: no cap 0.066 ms, 8 per CU 0.072, what is resident 0.078)
+        if (opt.expand_cus > 0 && blocks > (int64_t)st->num_cus * opt.expand_cus) blocks = (int64_t)st->num_cus * opt.expand_cus;
+        if (n_map == n)
+            hipLaunchKernelGGL((k_closest_expand_slots_tiled<RAYS, false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                               d_rec, n, row_length, bvh->tris, bvh->num_tris, d_hit, d_front, d_tri, d_loc, d_uv, rf);
+        else
+            hipLaunchKernelGGL((k_closest_expand_slots_tiled<RAYS, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                               d_rec, n, row_length, bvh->tris, bvh->num_tris, d_hit, d_front, d_tri, d_loc, d_uv, rf);
+    } else if (n >= 4096) {
+        int64_t blocks = (n + 1023) / 1024;
+        if (opt.expand_cus > 0 && blocks > (int64_t)st->num_cus * opt.expand_cus) blocks = (int64_t)st->num_cus * opt.expand_cus;
+        hipLaunchKernelGGL((k_closest_expand_slots<4, RAYS>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                           d_rec, n, bvh->tris, bvh->num_tris, d_hit, d_front, d_tri, d_loc, d_uv, rf);
+    } else {
+        hipLaunchKernelGGL((k_closest_expand_slots<1, RAYS>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           d_rec, n, bvh->tris, bvh->num_tris, d_hit, d_front, d_tri, d_loc, d_uv, rf);
+    }
+    TR_HIP_TRY(hipGetLastError());
+    return TR_OK;
+}
+}   // extern "C++"
+
 int tr_closest_expand_slots_rows(const tr_bvh* bvh, const tr_packed_hit* d_packed, int64_t n, int64_t row_length, uint8_t* d_hit,
                                  uint8_t* d_front, int32_t* d_tri, float* d_loc, float* d_uv, void* stream) {
     if (!bvh) return tr_fail(TR_ERR_INVALID_ARG, "bvh == NULL");
     if (n < 0 || row_length < 0) return tr_fail(TR_ERR_INVALID_ARG, "negative size");
     if (n == 0) return TR_OK;
     if (!d_packed) return tr_fail(TR_ERR_INVALID_ARG, "d_packed == NULL");
-    if (bvh->num_tris * (int64_t)sizeof(tr_tri) >= ((int64_t)1 << 31)) return tr_fail(TR_ERR_INVALID_ARG, "slot form needs a triangle array below 2 GiB");
     tr_device_guard guard;
     TR_TRY(enter_bvh_device(bvh, nullptr, &guard));
-    tr_device_state* st;
-    TR_TRY(tr_get_device_state(bvh->device, &st));
-    const tr_options opt = tr_opts();
-    // image-shaped rows (row_length pixels each, a multiple of 8 rows in all): 8x8 pixel tiles per wave, so that the rays
-    // that share a triangle record share a wave (option expand_tiles)
-    const bool tiled = opt.expand_tiles && row_length >= 32 && row_length % 32 == 0 && n % (8 * row_length) == 0 && n >= 4096;
-    if (tiled) {
-        int64_t blocks = (n / 256 + 3) / 4;                   // 4 waves per workgroup, one block of 8 x 32 pixels per wave and pass
-        // one wave per block of 8 rows x 32 pixels (expand_cus = N > 0: at most N workgroups per CU, the waves loop;
-        // measured on 7.3 M records of the headline image: no cap 0.066 ms, 8 per CU 0.072, what is resident 0.078)
-        if (opt.expand_cus > 0 && blocks > (int64_t)st->num_cus * opt.expand_cus) blocks = (int64_t)st->num_cus * opt.expand_cus;
-        hipLaunchKernelGGL(k_closest_expand_slots_tiled, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                           d_packed, n, row_length, bvh->tris, bvh->num_tris, d_hit, d_front, d_tri, d_loc, d_uv);
-    } else if (n >= 4096) {
-        int64_t blocks = (n + 1023) / 1024;
-        if (opt.expand_cus > 0 && blocks > (int64_t)st->num_cus * opt.expand_cus) blocks = (int64_t)st->num_cus * opt.expand_cus;
-        hipLaunchKernelGGL(k_closest_expand_slots<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                           d_packed, n, bvh->tris, bvh->num_tris, d_hit, d_front, d_tri, d_loc, d_uv);
-    } else {
-        hipLaunchKernelGGL(k_closest_expand_slots<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                           d_packed, n, bvh->tris, bvh->num_tris, d_hit, d_front, d_tri, d_loc, d_uv);
-    }
-    TR_HIP_TRY(hipGetLastError());
-    return TR_OK;
+    RayFetch none{};
+    return expand_slots_impl<false>(bvh, d_packed, n, row_length, none, d_hit, d_front, d_tri, d_loc, d_uv, stream);
+}
+
+// The 4-byte record form (round 4): the traversal writes only the arena slot of the winning triangle (or -1), and
+// whoever holds the RAYS finishes the query from (ray, slot) -- what write_result does at the end of a dense trace.
+int tr_intersects_closest_slots(const tr_bvh* bvh, const tr_rays* rays, int32_t* d_slot, void* stream) {
+    if (!d_slot && rays && rays->nray > 0) return tr_fail(TR_ERR_INVALID_ARG, "d_slot == NULL");
+    if (bvh && bvh->num_tris * (int64_t)sizeof(tr_tri) >= ((int64_t)1 << 31))
+        return tr_fail(TR_ERR_INVALID_ARG, "slot form needs a triangle array below 2 GiB");
+    QueryOut out = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, reinterpret_cast<tr_packed_hit*>(d_slot), 2};
+    return launch_query<TR_Q_CLOSEST, false>(bvh, rays, out, nullptr, (hipStream_t)stream);
+}
+
+int tr_closest_from_slots(const tr_bvh* bvh, const tr_rays* rays, const int32_t* d_slot, int64_t row_length, uint8_t* d_hit,
+                          uint8_t* d_front, int32_t* d_tri, float* d_loc, float* d_uv, void* stream) {
+    if (!bvh) return tr_fail(TR_ERR_INVALID_ARG, "bvh == NULL");
+    if (row_length < 0) return tr_fail(TR_ERR_INVALID_ARG, "negative size");
+    RayFetch rf;
+    TR_TRY(make_fetch(rays, &rf));
+    if (rf.n == 0) return TR_OK;
+    if (!d_slot) return tr_fail(TR_ERR_INVALID_ARG, "d_slot == NULL");
+    tr_device_guard guard;
+    TR_TRY(enter_bvh_device(bvh, rays, &guard));
+    return expand_slots_impl<true>(bvh, d_slot, rf.n, row_length, rf, d_hit, d_front, d_tri, d_loc, d_uv, stream);
 }
 
 int tr_closest_expand_slots(const tr_bvh* bvh, const tr_packed_hit* d_packed, int64_t n, uint8_t* d_hit, uint8_t* d_front,

@@ -30,7 +30,7 @@ MAX_ANYHIT_SIZE = 8   # LaunchParams.h:8
 MAX_SIZE_LENGTH = 4   # LaunchParams.h:9
 
 _LIB_NAME = "libtriro_hip.so"
-ABI_VERSION = 7     # TR_ABI_VERSION of include/triro_hip.h this binding was written against
+ABI_VERSION = 8     # TR_ABI_VERSION of include/triro_hip.h this binding was written against
 _lib = None
 _lib_error = None
 
@@ -94,6 +94,8 @@ ABI = {
     "tr_intersects_closest_packed_slots": (_int, [_vp, C.POINTER(TrRays), _vp, _vp]),
     "tr_closest_expand_slots": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tr_closest_expand_slots_rows": (_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tr_intersects_closest_slots": (_int, [_vp, C.POINTER(TrRays), _vp, _vp]),
+    "tr_closest_from_slots": (_int, [_vp, C.POINTER(TrRays), _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tr_hits_scan": (_int, [_vp, _i64, _i32, _vp, _vp, C.POINTER(_i64), _vp]),
     "tr_intersects_location_fill": (_int, [_vp, C.POINTER(TrRays), _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
     "tr_intersects_count_topk": (_int, [_vp, C.POINTER(TrRays), _i32, _vp, _vp, _vp]),
@@ -282,6 +284,51 @@ def intersects_closest_packed(accel_structure, origins, dirs, out: torch.Tensor 
     with torch.cuda.device(dev):
         _check(fn(_handle(accel_structure, origins), C.byref(make_rays(origins, dirs)), out.data_ptr(), _stream_ptr(dev)))
     return out
+
+
+def intersects_closest_slots(accel_structure, origins, dirs, out: torch.Tensor = None) -> torch.Tensor:
+    """tr_intersects_closest_slots: closest hit as 4 bytes per ray -- int32 [n]: the arena slot of the nearest
+    triangle, -1 for a miss.  For a destination that holds the rays (closest_from_slots finishes the query there);
+    valid for this hierarchy or a bit-identical replica.  `out`: optional preallocated int32 [n] destination."""
+    check_rays(origins, dirs)
+    n, dev = origins.numel() // 3, origins.device
+    if out is None:
+        out = torch.empty((n,), dtype=torch.int32, device=dev)
+    elif out.dtype != torch.int32 or tuple(out.shape) != (n,) or not out.is_contiguous() or out.device != dev:
+        raise ValueError("out must be a contiguous int32 [n] tensor on the rays' device")
+    with torch.cuda.device(dev):
+        _check(get_module().tr_intersects_closest_slots(_handle(accel_structure, origins), C.byref(make_rays(origins, dirs)),
+                                                        out.data_ptr(), _stream_ptr(dev)))
+    return out
+
+
+def closest_from_slots(accel_structure, origins, dirs, slots: torch.Tensor, outs=None, row_length: int = 0):
+    """tr_closest_from_slots: (rays, their slots from intersects_closest_slots on any bit-identical replica) ->
+    (hit, front, tri_idx, loc, uv), the bits of intersects_closest on the same rays.  `outs`: optional preallocated
+    contiguous destinations (bool [n], bool [n], int32 [n], float32 [n, 3], float32 [n, 2]); otherwise the outputs
+    take the rays' batch shape.  row_length: the rays are whole rows of an image of that width."""
+    check_rays(origins, dirs)
+    n, dev = origins.numel() // 3, origins.device
+    if slots.dtype != torch.int32 or tuple(slots.shape) != (n,) or not slots.is_contiguous() or slots.device != dev:
+        raise ValueError("slots must be a contiguous int32 [n] tensor on the rays' device, one per ray")
+    if outs is not None:
+        want = ((torch.bool, (n,)), (torch.bool, (n,)), (torch.int32, (n,)), (torch.float32, (n, 3)), (torch.float32, (n, 2)))
+        if len(outs) != 5 or any(t.dtype != dt or tuple(t.shape) != sh or not t.is_contiguous() or t.device != dev
+                                 for t, (dt, sh) in zip(outs, want)):
+            raise ValueError("outs must be contiguous (bool[n], bool[n], int32[n], float32[n,3], float32[n,2]) on the rays' device")
+        hit, front, tri, loc, uv = outs
+    else:
+        b = origins.shape[:-1]
+        hit = torch.empty(b, dtype=torch.bool, device=dev)
+        front = torch.empty(b, dtype=torch.bool, device=dev)
+        tri = torch.empty(b, dtype=torch.int32, device=dev)
+        loc = torch.empty((*b, 3), dtype=torch.float32, device=dev)
+        uv = torch.empty((*b, 2), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _check(get_module().tr_closest_from_slots(_handle(accel_structure, origins), C.byref(make_rays(origins, dirs)),
+                                                  slots.data_ptr(), int(row_length), hit.data_ptr(), front.data_ptr(),
+                                                  tri.data_ptr(), loc.data_ptr(), uv.data_ptr(), _stream_ptr(dev)))
+    return hit, front, tri, loc, uv
 
 
 def closest_expand_slots(accel_structure, packed: torch.Tensor, batch_shape=None, outs=None, row_length: int = 0):

@@ -137,6 +137,18 @@ class RayMeshIntersector:
         f = self.mesh_faces if self.mesh_faces.device == dev else self.mesh_faces.to(dev)
         return hops.closest_expand(packed, v, f, batch_shape, outs)
 
+    slot_records = True     # ... and the 4-byte record for a destination that holds the rays
+
+    def intersects_closest_slots(self, origins, directions, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Closest hit as int32 [n]: the arena slot of the nearest triangle, -1 for a miss -- 4 bytes per ray (not in the
+        reference).  Whoever holds the rays and a bit-identical replica finishes the query with closest_from_slots."""
+        return hops.intersects_closest_slots(self.as_wrapper, origins, directions, out)
+
+    def closest_from_slots(self, origins, directions, slots: torch.Tensor, outs=None, row_length: int = 0):
+        """(rays, slots) -> (hit, front, tri_idx, loc, uv): the end of intersects_closest (ray against the one winning
+        triangle, barycentric outputs) without the traversal -- the same bits."""
+        return hops.closest_from_slots(self.as_wrapper, origins, directions, slots, outs, row_length)
+
     def intersects_location(self, origins, directions) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """ray_optix.py:157-164.  (loc[h,3], ray_idx[h], tri_idx[h]), <= 8 hits per ray."""
         return hops.intersects_location(self.as_wrapper, origins, directions)

@@ -36,7 +36,12 @@ Round 4:
     ranks can share ONE GPU and run the real tracer through every branch of this module -- a
     functional check, never a measurement;
   * `EmulatedWorld`: the destination rank's side of an N-rank gather on one GPU (the peers' records
-    are traced beforehand and arrive as device copies on a copy stream), for bench.py --emulate-world.
+    are traced beforehand and arrive as device copies on a copy stream), for bench.py --emulate-world;
+  * 4-byte records (`records="slot"`): when the destination HOLDS THE RAYS of the whole batch -- the
+    reference's call hands the whole batch to one process, and `intersects_closest` here sees it on every
+    rank -- the peers send only the arena slot of each ray's nearest triangle and the destination finishes
+    the query from (ray, slot) (`closest_from_slots`: the end of a dense trace, the same bits): 4 instead
+    of 12 bytes per ray cross the links, for 24 more bytes per ray read on the destination.
 """
 from __future__ import annotations
 
@@ -188,6 +193,8 @@ class ShardedRayMeshIntersector:
         # record per hit instead of four rows in four cache lines; needs bit-identical replicas on all ranks (same
         # mesh, same build options -- the builder is deterministic).  TRIRO_PACKED_SLOTS=0 keeps the face form.
         self.slots = bool(getattr(local, "packed_slots", False)) and os.environ.get("TRIRO_PACKED_SLOTS", "1") != "0"
+        # 4-byte records (the slot alone) where the destination holds the rays: TRIRO_SLOT_RECORDS=0 keeps the 12-byte ones
+        self.slot_records = self.slots and bool(getattr(local, "slot_records", False)) and os.environ.get("TRIRO_SLOT_RECORDS", "1") != "0"
         self._side = None      # side stream of the destination rank (wait for chunk, expand)
 
     # ---- helpers -------------------------------------------------------------------------
@@ -371,7 +378,8 @@ class ShardedRayMeshIntersector:
 
     def closest_of_shard_async(self, o: torch.Tensor, d: torch.Tensor, n_total: int, batch_shape=None,
                                dst: Optional[int] = 0, chunks: Optional[int] = None, bounds=None,
-                               row_quantum: Optional[int] = None) -> PendingClosest:
+                               row_quantum: Optional[int] = None, records: str = "packed",
+                               all_rays=None) -> PendingClosest:
         """Closest hit of ONE batch of `n_total` rays of which this rank holds (only) its shard `o`, `d`
         = rows bounds[rank] of the batch (default: self.bounds(n_total, dst, weighted=True) -- even shards
         unless dst_share is set); results for all n_total rays on rank `dst` (None: on every rank), shaped
@@ -379,8 +387,16 @@ class ShardedRayMeshIntersector:
         destination rank: dense, straight into its rows of the outputs) -> asynchronous exchange of chunk k
         while chunk k+1 is traced -> on the destination, a side stream waits for chunk k and expands the
         peers' records into the dense outputs.  Returns at once; PendingClosest.wait() orders the caller's
-        stream behind the result."""
+        stream behind the result.
+        records="slot" (every rank alike): 4-byte records; the destination rank(s) pass `all_rays` = (origins,
+        directions) of the WHOLE batch ([*batch_shape, 3] or [n_total, 3], any strides)."""
         world, rank = self.world, self.rank
+        if records not in ("packed", "slot"):
+            raise ValueError("records must be 'packed' or 'slot'")
+        slot_rec = records == "slot"
+        if slot_rec and not self.slot_records:
+            raise ValueError("records='slot' needs a tracer with intersects_closest_slots / closest_from_slots")
+        rec_shape = () if slot_rec else (3,)
         image = o.dim() == 3           # image-shaped shard: chunk by whole rows
         # rays per image row: every rank must chunk alike, also one whose own shard is empty (and therefore
         # flat) -- callers that know the batch's row length pass it (row_quantum)
@@ -407,10 +423,26 @@ class ShardedRayMeshIntersector:
         # The destination of a dst-gather traces its own rays dense, in place: nobody else needs its records.
         # (dst=None: every rank's records travel, so everybody traces packed and expands everything.)
         dense_mine = want and dst is not None and hasattr(self.local, "intersects_closest_into")
-        packed_all = self._alloc((n_total, 3), torch.int32, dev) if want else None
+        packed_all = self._alloc((n_total, *rec_shape), torch.int32, dev) if want else None
         mine = None
         if not dense_mine:
-            mine = packed_all[lo:hi] if want else (self._alloc((m, 3), torch.int32, dev) if m > 0 else None)
+            mine = packed_all[lo:hi] if want else (self._alloc((m, *rec_shape), torch.int32, dev) if m > 0 else None)
+        ray_rows = None
+        if slot_rec and want:
+            if all_rays is None:
+                raise ValueError("records='slot': the destination rank needs all_rays")
+            O, D = all_rays
+            if O.numel() != 3 * n_total or D.numel() != 3 * n_total:
+                raise ValueError(f"all_rays must hold the {n_total} rays of the batch")
+            if per_row > 1 and O.dim() == 3 and O.shape[1] == per_row and D.shape == O.shape:
+                # image-shaped: rows [ra, rz) of the batch as views (a stride-0 broadcast stays one)
+                def ray_rows(ra, rz, O=O, D=D, w=per_row):
+                    return O[ra // w:rz // w], D[ra // w:rz // w]
+            else:
+                Of, Df = O.expand(*O.shape).reshape(-1, 3), D.expand(*D.shape).reshape(-1, 3)
+
+                def ray_rows(ra, rz, Of=Of, Df=Df):
+                    return Of[ra:rz], Df[ra:rz]
         outs = flat_outs = None
         if want:
             # the five dense outputs out of ONE allocation (26 B per ray: loc | uv | tri | hit | front, each
@@ -451,6 +483,8 @@ class ShardedRayMeshIntersector:
                 ok, dk = (o[a // per_row:z // per_row], d[a // per_row:z // per_row]) if image else (o[a:z], d[a:z])
                 if dense_mine:
                     self.local.intersects_closest_into(ok, dk, tuple(x[lo + a:lo + z] for x in flat_outs))
+                elif slot_rec:
+                    self.local.intersects_closest_slots(ok, dk, out=mine[a:z])
                 else:
                     if self.slots:
                         self.local.intersects_closest_packed(ok, dk, out=mine[a:z], slots=True)
@@ -458,13 +492,16 @@ class ShardedRayMeshIntersector:
                         self.local.intersects_closest_packed(ok, dk, out=mine[a:z])
             if world > 1 or self.force_collectives:
                 if dense_mine:
-                    # nothing of this rank travels: it only receives (its own rows of packed_all stay unused)
+                    # nothing of this rank travels: it only receives (its own rows of packed_all stay unused).
+                    # Posted AFTER this rank's trace of chunk k on purpose: a collective starts behind what the
+                    # calling stream holds, the peers' chunk k is ready when ours is, and a receive kernel posted
+                    # earlier would spin on CUs through the whole trace.
                     rb = [(ra, rz) if r != rank else (ra, ra) for r, (ra, rz) in enumerate(cb)]
                     if empty is None:
-                        empty = torch.empty((0, 3), dtype=torch.int32, device=dev)
+                        empty = torch.empty((0, *rec_shape), dtype=torch.int32, device=dev)
                     works = self._exchange_recv_only(empty, packed_all, rb, cb, dst)
                 else:
-                    src = mine[a:z] if m > 0 else torch.empty((0, 3), dtype=torch.int32, device=dev)
+                    src = mine[a:z] if m > 0 else torch.empty((0, *rec_shape), dtype=torch.int32, device=dev)
                     works = self._exchange_send(src, packed_all, cb, dst)
             else:
                 works = []
@@ -478,7 +515,11 @@ class ShardedRayMeshIntersector:
                         else:
                             merged.append((ra, rz))
                     for ra, rz in merged:
-                        if self.slots:
+                        if slot_rec:
+                            ro, rd = ray_rows(ra, rz)
+                            self.local.closest_from_slots(ro, rd, packed_all[ra:rz], outs=tuple(x[ra:rz] for x in flat_outs),
+                                                          row_length=per_row if per_row > 1 else 0)
+                        elif self.slots:
                             # (rows of an image: a wave expands a block of 8 rows x 32 pixels)
                             self.local.closest_expand(packed_all[ra:rz], outs=tuple(x[ra:rz] for x in flat_outs), slots=True,
                                                       row_length=per_row if per_row > 1 else 0)
@@ -506,7 +547,7 @@ class ShardedRayMeshIntersector:
         if side is not None:
             event = torch.cuda.Event()
             event.record(side)
-        return PendingClosest(outs, event, works_all, keep=(packed_all, mine, o, d), device=dev if cuda else None)
+        return PendingClosest(outs, event, works_all, keep=(packed_all, mine, o, d, all_rays), device=dev if cuda else None)
 
     def _exchange_send(self, src, packed_all, cb, dst):
         return self._exchange(src, packed_all, cb, dst, async_op=True)
@@ -531,6 +572,10 @@ class ShardedRayMeshIntersector:
         bounds = self.bounds(n, dst, q, weighted=True)
         b, n, lo, hi, o, d = self._my_rays(origins, directions, bounds)
         rows = q if q > 1 and all(a % q == 0 and z % q == 0 for a, z in bounds) else None
+        # the whole batch is visible on every rank: the destination holds the rays, 4-byte records will do
+        if self.slot_records:
+            return self.closest_of_shard_async(o, d, n, batch_shape=b, dst=dst, chunks=chunks, bounds=bounds, row_quantum=rows,
+                                               records="slot", all_rays=(origins, directions.expand(*origins.shape)))
         return self.closest_of_shard_async(o, d, n, batch_shape=b, dst=dst, chunks=chunks, bounds=bounds, row_quantum=rows)
 
     # ---- queries (same names / return orders as RayMeshIntersector) -------------------------
@@ -613,7 +658,7 @@ class EmulatedWorld(ShardedRayMeshIntersector):
             plain_alloc = self._alloc
 
             def alloc(shape, dtype, device):
-                if tuple(shape) == (n_total, 3) and dtype == torch.int32:
+                if tuple(shape) == tuple(self.peer_records.shape) and dtype == torch.int32:
                     return self.peer_records
                 return plain_alloc(shape, dtype, device)
             self._alloc = alloc
