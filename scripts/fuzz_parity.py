@@ -96,6 +96,11 @@ for it in range(a.iters):
             for rl in ((0, ot.shape[1]) if ot.dim() == 3 else (0,)):
                 exp6 = r.closest_expand(recs, batch_shape=ot.shape[:-1], slots=True, row_length=int(rl))
                 ok &= all(np.array_equal(x.cpu().numpy().reshape(e.shape), e) for x, e in zip(exp6, (hit, front, tri, loc, uv)))
+            # ... and 4-byte records (the slot alone) finished from the rays
+            sl4 = r.intersects_closest_slots(ot, dt)
+            for rl in ((0, ot.shape[1]) if ot.dim() == 3 else (0,)):
+                exp7 = r.closest_from_slots(ot, dt, sl4, row_length=int(rl))
+                ok &= all(np.array_equal(x.cpu().numpy().reshape(e.shape), e) for x, e in zip(exp7, (hit, front, tri, loc, uv)))
             if not ok: break
     finally:
         for k, val in DEFAULTS.items(): hops.set_option(k, val)
