@@ -16,7 +16,10 @@ class StubTracer:
 
     # 12-byte records {tri | front << 30 (-1: miss), s bits, 0} and their expansion: the shape of the
     # packed pipeline of triro.ray.sharded; intersects_closest is expand(packed), so both paths agree
-    def intersects_closest_packed(self, origins, directions, out=None):
+    packed_slots = True      # (the stand-in's "slot" is its triangle number)
+    slot_records = True
+
+    def intersects_closest_packed(self, origins, directions, out=None, slots=False):
         b = origins.shape[:-1]
         s = (origins.expand(*b, 3) * 3.0 + directions).sum(-1).reshape(-1).to(torch.float32)
         hit = s > 0
@@ -29,7 +32,29 @@ class StubTracer:
         out.copy_(rec)
         return out
 
-    def closest_expand(self, packed, batch_shape=None, outs=None):
+    # 4-byte records: the triangle number alone; whoever holds the rays finishes the query (and here CHECKS that the
+    # rays it was handed are the ones the slots belong to)
+    def intersects_closest_slots(self, origins, directions, out=None):
+        rec = self.intersects_closest_packed(origins, directions)
+        sl = torch.where(rec[:, 0] >= 0, rec[:, 0] & 0x3fffffff, torch.full_like(rec[:, 0], -1))
+        if out is None:
+            return sl
+        out.copy_(sl)
+        return out
+
+    def closest_from_slots(self, origins, directions, slots, outs=None, row_length=0):
+        rec = self.intersects_closest_packed(origins, directions)
+        mine = torch.where(rec[:, 0] >= 0, rec[:, 0] & 0x3fffffff, torch.full_like(rec[:, 0], -1))
+        assert torch.equal(mine, slots.reshape(-1)), "record rows paired with the wrong rays"
+        return self.closest_expand(rec, origins.shape[:-1], outs)
+
+    def intersects_closest_into(self, origins, directions, outs):
+        res = self.closest_expand(self.intersects_closest_packed(origins, directions))
+        for dst_, src_ in zip(outs, res):
+            dst_.copy_(src_.reshape(dst_.shape))
+        return outs
+
+    def closest_expand(self, packed, batch_shape=None, outs=None, slots=False, row_length=0):
         hit = packed[:, 0] >= 0
         tri = torch.where(hit, packed[:, 0] & 0x3fffffff, torch.full_like(packed[:, 0], -1))
         front = hit & (((packed[:, 0] >> 30) & 1) == 1)
