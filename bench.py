@@ -9,12 +9,16 @@ test/performance_test.py:54-57); rays and BVH are resident in HBM before the tim
 
 Workloads
   c5i  (default, the metric's config): one 1024x1024 pinhole ray batch per GPU against the
-       1 310 720-triangle headline mesh.  N > 1: every rank owns a BVH replica
-       and its own 1024^2 batch -> "scaling": "weak"; `--scaling strong` cuts ONE 1024^2 batch into
-       N row bands instead.  For N > 1 the results are gathered to rank 0 INSIDE the timed region
+       1 310 720-triangle headline mesh.  N > 1: every rank owns a BVH replica and
+       the job is N such batches per step -> "scaling": "weak" (the stack [N x 1024, 1024] is cut into row
+       bands: even ones with `--dst-share 1`; by default rank 0, which also finishes everybody else's rays,
+       takes a narrower band and the peers wider ones -- same total); `--scaling strong` cuts ONE 1024^2
+       batch into N row bands instead.  For N > 1 the results are gathered to rank 0 INSIDE the timed region
        ("all outputs resident on the caller's GPU"; `--no-gather` leaves them in place):
-       12-byte packed records over RCCL, expanded on rank 0 (triro.ray.sharded), step k's exchange
-       overlapping step k+1's trace.
+       rank 0 holds the rays of the whole batch (as the reference's caller does), the peers send 4-byte
+       records -- the arena slot of each ray's nearest triangle -- over RCCL and rank 0 finishes those rays
+       from (ray, slot) (`--records packed`: 12-byte {slot, u, v} records, rank 0 needs no rays;
+       triro.ray.sharded), step k's exchange overlapping step k+1's trace.
   c5ii (BASELINE.json config 5): ONE batch of 100 000 000 hash rays (seed 99) split into N
        contiguous shards (triro.ray.sharded.shard_bounds), BVH replicated, results gathered to
        rank 0 INSIDE the timed region -> "scaling": "strong".
