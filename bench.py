@@ -562,6 +562,9 @@ def run_rank(args):
             wl = (f"C5(i): icosphere({args.subdiv})+displacement seed 0, {len(f)} tris; {args.res}x{args.res} "
                   f"{args.rays} rays per GPU; intersects_closest (stream_compaction=False)")
             par = f"ray-sharded x{world}, BVH replicated" + gather_txt
+            if world > 1 and share is not None:
+                par += (f"; the {world} x {args.res}^2 rays of a step are cut into row bands, rank 0's narrower (dst_share {share}): "
+                        f"total work per step = {world} x the 1-GPU batch")
             scaling = "weak"
         else:
             metric = "Mrays/s closest-hit, 1M-tri mesh, 100M-ray batch (BASELINE.json config 5; not the 1024^2 headline batch)"
@@ -580,7 +583,8 @@ def run_rank(args):
                      if gloo else "synthetic"),
             "verified": verified,
             "config": {"workload": wl, "rays_per_gpu": n, "rays_total": n_total, "triangles": int(len(f)),
-                       "parallelism": par, "dst_share": share if world > 1 else None, "warmup_steps_done": w_done,
+                       "parallelism": par, "dst_share": share if world > 1 else None,
+                       "shard_rays": [z_ - a_ for a_, z_ in bounds_all] if world > 1 else None, "warmup_steps_done": w_done,
                        "bvh_depth": info["depth"], "bvh_bytes": int(bvh_bytes), "bvh_build_ms": round(build_ms, 2),
                        "hit_fraction": round(float(hit0.float().mean().item()), 4) if hit0 is not None else None},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
