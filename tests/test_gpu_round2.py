@@ -494,6 +494,15 @@ def test_large_meshes_deep_trees_and_arrays_above_4gib(device, subdiv):
     r2 = make(v, f, device)
     hit2, front2, tri2, loc2, uv2 = r2.intersects_closest(ot, dt)
     assert torch.equal(tri2, tri) and torch.equal(loc2, loc) and torch.equal(uv2, uv) and torch.equal(front2, front)
+    # what a sharded run exchanges: the slot forms of the records exist while the triangle array stays below 2 GiB
+    # (32-bit byte offsets in the expansion); above that the tracer says so and the face form carries on
+    assert r.packed_slots == (len(f) * 48 < (1 << 31)) and r.slot_records == r.packed_slots
+    rec = r.intersects_closest_packed(ot, dt, slots=r.packed_slots)
+    for a, e in zip(r2.closest_expand(rec, batch_shape=ot.shape[:-1], slots=r.packed_slots), (hit, front, tri, loc, uv)):
+        assert torch.equal(a, e)
+    if r.slot_records:
+        for a, e in zip(r2.closest_from_slots(ot, dt, r.intersects_closest_slots(ot, dt)), (hit, front, tri, loc, uv)):
+            assert torch.equal(a, e)
 
 
 def test_last_launch_reports_the_shape_and_the_measured_node_flavour(device):

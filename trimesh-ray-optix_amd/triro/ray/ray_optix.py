@@ -116,7 +116,15 @@ class RayMeshIntersector:
         straight into its rows of the full-size results (triro.ray.sharded; not in the reference)."""
         return hops.intersects_closest(self.as_wrapper, origins, directions, outs=outs)
 
-    packed_slots = True     # this tracer offers the slot form of the packed records (triro.ray.sharded)
+    @property
+    def packed_slots(self) -> bool:
+        """this tracer offers the slot form of the packed records (triro.ray.sharded): the expansion addresses the
+        triangle array with 32-bit byte offsets, so the array has to stay below 2 GiB (44.7 M triangles); larger meshes
+        keep the face form"""
+        try:
+            return int(self.bvh_info()["tri_bytes"]) < (1 << 31)
+        except Exception:
+            return False
 
     def intersects_closest_packed(self, origins, directions, out: Optional[torch.Tensor] = None, slots: bool = False) -> torch.Tensor:
         """Closest hit as int32 [n, 3] rows {tri_idx | front << 30 (-1: miss), u bits, v bits}: 12 bytes
@@ -137,7 +145,10 @@ class RayMeshIntersector:
         f = self.mesh_faces if self.mesh_faces.device == dev else self.mesh_faces.to(dev)
         return hops.closest_expand(packed, v, f, batch_shape, outs)
 
-    slot_records = True     # ... and the 4-byte record for a destination that holds the rays
+    @property
+    def slot_records(self) -> bool:
+        """... and the 4-byte record for a destination that holds the rays (same size limit)"""
+        return self.packed_slots
 
     def intersects_closest_slots(self, origins, directions, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Closest hit as int32 [n]: the arena slot of the nearest triangle, -1 for a miss -- 4 bytes per ray (not in the

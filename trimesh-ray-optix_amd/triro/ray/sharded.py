@@ -192,10 +192,27 @@ class ShardedRayMeshIntersector:
         # slot form of the packed records (RayMeshIntersector.packed_slots): the destination reads one 48-byte triangle
         # record per hit instead of four rows in four cache lines; needs bit-identical replicas on all ranks (same
         # mesh, same build options -- the builder is deterministic).  TRIRO_PACKED_SLOTS=0 keeps the face form.
-        self.slots = bool(getattr(local, "packed_slots", False)) and os.environ.get("TRIRO_PACKED_SLOTS", "1") != "0"
+        # (asked of `local` at every call: a mesh of more than 44.7 M triangles has no slot form, update_raw can change it)
+        self._slots_on = os.environ.get("TRIRO_PACKED_SLOTS", "1") != "0"
         # 4-byte records (the slot alone) where the destination holds the rays: TRIRO_SLOT_RECORDS=0 keeps the 12-byte ones
-        self.slot_records = self.slots and bool(getattr(local, "slot_records", False)) and os.environ.get("TRIRO_SLOT_RECORDS", "1") != "0"
+        self._slot_records_on = os.environ.get("TRIRO_SLOT_RECORDS", "1") != "0"
         self._side = None      # side stream of the destination rank (wait for chunk, expand)
+
+    @property
+    def slots(self) -> bool:
+        return self._slots_on and bool(getattr(self.local, "packed_slots", False))
+
+    @slots.setter
+    def slots(self, on: bool):
+        self._slots_on = bool(on)
+
+    @property
+    def slot_records(self) -> bool:
+        return self._slot_records_on and self.slots and bool(getattr(self.local, "slot_records", False))
+
+    @slot_records.setter
+    def slot_records(self, on: bool):
+        self._slot_records_on = bool(on)
 
     # ---- helpers -------------------------------------------------------------------------
     def bounds(self, n: int, dst: Optional[int] = None, quantum: int = 1, weighted: bool = False) -> List[Tuple[int, int]]:
@@ -394,6 +411,7 @@ class ShardedRayMeshIntersector:
         if records not in ("packed", "slot"):
             raise ValueError("records must be 'packed' or 'slot'")
         slot_rec = records == "slot"
+        slots_on = self.slots            # (asks the tracer: once per call)
         if slot_rec and not self.slot_records:
             raise ValueError("records='slot' needs a tracer with intersects_closest_slots / closest_from_slots")
         rec_shape = () if slot_rec else (3,)
@@ -486,7 +504,7 @@ class ShardedRayMeshIntersector:
                 elif slot_rec:
                     self.local.intersects_closest_slots(ok, dk, out=mine[a:z])
                 else:
-                    if self.slots:
+                    if slots_on:
                         self.local.intersects_closest_packed(ok, dk, out=mine[a:z], slots=True)
                     else:
                         self.local.intersects_closest_packed(ok, dk, out=mine[a:z])
@@ -519,7 +537,7 @@ class ShardedRayMeshIntersector:
                             ro, rd = ray_rows(ra, rz)
                             self.local.closest_from_slots(ro, rd, packed_all[ra:rz], outs=tuple(x[ra:rz] for x in flat_outs),
                                                           row_length=per_row if per_row > 1 else 0)
-                        elif self.slots:
+                        elif slots_on:
                             # (rows of an image: a wave expands a block of 8 rows x 32 pixels)
                             self.local.closest_expand(packed_all[ra:rz], outs=tuple(x[ra:rz] for x in flat_outs), slots=True,
                                                       row_length=per_row if per_row > 1 else 0)
