@@ -367,3 +367,43 @@ def test_four_byte_slot_records_finish_to_the_dense_outputs(device):
         assert not bool(r.closest_from_slots(oo, dd, bad)[0].reshape(-1)[::5].any())
     with pytest.raises(ValueError):
         r.closest_from_slots(ho, hd, sl[:5])
+
+
+def test_four_byte_records_edge_cases(device):
+    """the 4-byte records on the inputs the dense path is tested with: a single-triangle mesh (no hierarchy), zero
+    rays, NaN / Inf rays (miss), a stride-0 origin with three batch dims and non-contiguous directions, wrong arguments"""
+    from triro.ray.ray_optix import RayMeshIntersector
+    Td = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(device)  # noqa: E731
+    v1 = np.array([[0.5, -0.5, 0], [0, 0.5, 0], [-0.5, -0.5, 0]], np.float32)
+    f1 = np.array([[0, 1, 2]], np.int32)
+    r1 = RayMeshIntersector(vertices=Td(v1), faces=Td(f1))
+    o = torch.tensor([[0, 0, 4.0], [10, 10, 10], [float("nan"), 0, 1], [0, 0, -4.0]], device=device)
+    d = torch.tensor([[0, 0, -1.0], [0, 1, 0], [0, 0, -1], [0, 0, float("inf")]], device=device)
+    dense = r1.intersects_closest(o, d)
+    sl = r1.intersects_closest_slots(o, d)
+    assert sl.tolist() == [0, -1, -1, -1]
+    for a, e in zip(r1.closest_from_slots(o, d, sl), dense):
+        assert torch.equal(a, e)
+    z3 = torch.zeros(0, 3, device=device)
+    empty = r1.intersects_closest_slots(z3, z3)
+    assert empty.shape == (0,)
+    assert [tuple(x.shape) for x in r1.closest_from_slots(z3, z3, empty)] == [(0,), (0,), (0,), (0, 3), (0, 2)]
+    v, f = W.icosphere(4)
+    r = RayMeshIntersector(vertices=Td(v), faces=Td(f))
+    dn = W.pinhole_grid(40, 24)[1].reshape(2, 12, 40, 3)
+    big = torch.zeros(2, 12, 40, 6, device=device)
+    big[..., ::2] = Td(dn)
+    dirs = big[..., ::2]
+    assert not dirs.is_contiguous()
+    org = torch.tensor([0.0, 0.0, 2.5], device=device).expand(2, 12, 40, 3)
+    dense = r.intersects_closest(org, dirs)
+    sl = r.intersects_closest_slots(org, dirs)
+    assert tuple(sl.shape) == (960,) and 0.1 < float((sl >= 0).float().mean()) < 0.9
+    for a, e in zip(r.closest_from_slots(org, dirs, sl), dense):
+        assert a.shape == e.shape and torch.equal(a, e)
+    with pytest.raises(ValueError):
+        r.closest_from_slots(org, dirs, sl.float())                              # not int32
+    with pytest.raises(ValueError):
+        r.closest_from_slots(org, dirs, sl[:7])                                  # not one slot per ray
+    with pytest.raises(ValueError):
+        r.intersects_closest_slots(org, dirs, out=torch.zeros(7, dtype=torch.int32, device=device))
