@@ -35,3 +35,12 @@ def device():
     import torch
     assert torch.cuda.is_available()
     return torch.device("cuda:0")
+
+
+def free_port() -> int:
+    """a TCP port nobody listens on (rendezvous of the multi-process tests): fixed ports derived from the pid collide when
+    two tests of one session reuse them back to back -- the second rendezvous then waits out its 15-minute timeout"""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return int(sk.getsockname()[1])

@@ -30,6 +30,9 @@ try:
     o, d = torch.from_numpy(np.ascontiguousarray(o_np)).to(dev), torch.from_numpy(d_np).to(dev)
     lo, hi = v.min(0) * 1.5, v.max(0) * 1.5
     ho, hd = W.hash_rays_torch(100_001, 99, lo, hi, start=0, device=dev)      # ragged: odd count, flat, incoherent
+    # the replica handshake of the slot-form records: both ranks built the same mesh, the fingerprints agree
+    S0 = ShardedRayMeshIntersector(r)
+    assert S0.slots and S0.slot_records and S0._fp_ok is True
     batches = {"image": (o, d), "hash": (ho, hd)}
     for name, (bo, bd) in batches.items():
         exp = r.intersects_closest(bo, bd)

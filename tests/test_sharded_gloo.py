@@ -339,6 +339,29 @@ def _worker(rank, world, port, q):
                 if rank == 0:
                     for a, e in zip(g11, exp):
                         ok &= torch.equal(a.reshape(e.shape), e)
+        # ---- replica handshake: slot-form records only travel when every rank's replica has the same slot layout --------
+        class Fingerprinted(CpuLocalSlots):
+            def __init__(self, v_, f_, fp):
+                super().__init__(v_, f_)
+                self.fp, self.fp_calls = fp, 0
+
+            def replica_fingerprint(self):
+                self.fp_calls += 1
+                return self.fp
+        for differ in (False, True):
+            F = ShardedRayMeshIntersector(Fingerprinted(v, f, 1234 + (rank if differ else 0)))
+            for _ in range(2):
+                g12 = F.intersects_closest(o, d, dst=0, chunks=2)
+                if rank == 0:
+                    for a, e in zip(g12, exp):
+                        ok &= torch.equal(a.reshape(e.shape), e)
+            ok &= F.local.fp_calls == 1                                     # asked once per hierarchy
+            ok &= F.slot_records == (not differ) and F.slots == (not differ)
+            if differ:      # every rank fell back to the 12-byte records alike: nothing slot-shaped was traced or finished
+                ok &= not F.local.slot_calls and not F.local.from_calls
+                ok &= (len(F.local.packed_calls) > 0) == (rank != 0)
+            else:
+                ok &= not F.local.packed_calls and (len(F.local.slot_calls) > 0) == (rank != 0)
         ok &= 0.0 < auto_dst_share(8) < 1.0 and auto_dst_share(1) == 1.0
         # round 1's padded exchange stays selectable (fallback until the in-place path has run on RCCL)
         Q = ShardedRayMeshIntersector(CpuLocal(v, f), gather_mode="padded")
@@ -358,7 +381,8 @@ def _worker(rank, world, port, q):
 def test_sharded_world2_gloo():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
+    from conftest import free_port
+    port = free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()

@@ -145,6 +145,25 @@ class RayMeshIntersector:
         f = self.mesh_faces if self.mesh_faces.device == dev else self.mesh_faces.to(dev)
         return hops.closest_expand(packed, v, f, batch_shape, outs)
 
+    def replica_fingerprint(self) -> int:
+        """64-bit summary of this hierarchy's SLOT LAYOUT: the slots 8 192 fixed probe rays hit, position-weighted.  Two
+        replicas whose fingerprints agree name the same triangles by the same slots (the builder is deterministic, so
+        replicas of one mesh built with the same options do); triro.ray.sharded compares them across ranks before it
+        lets slot-form records travel."""
+        info = self.bvh_info()
+        lo = torch.tensor(info["aabb_min"], dtype=torch.float32)
+        hi = torch.tensor(info["aabb_max"], dtype=torch.float32)
+        g = torch.Generator().manual_seed(20240229)
+        u = torch.rand((8192, 3), generator=g)
+        w = torch.rand((8192, 3), generator=g)
+        ext = (hi - lo).clamp_min(1e-30)
+        o = (lo - 0.25 * ext) + u * (1.5 * ext)
+        d = (lo + w * ext) - o                       # towards a point inside the box: most probes hit something
+        dev = self.mesh_vertices.device
+        sl = self.intersects_closest_slots(o.to(dev), d.to(dev)).to(torch.int64)
+        k = torch.arange(1, sl.numel() + 1, dtype=torch.int64, device=dev)
+        return int(((sl + 2) * k).sum().item()) ^ (int(info["num_tris"]) << 40)
+
     @property
     def slot_records(self) -> bool:
         """... and the 4-byte record for a destination that holds the rays (same size limit)"""

@@ -196,11 +196,36 @@ class ShardedRayMeshIntersector:
         self._slots_on = os.environ.get("TRIRO_PACKED_SLOTS", "1") != "0"
         # 4-byte records (the slot alone) where the destination holds the rays: TRIRO_SLOT_RECORDS=0 keeps the 12-byte ones
         self._slot_records_on = os.environ.get("TRIRO_SLOT_RECORDS", "1") != "0"
+        self._fp_key, self._fp_ok = None, None       # replica handshake (_replicas_agree)
         self._side = None      # side stream of the destination rank (wait for chunk, expand)
+
+    def _replicas_agree(self) -> bool:
+        """Slot-form records name triangles by their position in the sender's arena: they are only let out when every
+        rank's replica has the same slot layout.  Checked once per hierarchy (the tracer's `replica_fingerprint`, a
+        64-bit summary of the slots a fixed probe batch hits, all-gathered: 8 bytes per rank); a mismatch -- different
+        meshes, build options or library versions on the ranks -- switches this front end to the face form on EVERY
+        rank (they all see the same gathered values) instead of returning wrong triangles."""
+        if self.world < 2 or not dist.is_initialized() or not hasattr(self.local, "replica_fingerprint"):
+            return True
+        info = self.local.bvh_info() if hasattr(self.local, "bvh_info") else {}
+        key = (info.get("num_tris"), info.get("num_nodes"), info.get("arena_bytes"))
+        if self._fp_key != key or self._fp_ok is None:
+            fp = int(self.local.replica_fingerprint()) & 0x7fffffffffffffff
+            cdev = torch.device("cpu") if self._stage or not torch.cuda.is_available() else torch.device("cuda", torch.cuda.current_device())
+            mine = torch.tensor([fp], dtype=torch.int64, device=cdev)
+            every = torch.empty((self.world,), dtype=torch.int64, device=cdev)
+            dist.all_gather_into_tensor(every, mine, group=self.group)
+            self._fp_ok = bool((every == every[0]).all().item())
+            self._fp_key = key
+            if not self._fp_ok and self.rank == 0:
+                import warnings
+                warnings.warn("triro.ray.sharded: the ranks' BVH replicas differ in their slot layout; closest-hit records fall "
+                              "back to the face form (12 bytes per ray)")
+        return self._fp_ok
 
     @property
     def slots(self) -> bool:
-        return self._slots_on and bool(getattr(self.local, "packed_slots", False))
+        return self._slots_on and bool(getattr(self.local, "packed_slots", False)) and self._replicas_agree()
 
     @slots.setter
     def slots(self, on: bool):
