@@ -242,7 +242,7 @@ def run_rank(args):
     import numpy as np
     import torch
     import workloads as W
-    from triro.ray.sharded import ShardedRayMeshIntersector, shard_bounds, weighted_bounds, auto_dst_share
+    from triro.ray.sharded import ShardedRayMeshIntersector, shard_bounds, dst_bounds
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -303,7 +303,7 @@ def run_rank(args):
 
     def split_batch(n_rays, quantum):
         if share is not None and share < 1.0 and world > 1:
-            return weighted_bounds(n_rays, [share] + [1.0] * (world - 1), quantum)
+            return dst_bounds(n_rays, world, 0, share, quantum)
         return [shard_bounds(n_rays, world, k) for k in range(world)]
     row_quantum = None
     if strong_c5i:
@@ -786,7 +786,7 @@ def run_emulation(args):
     import workloads as W
     import triro.backend.ops as hops
     from triro.ray.ray_optix import RayMeshIntersector
-    from triro.ray.sharded import EmulatedWorld, shard_bounds, weighted_bounds, auto_dst_share
+    from triro.ray.sharded import EmulatedWorld, shard_bounds, dst_bounds
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py --emulate-world needs a GPU")
@@ -820,7 +820,7 @@ def run_emulation(args):
         n = res_ * res_
         n_total = N * n
         if share is not None and share < 1.0:
-            bounds = weighted_bounds(n_total, [share] + [1.0] * (N - 1), res_ if pinhole else 1)
+            bounds = dst_bounds(n_total, N, 0, share, res_ if pinhole else 1)
         else:
             bounds = [(k * n, (k + 1) * n) for k in range(N)]
         bshape = (N * res_, res_) if pinhole else (n_total,)
@@ -842,7 +842,7 @@ def run_emulation(args):
         n_total = res_ * res_ if args.workload == "c5i" else args.total_rays
         q = res_ if pinhole else 1
         if share is not None and share < 1.0:
-            bounds = weighted_bounds(n_total, [share] + [1.0] * (N - 1), q)
+            bounds = dst_bounds(n_total, N, 0, share, q)
         else:
             bounds = [shard_bounds(n_total, N, k) for k in range(N)]
         rows_ok = pinhole and all(a % res_ == 0 and z % res_ == 0 for a, z in bounds)

@@ -262,7 +262,7 @@ def _worker(rank, world, port, q):
             for a, e in zip(g4, exp):
                 ok &= torch.equal(a.reshape(e.shape), e)
         # ---- round 4: the destination traces dense in place, weighted shards, host staging ---------------
-        from triro.ray.sharded import weighted_bounds, auto_dst_share
+        from triro.ray.sharded import weighted_bounds, auto_dst_share, dst_bounds
         for stage in (False, True):          # True: every exchange through the host-staging transport (gloo + device tensors)
             for share in (None, 0.5, 0.0):
                 D = ShardedRayMeshIntersector(CpuLocalInto(v, f), dst_share=share, stage_through_host=stage or None)
@@ -271,7 +271,7 @@ def _worker(rank, world, port, q):
                     g6 = D.intersects_closest(o, d, dst=dst_, chunks=ch)
                     bb = D.bounds(851, dst_, 37, weighted=True)
                     if share == 0.5 and dst_ is not None:
-                        ok &= bb == weighted_bounds(851, [0.5 if r == dst_ else 1.0 for r in range(world)], 37)
+                        ok &= bb == dst_bounds(851, world, dst_, 0.5, 37)
                         ok &= (bb[dst_][1] - bb[dst_][0]) < (bb[1 - dst_][1] - bb[1 - dst_][0])
                     if dst_ is None or dst_ == rank:
                         for a, e in zip(g6, exp):
@@ -415,3 +415,23 @@ def test_shard_bounds():
             assert all(chunks[i][1] == chunks[i + 1][0] for i in range(w - 1))
             sizes = [hi - lo for lo, hi in chunks]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_dst_bounds_gives_equal_peer_shards():
+    from triro.ray.sharded import dst_bounds
+    for n in (0, 1, 5, 851, 1024 * 1024, 8192 * 1024, 100_000_000):
+        for world in (1, 2, 3, 8):
+            for dst in sorted({0, world - 1, world // 2}):
+                for share in (0.0, 0.25, 0.47, 1.0):
+                    for q in (1, 37, 1024):
+                        b = dst_bounds(n, world, dst, share, q)
+                        assert len(b) == world and b[0][0] == 0 and b[-1][1] == n
+                        assert all(b[k][1] == b[k + 1][0] for k in range(world - 1))
+                        sizes = [z - a for a, z in b]
+                        assert len({sizes[r] for r in range(world) if r != dst}) <= 1          # the peers: equal
+                        if n % q == 0 and q > 1:
+                            assert all(a % q == 0 for a, _ in b)
+                        if world > 1 and share == 1.0 and n % (world * q) == 0:
+                            assert len(set(sizes)) == 1                                       # even
+                        if world > 1 and sizes[(dst + 1) % world] > 0:
+                            assert sizes[dst] <= sizes[(dst + 1) % world] + (world - 1) * q    # (+ the remainder)

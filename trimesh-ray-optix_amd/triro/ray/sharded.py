@@ -76,6 +76,28 @@ def weighted_bounds(n: int, weights: Sequence[float], quantum: int = 1) -> List[
     return [(edges[r] * quantum, edges[r + 1] * quantum) for r in range(world)]
 
 
+def dst_bounds(n: int, world: int, dst: int, share: float, quantum: int = 1) -> List[Tuple[int, int]]:
+    """Contiguous shards of [0, n) in rank order where rank `dst` traces `share` x an even shard and ALL OTHER ranks
+    trace equally much (the remainder of the division goes to `dst`): equal peer chunks travel in ONE gather collective
+    (the destination hands in a scratch chunk of the peers' size), ragged ones need a point-to-point operation per peer
+    and step.  Cut at multiples of `quantum` rays (whole image rows) when n is a multiple of it."""
+    if world < 2:
+        return [(0, n)]
+    if quantum < 1 or n % quantum:
+        quantum = 1
+    units = n // quantum
+    share = min(max(float(share), 0.0), 1.0)
+    d_units = int(round(units * share / (share + world - 1)))
+    each, rem = divmod(units - d_units, world - 1)
+    d_units += rem
+    out, at = [], 0
+    for r in range(world):
+        k = d_units if r == dst else each
+        out.append((at * quantum, (at + k) * quantum))
+        at += k
+    return out
+
+
 def auto_dst_share(world: int, rho: float = 0.10) -> float:
     """Share of an EVEN shard the destination rank of a packed closest-hit gather should trace so that
     all ranks finish together: the destination spends rho x (a ray's trace time) on every ray somebody
@@ -197,6 +219,7 @@ class ShardedRayMeshIntersector:
         # 4-byte records (the slot alone) where the destination holds the rays: TRIRO_SLOT_RECORDS=0 keeps the 12-byte ones
         self._slot_records_on = os.environ.get("TRIRO_SLOT_RECORDS", "1") != "0"
         self._fp_key, self._fp_ok = None, None       # replica handshake (_replicas_agree)
+        self._scratch_bufs = {}
         self._side = None      # side stream of the destination rank (wait for chunk, expand)
 
     def _replicas_agree(self) -> bool:
@@ -245,9 +268,7 @@ class ShardedRayMeshIntersector:
         and a destination with dst_share < 1 exist: then the destination's shard is that fraction of an
         even one, cut at multiples of `quantum`."""
         if weighted and dst is not None and self.world > 1 and self.dst_share is not None and self.dst_share < 1.0:
-            w = [1.0] * self.world
-            w[dst] = float(self.dst_share)
-            return weighted_bounds(n, w, quantum)
+            return dst_bounds(n, self.world, dst, float(self.dst_share), quantum)
         return [shard_bounds(n, self.world, r) for r in range(self.world)]
 
     def _my_rays(self, origins: torch.Tensor, directions: torch.Tensor, bounds=None):
@@ -284,6 +305,11 @@ class ShardedRayMeshIntersector:
         world, rank = self.world, self.rank
         sizes = [hi - lo for lo, hi in bounds]
         equal = len(set(sizes)) == 1
+        # all ranks but the destination hold equally many rows (dst_bounds; a destination that traced dense sends none):
+        # still ONE gather -- the destination hands in, and receives into, a scratch chunk of the peers' size.  Decided
+        # from the peers' sizes only, which every rank sees alike whatever it was told about the destination's rows.
+        peer_sizes = {sizes[r] for r in range(world) if r != dst} if (dst is not None and world > 1) else set()
+        peer_equal = not equal and len(peer_sizes) == 1 and min(peer_sizes) > 0
         want = dst is None or rank == dst
         if self.gather_mode == "padded" and not self._staged(src):
             return self._exchange_padded(src, out, bounds, dst)
@@ -321,6 +347,18 @@ class ShardedRayMeshIntersector:
                     views = [torch.empty_like(src_x) if r == rank else v for r, v in enumerate(views)]
                 w = dist.gather(src_x, views, dst=dst, group=self.group, async_op=async_op)
             works = [w] if async_op and w is not None else []
+        elif peer_equal:
+            psz = next(iter(peer_sizes))
+            if want:
+                lo, hi = bounds[rank]
+                if not staged and hi > lo and views[rank].data_ptr() != src_x.data_ptr():
+                    views[rank].copy_(src_x)            # (its own records, when it traced packed: local)
+                scratch = self._scratch((psz, *src.shape[1:]), src.dtype, torch.device("cpu") if staged else src.device)
+                glist = [scratch if r == rank else views[r] for r in range(world)]
+                w = dist.gather(scratch, glist, dst=dst, group=self.group, async_op=async_op)
+            else:
+                w = dist.gather(src_x, None, dst=dst, group=self.group, async_op=async_op)
+            works = [w] if async_op and w is not None else []
         else:
             ops = []
             if want:
@@ -348,6 +386,14 @@ class ShardedRayMeshIntersector:
             fin.wait()
             return []
         return works
+
+    def _scratch(self, shape, dtype, device):
+        """the destination's throw-away chunk of a peer-equal gather (kept: one per shape)"""
+        key = (tuple(shape), dtype, str(device))
+        t = self._scratch_bufs.get(key)
+        if t is None:
+            t = self._scratch_bufs[key] = torch.empty(shape, dtype=dtype, device=device)
+        return t
 
     def _global_rank(self, r: int) -> int:
         return r if self.group is None else dist.get_global_rank(self.group, r)
@@ -602,6 +648,7 @@ class ShardedRayMeshIntersector:
         sizes = [z - a for a, z in cb]
         if len(set(sizes)) == 1 and sizes[0] > 0:
             return self._exchange(packed_all[cb[self.rank][0]:cb[self.rank][1]], packed_all, cb, dst, async_op=True)
+        # (peers of equal size: one gather with a scratch chunk on this side; ragged peers: grouped receives)
         return self._exchange(empty, packed_all, rb, dst, async_op=True)
 
     def intersects_closest_async(self, origins, directions, dst: Optional[int] = 0,
