@@ -549,8 +549,9 @@ def run_rank(args):
             if args.force_gather and world == 1:
                 gather_txt += " [--force-gather: the exchange is a self-gather in a one-rank communicator]"
             if packed_ok:
-                gather_txt += (" (4 B/ray slot records over RCCL, finished on rank 0 from its copy of the rays, " if slot_rec else
-                               " (12 B/ray packed records over RCCL, expanded on rank 0, ") + "exchange of step k overlaps trace of step k+1)"
+                via = "gloo, host-staged" if gloo else "RCCL"
+                gather_txt += (f" (4 B/ray slot records over {via}, finished on rank 0 from its copy of the rays, " if slot_rec else
+                               f" (12 B/ray packed records over {via}, expanded on rank 0, ") + "exchange of step k overlaps trace of step k+1)"
         metric = "Mrays/s closest-hit, 1M-tri mesh, 1024^2 ray batch"
         kernel_name = "k_query_direct<CLOSEST>"
         if strong_c5i:

@@ -72,11 +72,11 @@ def test_gpus2_gathers_by_default_and_strong_scaling_of_one_image():
     assert p.returncode == 0, p.stderr[-2000:]
     r = json.loads(p.stdout.strip().splitlines()[-1])
     assert r["scaling"] == "weak" and r["config"]["rays_total"] == 2 * 64 * 64 and r["verified"] is True
-    assert "gathered to rank 0 inside the timed region (4 B/ray slot" in r["config"]["parallelism"]      # rank 0 holds the rays
+    assert "gathered to rank 0 inside the timed region (4 B/ray slot records over gloo" in r["config"]["parallelism"]      # rank 0 holds the rays
     p = run_bench(*common, "--records", "packed")
     assert p.returncode == 0, p.stderr[-2000:]
     r = json.loads(p.stdout.strip().splitlines()[-1])
-    assert r["verified"] is True and "(12 B/ray packed" in r["config"]["parallelism"]
+    assert r["verified"] is True and "(12 B/ray packed records over gloo" in r["config"]["parallelism"]
     p = run_bench(*common, "--scaling", "strong")
     assert p.returncode == 0, p.stderr[-2000:]
     r = json.loads(p.stdout.strip().splitlines()[-1])

@@ -305,7 +305,7 @@ def test_bench_result_pipeline_on_rccl_one_rank():
         line = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')][-1]
         r = json.loads(line)
         assert r["verified"] is True and r["n_gpus"] == 1 and r["value"] > 100
-        want = "12 B/ray packed" if "packed" in extra else "4 B/ray slot"       # (round 4: rank 0 holds the rays by default)
+        want = "12 B/ray packed records over RCCL" if "packed" in extra else "4 B/ray slot records over RCCL"       # (round 4: rank 0 holds the rays by default)
         assert want in r["config"]["parallelism"] and "--force-gather" in r["config"]["parallelism"]
 
 

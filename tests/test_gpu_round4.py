@@ -63,6 +63,20 @@ def test_bench_two_ranks_on_one_gpu_over_gloo(extra):
 
 
 @pytest.mark.timeout(900)
+@pytest.mark.parametrize("extra", [[], ["--workload", "c5ii", "--total-rays", "4000001"]], ids=["weak", "c5ii"])
+def test_bench_eight_ranks_on_one_gpu_over_gloo(extra):
+    """the driver's `bench.py --gpus 8` with the transport replaced (gloo, host-staged; all ranks on cuda:0): eight
+    shards with rank 0's narrower, seven peers' 4-byte records in one gather per step, finished on rank 0 -- and the
+    last timed step equal to the cold first call bit for bit"""
+    r = _bench(["--gpus", "8", "--backend", "gloo", "--subdiv", "6", "--res", "256", "--steps", "3", "--warmup", "1",
+                "--min-warmup-ms", "0", "--no-cpu-baseline", "--no-companions"] + extra)
+    assert r["n_gpus"] == 8 and r["verified"] is True and "NOT a measurement" in r["data"]
+    sh = r["config"]["shard_rays"]
+    assert len(sh) == 8 and len(set(sh[1:])) == 1 and 0 < sh[0] < sh[1] and sum(sh) == r["config"]["rays_total"]
+    assert "4 B/ray slot records over gloo" in r["config"]["parallelism"]
+
+
+@pytest.mark.timeout(900)
 @pytest.mark.parametrize("extra", [
     ["--emulate-world", "8"],
     ["--emulate-world", "8", "--dst-share", "1"],
