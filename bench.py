@@ -104,6 +104,10 @@ def parse(argv=None):
     ap.add_argument("--trace-priority", action="store_true",
                     help="N > 1 / --emulate-world: the step loop (the traces) runs on a HIGH-priority stream, so that the expansion on "
                          "the side stream only takes the wave slots the trace leaves free")
+    ap.add_argument("--event-stride", type=int, default=0,
+                    help="bracket every N-th timed step with a HIP event pair for the roofline's kernel time (0 = 5 ... 64 samples "
+                         "over the timed region, an odd stride: 20 steps -> every 3rd, 1000 steps -> every 15th; measured: pairs around EVERY step "
+                         "cost the wall clock 7.5 us of every 205)")
     ap.add_argument("--records", choices=["slot", "packed"], default="slot",
                     help="N > 1, closest-hit gather: 'slot' = 4-byte records, rank 0 holds the rays of the whole batch and "
                          "finishes the query from (ray, slot); 'packed' = 12-byte {slot, u, v} records, rank 0 needs no rays")
@@ -463,7 +467,12 @@ def run_rank(args):
     # event objects, a garbage collection) happens BEFORE the warm-up: after a few milliseconds of
     # idleness the chip needs ~50 launches to come back to its steady clock, which is all a
     # 20-step run ever sees (measured: 0.275 instead of 0.256 ms per launch).
-    ev = [event_pair() for _ in range(args.steps)]
+    # (the event pairs bracket every `stride`-th step: an event is a packet of its own in the queue, two per step cost
+    # the wall clock -- from which `value` is computed -- a few microseconds of every 200; short runs keep every step)
+    ev_stride = max(1, int(args.event_stride)) if args.event_stride else max(1, args.steps // min(64, max(6, args.steps // 3)))
+    if not args.event_stride and ev_stride % 2 == 0:
+        ev_stride += 1          # (odd: the block-cost sort runs behind every 4th launch -- the samples must not lock onto it)
+    ev = [event_pair() if k % ev_stride == 0 else None for k in range(args.steps)]
     import gc
     gc.collect()
     gc.disable()            # a step is ~0.3 ms: keep collector pauses out of the timed region
@@ -491,7 +500,7 @@ def run_rank(args):
     barrier()
     elapsed = time.perf_counter() - t0
     gc.enable()
-    kernel_ms = [a.elapsed_time(b) for a, b in ev] if not stub else [elapsed / args.steps * 1e3] * args.steps
+    kernel_ms = [p_[0].elapsed_time(p_[1]) for p_ in ev if p_] if not stub else [elapsed / args.steps * 1e3] * args.steps
     if os.environ.get("TRIRO_BENCH_TRACE") and rank == 0:   # per-step durations, launch order
         print("per-step ms:", " ".join(f"{x:.3f}" for x in kernel_ms), file=sys.stderr)
     kernel_ms.sort()
@@ -591,7 +600,7 @@ def run_rank(args):
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kernel_name, "kernel_avg_ms": round(kernel_avg_ms, 4),
-                         "kernel_min_ms": round(kernel_ms[0], 4), "first_call_ms": round(first_call_ms, 4),
+                         "kernel_min_ms": round(kernel_ms[0], 4), "kernel_samples": len(kernel_ms), "first_call_ms": round(first_call_ms, 4),
                          "algorithmic_bytes": int(algo_bytes),
                          "node_flavour": "32-byte grid nodes" if grid_nodes else "exact 64-byte nodes",
                          "frac_on_exact_node_bytes": round(algo_bytes_exact / (kernel_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
