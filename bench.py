@@ -606,7 +606,10 @@ def run_rank(args):
                          "frac_on_exact_node_bytes": round(algo_bytes_exact / (kernel_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
                          "compulsory_frac": round(compulsory / HBM_PEAK_GBPS, 5),
                          "note": "achieved = (50 B/ray compulsory I/O + one read of the node and triangle arrays the launch walks) per launch / "
-                                 "event-timed kernel_avg_ms; compulsory_frac counts the 50 B/ray only; the path is "
+                                 "event-timed kernel_avg_ms (kernel_samples event pairs spread over the timed region; the interval "
+                                 "between a pair holds the kernel and a few microseconds of packet latency -- rocprofv3: 195 us "
+                                 "for the headline kernel, profiles/r04m_summary.md -- so it can exceed ms_per_step, the wall clock "
+                                 "of back-to-back launches); compulsory_frac counts the 50 B/ray only; the path is "
                                  "cache-latency / instruction-issue bound, not HBM-bandwidth bound (DESIGN.md 5); "
                                  "frac_on_exact_node_bytes = the same time against round 1's numerator (64-byte nodes), "
                                  "for comparison across rounds only"},
