@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define TR_ABI_VERSION 8
+#define TR_ABI_VERSION 9
 #define TR_MAX_ANYHIT_SIZE 8 /* LaunchParams.h:8  (per-ray cap of intersects_location) */
 #define TR_MAX_SIZE_LENGTH 4 /* LaunchParams.h:9  (ray tensors have <= 4 dims)         */
 #define TR_MAX_HITS_CAP 32   /* largest `cap` tr_intersects_location_fill accepts      */
@@ -197,6 +197,14 @@ int tr_closest_expand_slots_rows(const tr_bvh *bvh, const tr_packed_hit *d_packe
 int tr_intersects_closest_slots(const tr_bvh *bvh, const tr_rays *rays, int32_t *d_slot, void *stream);
 int tr_closest_from_slots(const tr_bvh *bvh, const tr_rays *rays, const int32_t *d_slot, int64_t row_length,
                           uint8_t *d_hit, uint8_t *d_front, int32_t *d_tri, float *d_loc3, float *d_uv2, void *stream);
+
+/* ... and what makes "a bit-identical replica" checkable (ABI 9): an exact 64-bit hash of the triangle arena -- for every
+ *    slot its position and the twelve words of its record (three vertices, face index) -- plus the triangle count.  Two
+ *    handles with the same hash name the same triangles by the same slots and hold the same vertices for them (up to a
+ *    2^-64 collision), so slot-form records of one can be finished on the other; a sharded front end compares the ranks'
+ *    hashes before it lets such records travel (triro/ray/sharded.py).  One pass over the arena (63 MB at 1.31 M
+ *    triangles), synchronises `stream`.  The reference has no counterpart (single GPU: base.cpp:15-17).        */
+int tr_bvh_replica_hash(const tr_bvh *bvh, uint64_t *h_hash, void *stream);
 
 /* -- multi-hit (intersectsLocation, ray.cpp:324-378):
  *    tr_hits_scan replaces the torch glue of ray.cpp:333-342: d_offsets[i] = exclusive

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Static look at a kernel of the shipped library: instruction mix of its loops (no GPU needed).
+usage: python scripts/round5/isa_loops.py <substring of the demangled kernel name> [path/to/lib.so]
+Prints, for every backward branch (a loop), the span it closes and the VALU / SALU / VMEM / LDS counts inside."""
+import os, re, subprocess, sys, tempfile
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import code_object_notes as con
+
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+def disassemble(so, want):
+    for img in con.code_objects(so):
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(img); f.flush()
+            ks = [k for k in con.kernels_of_image(f.name)] if hasattr(con, "kernels_of_image") else None
+            txt = subprocess.run([OBJDUMP, "-d", f.name], capture_output=True, text=True).stdout
+        cur, out = None, {}
+        for line in txt.split("\n"):
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+            if m:
+                cur = m.group(1); out[cur] = []; continue
+            if cur and line.startswith("\t"):
+                out[cur].append(line)
+        names = list(out)
+        dem = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
+        for n, d in zip(names, dem):
+            d = d.replace("(anonymous namespace)::", "").split("(")[0]
+            if want in d and not n.endswith(".kd"):
+                yield d, out[n]
+
+
+def classify(op):
+    if op.startswith("v_"): return "valu"
+    if op.startswith(("global_", "buffer_", "flat_", "scratch_")): return "vmem"
+    if op.startswith("ds_"): return "lds"
+    if op.startswith("s_load") or op.startswith("s_buffer"): return "smem"
+    if op.startswith("s_"): return "salu"
+    return "other"
+
+
+def main():
+    want = sys.argv[1]
+    here = os.path.dirname(os.path.abspath(__file__))
+    so = sys.argv[2] if len(sys.argv) > 2 else os.path.join(here, "..", "..", "trimesh-ray-optix_amd", "lib", "libtriro_hip.so")
+    for name, lines in disassemble(so, want):
+        ins = []
+        for l in lines:
+            body = l.split("//")[0].strip()
+            m = re.search(r"//\s*([0-9A-F]+):", l)
+            addr = int(m.group(1), 16) if m else None
+            if body: ins.append((addr, body))
+        addr_idx = {a: i for i, (a, _) in enumerate(ins)}
+        print(f"== {name}: {len(ins)} instructions, {sum(1 for _, b in ins if b.startswith('v_'))} VALU")
+        for i, (a, b) in enumerate(ins):
+            m = re.match(r"(s_cbranch_\w+|s_branch)\s+(\d+)", b)
+            if not m: continue
+            off = int(m.group(2))
+            if off < 32768: continue
+            tgt = a + 4 + (off - 65536) * 4
+            j = addr_idx.get(tgt)
+            if j is None: continue
+            mix = {}
+            for _, bb in ins[j:i + 1]:
+                c = classify(bb.split()[0]); mix[c] = mix.get(c, 0) + 1
+            pk = sum(1 for _, bb in ins[j:i + 1] if bb.startswith("v_pk_"))
+            print(f"  loop [{j}..{i}] {i - j + 1:5d} instr  " + " ".join(f"{k}={v}" for k, v in sorted(mix.items())) + f"  (v_pk={pk})")
+
+
+if __name__ == "__main__":
+    main()

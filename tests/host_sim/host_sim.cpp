@@ -11,6 +11,7 @@
 
 #include "../../trimesh-ray-optix_amd/csrc/tr_bvh.h"
 #include "../../trimesh-ray-optix_amd/csrc/tr_lbvh.h"
+#include "../../trimesh-ray-optix_amd/csrc/tr_wide.h"
 
 struct SimBvh {
     tr_qframe frame = {{0, 0, 0}, {1, 1, 1}};
@@ -276,7 +277,7 @@ static void run_query(const tr_bvh_view& v, const float* o, const float* d, int6
     uint64_t tn = 0, tt = 0, tc = 0;
     for (int64_t i = 0; i < n; i++) {
         tr_ray r;
-        bool valid = tr_ray_setup(r, o[3 * i], o[3 * i + 1], o[3 * i + 2], d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+        bool valid = tr_ray_setup_q(r, v.frame, o[3 * i], o[3 * i + 1], o[3 * i + 2], d[3 * i], d[3 * i + 1], d[3 * i + 2]);
         tr_result res;
         tr_topk<1> top;
         cnt.nodes = cnt.tris = cnt.climbs = 0;
@@ -460,13 +461,102 @@ void sim_packet_stats(const void* nodes_, int64_t nf, const float* o, const floa
     }
 }
 
+// The fused box test of the grid nodes (tr_ray_fuse / tr_qnode_slabs, round 5) against the contract's three-step form
+// on the same decoded boxes: for every (ray, grid node, child) the fused interval must CONTAIN what tr_slab_hit can
+// see of the contract's --  tn' <= max(tn, 0)  and  tf' >= min(tf, TR_TMAX)  -- so that the fused traversal visits a
+// superset of the nodes.  Returns the number of violations; out[0] = pairs checked, out[1] = children the fused test
+// accepts, out[2] = children the contract's test accepts (the looseness paid for one fma per plane).
+int64_t sim_check_fused(const void* qnodes_, int64_t nnodes, const float* f6, const float* o, const float* d, int64_t n,
+                        int64_t node_stride, int64_t* out) {
+    const tr_qnode* qn = (const tr_qnode*)qnodes_;
+    tr_qframe f;
+    for (int k = 0; k < 3; k++) { f.base[k] = f6[k]; f.scale[k] = f6[3 + k]; }
+    int64_t bad = 0, pairs = 0, acc_f = 0, acc_c = 0;
+    for (int64_t i = 0; i < n; i++) {
+        tr_ray r;
+        if (!tr_ray_setup_q(r, f, o[3 * i], o[3 * i + 1], o[3 * i + 2], d[3 * i], d[3 * i + 1], d[3 * i + 2])) continue;
+        for (int64_t j = i % node_stride; j < nnodes; j += node_stride) {
+            const tr_i4* w = reinterpret_cast<const tr_i4*>(qn + j);
+            float a0, b0, a1, b1, c0, e0, c1, e1;
+            tr_qnode_slabs(r, f, w[0], w[1], a0, b0, a1, b1);
+            tr_qnode_slabs_contract(r, f, w[0], w[1], c0, e0, c1, e1);
+            const float fn[2] = {a0, a1}, ff[2] = {b0, b1}, cn[2] = {c0, c1}, cf[2] = {e0, e1};
+            for (int c = 0; c < 2; c++) {
+                pairs++;
+                if (!(fn[c] <= fmaxf(cn[c], 0.0f)) || !(ff[c] >= fminf(cf[c], TR_TMAX))) bad++;
+                acc_f += tr_slab_hit(fn[c], ff[c], TR_TMAX) ? 1 : 0;
+                acc_c += tr_slab_hit(cn[c], cf[c], TR_TMAX) ? 1 : 0;
+            }
+        }
+    }
+    out[0] = pairs; out[1] = acc_f; out[2] = acc_c;
+    return bad;
+}
+
+// The same for the 8-wide nodes (tr_wide.h): every wide node of the hierarchy (one per binary node at a depth that is a
+// multiple of three, built with the product's tr_wexits / tr_wnode_make), every child, fused (tr_wfuse_axis + one fma
+// per plane, as traverse_wide.inc) against the contract's decode - subtract - multiply on the node's own 8-bit grid.
+int64_t sim_check_fused_wide(const void* nodes_, int64_t nnodes, const float* f6, const float* o, const float* d, int64_t n,
+                             int64_t node_stride, int64_t* out) {
+    const tr_node* nodes = (const tr_node*)nodes_;
+    tr_qframe f;
+    for (int k = 0; k < 3; k++) { f.base[k] = f6[k]; f.scale[k] = f6[3 + k]; }
+    // roots of the wide nodes
+    std::vector<int32_t> roots, stack;
+    std::vector<int64_t> widx((size_t)nnodes, 0);
+    stack.push_back(0);
+    while (!stack.empty()) {
+        const int32_t r0 = stack.back(); stack.pop_back();
+        widx[r0] = (int64_t)roots.size();
+        roots.push_back(r0);
+        tr_wexit ex[8];
+        const int ne = tr_wexits(nodes, r0, ex);
+        for (int j = 0; j < ne; j++) if (ex[j].id >= 0) stack.push_back(ex[j].id);
+    }
+    std::vector<tr_wnode> wn(roots.size());
+    for (size_t w = 0; w < roots.size(); w++) {
+        tr_wexit ex[8];
+        const int ne = tr_wexits(nodes, roots[w], ex);
+        tr_wnode_make(ex, ne, widx.data(), &wn[w]);
+    }
+    int64_t bad = 0, pairs = 0, acc_f = 0, acc_c = 0;
+    for (int64_t i = 0; i < n; i++) {
+        tr_ray r;
+        if (!tr_ray_setup_q(r, f, o[3 * i], o[3 * i + 1], o[3 * i + 2], d[3 * i], d[3 * i + 1], d[3 * i + 2])) continue;
+        const float ro[3] = {r.ox, r.oy, r.oz}, ri[3] = {r.ix, r.iy, r.iz}, rk[3] = {r.kx, r.ky, r.kz}, re[3] = {r.ex, r.ey, r.ez};
+        for (size_t w = (size_t)(i % node_stride); w < wn.size(); w += (size_t)node_stride) {
+            const tr_wnode& N = wn[w];
+            float A[3], Bn[3], Bf[3], sc[3];
+            for (int k = 0; k < 3; k++) { sc[k] = tr_wscale(N.e[k]); tr_wfuse_axis(N.base[k], sc[k], ro[k], rk[k], re[k], A[k], Bn[k], Bf[k]); }
+            for (int c = 0; c < (int)N.n; c++) {
+                float tn = -INFINITY, tf = INFINITY, cn = -INFINITY, cf = INFINITY;
+                for (int k = 0; k < 3; k++) {
+                    const bool ng = ri[k] < 0.f;
+                    const float qe = (float)(ng ? N.q[3 + k][c] : N.q[k][c]), qx = (float)(ng ? N.q[k][c] : N.q[3 + k][c]);
+                    tn = fmaxf(tn, fmaf(qe, A[k], Bn[k]));
+                    tf = fminf(tf, fmaf(qx, A[k], Bf[k]));
+                    cn = fmaxf(cn, (tr_wdecode((uint32_t)qe, sc[k], N.base[k]) - ro[k]) * ri[k]);
+                    cf = fminf(cf, (tr_wdecode((uint32_t)qx, sc[k], N.base[k]) - ro[k]) * ri[k]);
+                }
+                cf *= TR_SLAB_PAD;
+                pairs++;
+                if (!(tn <= fmaxf(cn, 0.0f)) || !(tf >= fminf(cf, TR_TMAX))) bad++;
+                acc_f += tr_slab_hit(tn, tf, TR_TMAX) ? 1 : 0;
+                acc_c += tr_slab_hit(cn, cf, TR_TMAX) ? 1 : 0;
+            }
+        }
+    }
+    out[0] = pairs; out[1] = acc_f; out[2] = acc_c;
+    return bad;
+}
+
 // multi-hit: counts[i] hits (uncapped), first min(count,cap) nearest written at i*cap
 void sim_location(const void* nodes, const void* links, const void* tris, int64_t nf, const float* o,
                   const float* d, int64_t n, int32_t cap, int32_t* count, int32_t* tri_out, float* t_out) {
     tr_bvh_view v = view_of((const tr_node*)nodes, (const tr_link*)links, (const tr_tri*)tris, nf);
     for (int64_t i = 0; i < n; i++) {
         tr_ray r;
-        bool valid = tr_ray_setup(r, o[3 * i], o[3 * i + 1], o[3 * i + 2], d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+        bool valid = tr_ray_setup_q(r, v.frame, o[3 * i], o[3 * i + 1], o[3 * i + 2], d[3 * i], d[3 * i + 1], d[3 * i + 2]);
         tr_result res; tr_topk<8> top; tr_counters cnt;
         int32_t ring_mem[TR_RING];
         tr_ring ring = {g_use_ring ? ring_mem : nullptr, 1};

@@ -17,7 +17,7 @@ def lib():
         src = os.path.join(_HERE, "host_sim.cpp")
         hdr = os.path.join(_HERE, "..", "..", "trimesh-ray-optix_amd", "csrc")
         newest = max([os.path.getmtime(src)] + [os.path.getmtime(os.path.join(hdr, h))
-                                                for h in ("tr_math.h", "tr_bvh.h", "tr_lbvh.h")])
+                                                for h in ("tr_math.h", "tr_bvh.h", "tr_lbvh.h", "tr_wide.h")])
         if not os.path.exists(so) or os.path.getmtime(so) < newest:
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                                    "-mfma", "-Wno-unknown-pragmas", "-o", so, src])
@@ -39,6 +39,10 @@ def lib():
         L.sim_use_unordered.argtypes = [C.c_int]
         L.sim_steps.argtypes = [C.c_void_p] * 3 + [C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.sim_packet_stats.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+        L.sim_check_fused_wide.restype = C.c_int64
+        L.sim_check_fused_wide.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+        L.sim_check_fused.restype = C.c_int64
+        L.sim_check_fused.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -111,6 +115,25 @@ class SimBVH:
         lib().sim_steps(self.nodes.ctypes.data, self.links.ctypes.data, self.tris.ctypes.data, self.nf,
                         o.ctypes.data, d.ctypes.data, n, nv.ctypes.data, tt.ctypes.data)
         return nv, tt
+
+    def check_fused(self, o, d, node_stride=1):
+        """the fused box test of the grid nodes against the contract's on the same decoded boxes (sim_check_fused):
+        (violations, pairs checked, children accepted by the fused test, children accepted by the contract's)"""
+        o = np.ascontiguousarray(o, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)
+        out = np.zeros(3, np.int64)
+        bad = lib().sim_check_fused(self.qnodes.ctypes.data, len(self.qnodes), self.frame.ctypes.data, o.ctypes.data,
+                                    d.ctypes.data, len(o), node_stride, out.ctypes.data)
+        return int(bad), int(out[0]), int(out[1]), int(out[2])
+
+    def check_fused_wide(self, o, d, node_stride=1):
+        """the same for the 8-wide nodes derived from this hierarchy (sim_check_fused_wide)"""
+        o = np.ascontiguousarray(o, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)
+        out = np.zeros(3, np.int64)
+        bad = lib().sim_check_fused_wide(self.nodes.ctypes.data, len(self.nodes), self.frame.ctypes.data, o.ctypes.data,
+                                         d.ctypes.data, len(o), node_stride, out.ctypes.data)
+        return int(bad), int(out[0]), int(out[1]), int(out[2])
 
     def packet_stats(self, o, d, group=64):
         """per group of `group` consecutive rays: [lane-visits, slowest ray's visits, distinct nodes, leaf tests, busiest

@@ -119,6 +119,12 @@ def test_split_blocks_of_the_learned_order_match_the_oracle(device, split, split
                 assert np.array_equal(r.intersects_first(ot, dt).cpu().numpy().reshape(-1), exp[2])
                 assert np.array_equal(r.intersects_any(ot, dt).cpu().numpy().reshape(-1), cnt > 0)
                 assert np.array_equal(r.intersects_count(ot, dt).cpu().numpy().reshape(-1), cnt)
+                if rep >= 2 and name in ("image", "flat") and split > 0:
+                    # a flat batch with split slots never left the plain launch shape (no order, no split);
+                    # from the third launch on every stealing batch shape runs with its learned, split order
+                    r.intersects_closest(ot, dt)
+                    li = r.as_wrapper.last_launch()
+                    assert li["learned_order"] == 1 and li["split_blocks"] > 0, (name, rep, li)
             hops.set_option("steal", 16)        # count through the stealing shape, split as well
             for rep in range(3):
                 assert np.array_equal(r.intersects_count(ot, dt).cpu().numpy().reshape(-1), cnt)

@@ -182,3 +182,98 @@ def test_golden_cube_boundary():
     r = B.query(Q_CLOSEST, g["origins"], g["directions"])
     assert np.array_equal(r["hit"], g["hit"]) and np.array_equal(r["tri"], g["tri"])
     assert np.array_equal(B.query(Q_COUNT, g["origins"], g["directions"])["count"], g["count"])
+
+
+# ---- round 5: the fused conservative box test (tr_ray_fuse / tr_qnode_slabs) ----------------------------------
+def _nasty_rays(lo, hi, rng, n):
+    """rays that stress the margins of the fused form: far and near origins, origins ON grid planes and mesh
+    vertices, axis-aligned and nearly axis-aligned directions, huge / tiny direction components"""
+    ext = np.maximum(hi - lo, 1e-6)
+    c = (lo + hi) / 2
+    o = rng.uniform(-1, 1, (n, 3)) * ext * rng.choice([0.4, 1.0, 3.0, 50.0, 1e4], (n, 1)) + c
+    d = rng.normal(size=(n, 3))
+    k = rng.integers(0, 8, n)
+    ax = rng.integers(0, 3, n)
+    idx = np.arange(n)
+    z = (k == 0) | (k == 1)
+    d[idx[z], ax[z]] = 0.0                                   # parallel to a coordinate plane (reciprocal clamped)
+    z2 = k == 1
+    d[idx[z2], (ax[z2] + 1) % 3] = 0.0                       # axis-aligned
+    t = k == 2
+    d[idx[t], ax[t]] *= 1e-30                                # beyond kmax, not zero
+    t = k == 3
+    d[idx[t], ax[t]] *= 1e-12
+    t = k == 4
+    d[t] *= 1e20
+    t = k == 5
+    d[t] *= 1e-20
+    t = k == 6                                               # origin exactly on the box / in a bounding plane
+    o[idx[t], ax[t]] = np.where(rng.random(t.sum()) < 0.5, lo[ax[t]], hi[ax[t]])
+    return o.astype(np.float32), d.astype(np.float32)
+
+
+@pytest.mark.parametrize("case", ["sphere", "soup", "far_from_origin", "flat", "huge", "tiny"])
+def test_fused_box_test_contains_the_contracts(case):
+    rng = np.random.default_rng(7)
+    if case == "sphere":
+        v, f = W.icosphere(4); v = W.displaced(v, seed=3, amplitude=0.1)
+    elif case == "soup":
+        v, f = W.random_soup(3000, seed=5, size=0.2)
+    elif case == "far_from_origin":
+        v, f = W.icosphere(3); v = (v * np.float32(0.01) + np.float32([1000.0, -2000.0, 512.25])).astype(np.float32)
+    elif case == "flat":
+        v, f = W.icosphere(3); v = v.copy(); v[:, 2] = np.float32(0.25)          # a degenerate axis
+    elif case == "huge":
+        v, f = W.icosphere(3); v = (v * np.float32(3e12)).astype(np.float32)
+    else:
+        v, f = W.icosphere(3); v = (v * np.float32(1e-12) + np.float32(1e-9)).astype(np.float32)
+    B = SimBVH(v, f)
+    lo, hi = v.min(0).astype(np.float64), v.max(0).astype(np.float64)
+    o, d = _nasty_rays(lo, hi, rng, 4000)
+    # plus rays that start on mesh vertices and on decoded grid planes
+    qb = B.qchild_boxes().reshape(-1, 6)
+    pick = rng.integers(0, len(qb), 500)
+    o2 = np.where(rng.random((500, 3)) < 0.5, qb[pick, :3], qb[pick, 3:]).astype(np.float32)
+    d2 = rng.normal(size=(500, 3)).astype(np.float32)
+    d2[rng.random(500) < 0.3, 0] = 0.0
+    o = np.concatenate([o, o2, v[rng.integers(0, len(v), 500)]]); d = np.concatenate([d, d2, rng.normal(size=(500, 3)).astype(np.float32)])
+    bad, pairs, acc_fused, acc_contract = B.check_fused(o, d, node_stride=3)
+    assert pairs > 1_000_000
+    assert bad == 0
+    assert acc_fused >= acc_contract
+    badw, pairsw, fw, cw = B.check_fused_wide(o, d, node_stride=2)
+    assert pairsw > 300_000 and badw == 0 and fw >= cw
+    if case in ("sphere", "soup"):
+        # the price of one fma per plane on ordinary rays (a camera within three extents, aimed at the mesh): the fused
+        # test accepts well under one per cent more children than the contract's
+        ext = hi - lo
+        oo = ((lo + hi) / 2 + rng.normal(size=(3000, 3)) / np.linalg.norm(rng.normal(size=(3000, 3)), axis=1, keepdims=True) * 0 +
+              rng.uniform(-3, 3, (3000, 3)) * ext).astype(np.float32)
+        dd = ((lo + hi) / 2 + rng.uniform(-0.5, 0.5, (3000, 3)) * ext - oo).astype(np.float32)
+        bad2, pairs2, f2, c2 = B.check_fused(oo, dd, node_stride=1)
+        assert bad2 == 0 and f2 >= c2
+        assert f2 <= c2 * 1.005 + 10, (f2, c2)
+        bad3, _, f3, c3 = B.check_fused_wide(oo, dd, node_stride=1)
+        assert bad3 == 0 and c3 <= f3 <= c3 * 1.01 + 10, (f3, c3)
+
+
+def test_fused_box_test_keeps_results_on_axis_aligned_rays():
+    """orthographic rays along an axis onto an axis-aligned box whose faces lie in grid planes, with ray origins IN
+    the planes of the side faces: the clamped reciprocals and the 2^-100 pad of the contract, through the grid-node
+    flavours of the fused trip (64- and 32-bit state) and the unordered schedule"""
+    import sim
+    v, f = W._box((0.0, 0.0, 0.0), (1.0, 1.0, 0.5), 6)
+    v = v.astype(np.float32); f = f.astype(np.int32)
+    o, d = W.ortho_grid(49)                     # linspace(-1, 1, 49) contains -1, 0 and 1 exactly
+    o = np.ascontiguousarray(o).reshape(-1, 3); d = np.ascontiguousarray(d).reshape(-1, 3)
+    for mode in (5, 6):
+        sim.use_fused(mode)
+        try:
+            compare_all(v, f, o, d)
+        finally:
+            sim.use_fused(0)
+    sim.use_unordered(True)
+    try:
+        compare_all(v, f, o, d)
+    finally:
+        sim.use_unordered(False)

@@ -66,6 +66,29 @@ struct opt_store {
 };
 opt_store g_opts;
 
+// exact hash of the triangle arena (tr_bvh_replica_hash): per slot a 64-bit mix of its index and the words of its
+// record, summed (order-free: any reduction order gives the same value)
+__device__ __forceinline__ unsigned long long tr_mix64(unsigned long long x) {
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
+    x ^= x >> 27; x *= 0x94d049bb133111ebull;
+    return x ^ (x >> 31);
+}
+__global__ __launch_bounds__(256) void k_replica_hash(const uint32_t* __restrict__ words, int64_t num_tris,
+                                                      unsigned long long* __restrict__ out) {
+    constexpr int W = (int)(sizeof(tr_tri) / 4);
+    unsigned long long acc = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < num_tris; i += (int64_t)gridDim.x * 256) {
+        unsigned long long h = tr_mix64((unsigned long long)i + 0x9e3779b97f4a7c15ull);
+        const uint32_t* p = words + i * W;
+#pragma unroll
+        for (int k = 0; k < W; k++) h = tr_mix64(h ^ ((unsigned long long)p[k] + ((unsigned long long)(k + 1) << 32)));
+        acc += h;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+
 }  // namespace
 
 void tr_set_error(const std::string& msg) { g_last_error = msg; }
@@ -314,6 +337,38 @@ int tr_bvh_destroy(tr_bvh* bvh) {
     delete bvh->sched_mutex;
     delete bvh;
     return status;
+}
+
+int tr_bvh_replica_hash(const tr_bvh* bvh, uint64_t* h_hash, void* stream) {
+    if (!bvh || !h_hash) return tr_fail(TR_ERR_INVALID_ARG, "null argument");
+    tr_device_guard g;
+    if (g.enter(bvh->device) != TR_OK) return tr_fail(TR_ERR_NO_DEVICE, "hipSetDevice failed");
+    tr_device_state* st;
+    TR_TRY(tr_get_device_state(bvh->device, &st));
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long sum = 0;
+    if (bvh->num_tris > 0) {
+        unsigned long long* d_sum = nullptr;
+        TR_HIP_TRY(hipMalloc((void**)&d_sum, sizeof(unsigned long long)));
+        hipError_t e = hipMemsetAsync(d_sum, 0, sizeof(unsigned long long), s);
+        if (e == hipSuccess) {
+            int64_t blocks = (bvh->num_tris + 255) / 256;
+            if (blocks > (int64_t)st->num_cus * 8) blocks = (int64_t)st->num_cus * 8;
+            hipLaunchKernelGGL(k_replica_hash, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const uint32_t*>(bvh->tris),
+                               bvh->num_tris, d_sum);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(&sum, d_sum, sizeof sum, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        (void)hipFree(d_sum);
+        if (e != hipSuccess) return tr_fail(TR_ERR_HIP, std::string("replica hash: ") + hipGetErrorName(e));
+    }
+    // (host side of the same mix: the triangle count and the record size are part of the identity)
+    unsigned long long x = sum ^ ((unsigned long long)bvh->num_tris * 0x9e3779b97f4a7c15ull) ^ ((unsigned long long)sizeof(tr_tri) << 56);
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
+    x ^= x >> 27; x *= 0x94d049bb133111ebull;
+    *h_hash = x ^ (x >> 31);
+    return TR_OK;
 }
 
 int tr_bvh_last_launch(const tr_bvh* bvh, tr_launch_info* info) {

@@ -93,6 +93,69 @@ TR_HD void tr_qframe_make(const float* mn, const float* mx, tr_qframe* f) {
         f->scale[k] = s;
     }
 }
+// ---- fused conservative box test (round 5) --------------------------------------------------------------------
+// The grid nodes (and the 8-wide nodes, tr_wide.h) only have to be tested CONSERVATIVELY: the leaves are decided by
+// the full predicate (tr_tri_hit), whose own slab interval lies inside every ancestor's (monotone under box
+// inclusion).  The contract's form of a plane's distance is three roundings deep -- p = fma(q, scale, base),
+// (p - o), (..) * inv: a packed fma, a packed add and a packed multiply per pair of planes, 18 of the ~44 VALU
+// instructions of a node's box test.  Here the ray carries, per axis, A = scale * k and B = (base - o) * k -+ e, and a
+// plane costs ONE fma: t' = fma(q, A, B).  What makes that safe:
+//   * k = the contract's reciprocal, its magnitude clamped to kmax = the power of two with kmax * M <= 2^100, M = the
+//     position scale of the axis (|base|, |top|, |base - o|, twice the extent): every product stays finite, no
+//     inf - inf, no 0 * inf.  Only rays (numerically) parallel to a coordinate plane are clamped.
+//   * e >= the largest possible difference between t' and the contract's value for any plane of the mesh's box.
+//     With u = 2^-24, T = (p - o) inv exact, P = max |plane|, E = 65536 scale (>= the extent):
+//       contract:  p^ = fl(q s + b), d^ = fl(p^ - o), t^ = fl(d^ inv):   |t^ - T|        <= u |inv| (|p| + 2 |p - o|)
+//       fused:     bo = fl(b - o), b0 = fl(bo k), B = fl(b0 -+ e), t' = fl(q A + B):
+//                                                                        |t' - (T -+ e)| <= u |k| (|p - o| + 3 |b - o|) + 2 u e
+//       exit pad:  t^ * (1 + 2^-22), rounded:                            + 5 u |inv| |p - o|
+//     and |p - o| <= |b - o| + E:  e >= u |inv| (P + 11 |b - o| + 8 E) for the grid nodes; the 8-wide nodes decode in
+//     their own frame (planes up to one extent outside the mesh's box, base_n - o rounded per node):
+//     e >= u |inv| (P + 10 |b - o| + 19 E).  e = 1.25 u |k| (P + 11 |b - o| + 19 E) covers both.  Entry planes get
+//     -e, exit planes +e (sel_n / sel_f already separate them): t'_entry <= t_entry, t'_exit >= t_exit * TR_SLAB_PAD.
+//   * a clamped axis additionally gets -+ 1.0001e7 (> TR_TMAX): with |k| < |inv| the fused distance has the sign of
+//     the contract's and a smaller magnitude, so an exit plane behind the origin stays behind, one in front is pushed
+//     beyond TR_TMAX (it cannot cull), an entry plane in front stays smaller, one behind stays <= 0 -- all that
+//     tr_slab_hit(max(tn, 0) <= min(tf, limit <= TR_TMAX)) can see.
+//   * M beyond 1e30 (or not finite): the axis is ignored (A = 0, B = -+inf).
+// So: tn' <= max(tn, 0) and tf' >= min(tf, TR_TMAX) for the contract's (tn, tf) of the same decoded box -- the fused
+// test accepts whatever the contract's test accepts (tests/host_sim checks exactly this over the fuzz corpus), the
+// traversal visits a superset of nodes, the leaves decide: results are bit-identical.  In position units the margin
+// is ~1.3 float spacings of the coordinates plus 7e-7 of the camera distance: a few hundredths of a grid cell for a
+// camera within a few extents of a mesh near the origin.
+TR_HD void tr_fuse_axis(float o, float inv, float base, float scale, float& k, float& e, float& A, float& Bn, float& Bf) {
+    const float top = fmaf(65535.0f, scale, base);
+    const float bo = base - o;
+    const float M = fmaxf(fabsf(base), fabsf(top)) + fabsf(bo) + 131072.0f * scale;
+    const bool usable = M <= 1.0e30f;                             // (false for NaN, too)
+    const uint32_t be = (tr_f2u(M) >> 23) & 0xffu;               // M = m * 2^(be - 127), m in [1, 2)  (be = 0: M < 2^-126)
+    const uint32_t ke = 353u - be > 254u ? 254u : 353u - be;      // kmax = 2^(226 - be): kmax * M < 2^100
+    const float kmax = tr_u2f(ke << 23);
+    const bool clamped = fabsf(inv) > kmax;
+    const float kk = clamped ? copysignf(kmax, inv) : inv;
+    const float Me = fmaxf(fabsf(base), fabsf(top)) + 11.0f * fabsf(bo) + 1245184.0f * scale;             // P + 11 |b - o| + 19 E
+    const float ee = fabsf(kk) * Me * 7.450580596923828e-08f + (clamped ? 1.0001e7f : 0.0f) + 1.0e-37f;   // 1.25 * 2^-24
+    const float b0 = bo * kk;
+    // (selects, no branch: an early return here left the compiler with a stack object for the B pairs)
+    k = usable ? kk : 0.0f;
+    e = usable ? ee : INFINITY;
+    A = usable ? scale * kk : 0.0f;
+    Bn = usable ? b0 - ee : -INFINITY;
+    Bf = usable ? b0 + ee : INFINITY;
+}
+TR_HD void tr_ray_fuse(tr_ray& r, const tr_qframe& f) {
+    tr_fuse_axis(r.ox, r.ix, f.base[0], f.scale[0], r.kx, r.ex, r.qax, r.qnx, r.qfx);
+    tr_fuse_axis(r.oy, r.iy, f.base[1], f.scale[1], r.ky, r.ey, r.qay, r.qny, r.qfy);
+    tr_fuse_axis(r.oz, r.iz, f.base[2], f.scale[2], r.kz, r.ez, r.qaz, r.qnz, r.qfz);
+    r.qaz2 = r.qaz;
+}
+// ray set-up for the kernels that walk grid nodes / 8-wide nodes
+TR_HD bool tr_ray_setup_q(tr_ray& r, const tr_qframe& f, float ox, float oy, float oz, float dx, float dy, float dz) {
+    const bool valid = tr_ray_setup(r, ox, oy, oz, dx, dy, dz);
+    tr_ray_fuse(r, f);
+    return valid;
+}
+
 // largest grid plane <= lo / smallest grid plane >= hi, defined through the traversal's own decode
 // (monotone in q); lo >= base and hi <= decode(65535) by construction.  Closed-form estimate plus a
 // fix-up walk of a step or two (round 2 ran a 16-step binary search per plane: 12 searches per node
@@ -527,8 +590,8 @@ TR_HD void tr_leaf_step(const tr_bvh_view& b, const tr_ray& r, tr_state& st, tr_
 // Slab intervals of both children of a 32-byte grid node held in two 16-byte registers:
 // w0 = q[0..3], w1 = q[4], q[5], c0, c1.  Decode: plane = fma(q, scale, base) per 16-bit half; then
 // the contract's subtract and multiply per plane.  On the device both steps are packed FP32.
-TR_HD void tr_qnode_slabs(const tr_ray& r, const tr_qframe& f, const tr_i4& w0, const tr_i4& w1,
-                          float& tn0, float& tf0, float& tn1, float& tf1) {
+TR_HD void tr_qnode_slabs_contract(const tr_ray& r, const tr_qframe& f, const tr_i4& w0, const tr_i4& w1,
+                                   float& tn0, float& tf0, float& tn1, float& tf1) {
     const uint32_t q0 = (uint32_t)w0.x, q1 = (uint32_t)w0.y, q2 = (uint32_t)w0.z, q3 = (uint32_t)w0.w;
     const uint32_t q4 = (uint32_t)w1.x, q5 = (uint32_t)w1.y;
 #if defined(__HIP_DEVICE_COMPILE__) && TR_PK_SLAB && !defined(TR_QNOSIGN)
@@ -588,6 +651,61 @@ TR_HD void tr_qnode_slabs(const tr_ray& r, const tr_qframe& f, const tr_i4& w0, 
             tr_qdecode(q2 & 0xffffu, sx, bx), tr_qdecode(q2 >> 16, sy, by), tr_qdecode(q1 >> 16, sz, bz), tn0, tf0);
     tr_slab(r, tr_qdecode(q3 & 0xffffu, sx, bx), tr_qdecode(q3 >> 16, sy, by), tr_qdecode(q4 & 0xffffu, sz, bz),
             tr_qdecode(q5 & 0xffffu, sx, bx), tr_qdecode(q5 >> 16, sy, by), tr_qdecode(q4 >> 16, sz, bz), tn1, tf1);
+#endif
+}
+
+// The fused form (tr_ray_fuse): per child three v_perm_b32 (entry / exit planes of this ray), six conversions, THREE
+// packed fma, one max3, one min3 -- 14 instead of 22 instructions; no pad multiply (the margin e is in B).  Host and
+// device evaluate the same fma per plane: identical (tn, tf), so tests/host_sim walks the very path the kernels walk.
+#ifndef TR_QFUSE
+#define TR_QFUSE 1      // 0: the contract's three-step form (A/B builds)
+#endif
+TR_HD void tr_qnode_slabs(const tr_ray& r, const tr_qframe& f, const tr_i4& w0, const tr_i4& w1,
+                          float& tn0, float& tf0, float& tn1, float& tf1) {
+#if !TR_QFUSE
+    tr_qnode_slabs_contract(r, f, w0, w1, tn0, tf0, tn1, tf1);
+#elif defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t q0 = (uint32_t)w0.x, q1 = (uint32_t)w0.y, q2 = (uint32_t)w0.z, q3 = (uint32_t)w0.w;
+    const uint32_t q4 = (uint32_t)w1.x, q5 = (uint32_t)w1.y;
+    typedef float tr_v2 __attribute__((ext_vector_type(2)));
+    const tr_v2 axy = {r.qax, r.qay}, azz = {r.qaz, r.qaz2};
+    const tr_v2 nxy = {r.qnx, r.qny}, fxy = {r.qfx, r.qfy}, bz = {r.qnz, r.qfz};
+#define TR_UNPK(w) tr_v2{(float)((w) & 0xffffu), (float)((w) >> 16)}
+    {
+        const uint32_t pn = __builtin_amdgcn_perm(q2, q0, r.sel_n), pf = __builtin_amdgcn_perm(q2, q0, r.sel_f);
+        const uint32_t zz = __builtin_amdgcn_perm(q1, q1, r.sel_z);      // (entry z | exit z << 16)
+        const tr_v2 a = __builtin_elementwise_fma(TR_UNPK(pn), axy, nxy);
+        const tr_v2 c = __builtin_elementwise_fma(TR_UNPK(pf), axy, fxy);
+        const tr_v2 b = __builtin_elementwise_fma(TR_UNPK(zz), azz, bz);
+        tn0 = fmaxf(fmaxf(a.x, a.y), b.x);
+        tf0 = fminf(fminf(c.x, c.y), b.y);
+    }
+    {
+        const uint32_t pn = __builtin_amdgcn_perm(q5, q3, r.sel_n), pf = __builtin_amdgcn_perm(q5, q3, r.sel_f);
+        const uint32_t zz = __builtin_amdgcn_perm(q4, q4, r.sel_z);
+        const tr_v2 a = __builtin_elementwise_fma(TR_UNPK(pn), axy, nxy);
+        const tr_v2 c = __builtin_elementwise_fma(TR_UNPK(pf), axy, fxy);
+        const tr_v2 b = __builtin_elementwise_fma(TR_UNPK(zz), azz, bz);
+        tn1 = fmaxf(fmaxf(a.x, a.y), b.x);
+        tf1 = fminf(fminf(c.x, c.y), b.y);
+    }
+#undef TR_UNPK
+#else
+    (void)f;
+    const bool nx = r.ix < 0.f, ny = r.iy < 0.f, nz = r.iz < 0.f;      // as sel_n / sel_f / sel_z (tr_ray_setup)
+    const uint32_t q[6] = {(uint32_t)w0.x, (uint32_t)w0.y, (uint32_t)w0.z, (uint32_t)w0.w, (uint32_t)w1.x, (uint32_t)w1.y};
+    float tn[2], tf[2];
+    for (int c = 0; c < 2; c++) {
+        const uint32_t lox = q[3 * c] & 0xffffu, loy = q[3 * c] >> 16, loz = q[3 * c + 1] & 0xffffu;
+        const uint32_t hiz = q[3 * c + 1] >> 16, hix = q[3 * c + 2] & 0xffffu, hiy = q[3 * c + 2] >> 16;
+        const float ax = fmaf((float)(nx ? hix : lox), r.qax, r.qnx), ay = fmaf((float)(ny ? hiy : loy), r.qay, r.qny);
+        const float az = fmaf((float)(nz ? hiz : loz), r.qaz, r.qnz);
+        const float cx = fmaf((float)(nx ? lox : hix), r.qax, r.qfx), cy = fmaf((float)(ny ? loy : hiy), r.qay, r.qfy);
+        const float cz = fmaf((float)(nz ? loz : hiz), r.qaz, r.qfz);
+        tn[c] = fmaxf(fmaxf(ax, ay), az);
+        tf[c] = fminf(fminf(cx, cy), cz);
+    }
+    tn0 = tn[0]; tf0 = tf[0]; tn1 = tn[1]; tf1 = tf[1];
 #endif
 }
 

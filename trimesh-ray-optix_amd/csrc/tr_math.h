@@ -46,6 +46,19 @@ struct tr_ray {
     // byte selectors (v_perm_b32) that pick, from a grid node's 16-bit plane pairs, the planes this ray ENTERS a box
     // through (lo where its direction is positive, hi where negative) and the ones it leaves through (tr_qnode_slabs)
     uint32_t sel_n, sel_f, sel_z;
+    // Round 5: constants of the FUSED conservative box test of the grid nodes and the 8-wide nodes (tr_ray_fuse,
+    // tr_bvh.h): t(plane q) = fma(q, qa, qn | qf) -- one fused multiply-add per plane instead of decode, subtract,
+    // multiply.  (kx.., ex..: the per-axis reciprocal clamped so that every product stays finite, and the outward
+    // margin that covers the rounding differences to the contract's three-step form: what a node with its own frame
+    // -- the 8-wide nodes -- folds into its A / B.)  Only read by the kernels that walk those nodes.
+    // (field order = the register pairs of the packed fma: (ax, ay) (nx, ny) (fx, fy) (nz, fz))
+    float qax, qay;           // A  = scale * k
+    float qnx, qny;           // B of the planes the ray ENTERS a box through:  (base - o) * k - e
+    float qfx, qfy;           // B of the planes it leaves through:             (base - o) * k + e
+    float qnz, qfz;
+    float qaz, qaz2;          // (A of z twice: a register pair of its own)
+    float kx, ky, kz;
+    float ex, ey, ez;
 };
 
 TR_HD uint32_t tr_f2u(float f) { union { float f; uint32_t u; } c; c.f = f; return c.u; }

@@ -65,6 +65,16 @@ TR_HD uint32_t tr_wceil(float x, float scale, float base) {
     return a;
 }
 
+// The fused conservative box test (tr_ray_fuse, tr_bvh.h) for a node with its own frame: per visit and axis
+// A = scale_n * k, B = (base_n - o) * k -+ e (the ray's margin e covers every plane of every node: tr_fuse_axis),
+// then ONE fma per plane: t' = fma(q, A, B).  Shared by the kernel (traverse_wide.inc) and tests/host_sim.
+TR_HD void tr_wfuse_axis(float base_n, float scale_n, float o, float k, float e, float& A, float& Bn, float& Bf) {
+    A = scale_n * k;
+    const float t0 = base_n - o;
+    Bn = fmaf(t0, k, -e);
+    Bf = fmaf(t0, k, e);
+}
+
 // the exits of the wide node rooted at binary node r, in left-to-right (Morton) order: box (lo[3], hi[3]) and
 // binary child id (>= 0: internal node = root of the next wide node, < 0: leaf).  Returns their number (2..8).
 struct tr_wexit {

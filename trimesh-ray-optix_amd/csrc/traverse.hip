@@ -394,6 +394,12 @@ __device__ __forceinline__ bool wave_traverse_steal(const tr_bvh_view& b, tr_ray
                 r.dx = __shfl(r.dx, src); r.dy = __shfl(r.dy, src); r.dz = __shfl(r.dz, src);
                 r.ix = __shfl(r.ix, src); r.iy = __shfl(r.iy, src); r.iz = __shfl(r.iz, src);
                 r.sel_n = (uint32_t)__shfl((int)r.sel_n, src); r.sel_f = (uint32_t)__shfl((int)r.sel_f, src); r.sel_z = (uint32_t)__shfl((int)r.sel_z, src);
+                if constexpr (QN) {      // the fused box-test constants of the grid nodes (tr_ray_fuse)
+                    r.qax = __shfl(r.qax, src); r.qay = __shfl(r.qay, src); r.qaz = __shfl(r.qaz, src);
+                    r.qnx = __shfl(r.qnx, src); r.qny = __shfl(r.qny, src); r.qnz = __shfl(r.qnz, src);
+                    r.qfx = __shfl(r.qfx, src); r.qfy = __shfl(r.qfy, src); r.qfz = __shfl(r.qfz, src);
+                    r.qaz2 = r.qaz;
+                }
                 const int own2 = __shfl(owner, src);
                 const float bt = __shfl(res.best_t, src);
                 const int n2 = SLIM ? __shfl(gnode, src) : 0, d2 = SLIM ? __shfl(gdepth, src) : 0;
@@ -473,7 +479,7 @@ __device__ __forceinline__ void process_ray_steal(const tr_bvh_view& b, const Ra
     float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
     if (in_range) fetch_ray(rf, i, o, d);
     tr_ray r;
-    const bool valid = tr_ray_setup(r, o[0], o[1], o[2], d[0], d[1], d[2]) && in_range;
+    const bool valid = tr_ray_setup_q(r, b.frame, o[0], o[1], o[2], d[0], d[1], d[2]) && in_range;
     tr_result res;
     bool split = false;
     if (b.num_tris >= 2) split = wave_traverse_steal<Q, STATS, COMPACT, DEEP, QN, LT, SLIM>(b, r, valid, res, cnt, ring, wl, (int)(threadIdx.x & 63), steal_min, toplds);
@@ -614,6 +620,10 @@ __device__ __forceinline__ int wave_count_unordered_steal(const tr_bvh_view& b, 
         r.dx = __shfl(r.dx, src); r.dy = __shfl(r.dy, src); r.dz = __shfl(r.dz, src);
         r.ix = __shfl(r.ix, src); r.iy = __shfl(r.iy, src); r.iz = __shfl(r.iz, src);
         r.sel_n = (uint32_t)__shfl((int)r.sel_n, src); r.sel_f = (uint32_t)__shfl((int)r.sel_f, src); r.sel_z = (uint32_t)__shfl((int)r.sel_z, src);
+        r.qax = __shfl(r.qax, src); r.qay = __shfl(r.qay, src); r.qaz = __shfl(r.qaz, src);      // (tr_ray_fuse)
+        r.qnx = __shfl(r.qnx, src); r.qny = __shfl(r.qny, src); r.qnz = __shfl(r.qnz, src);
+        r.qfx = __shfl(r.qfx, src); r.qfy = __shfl(r.qfy, src); r.qfz = __shfl(r.qfz, src);
+        r.qaz2 = r.qaz;
         const int own2 = __shfl(owner, src), n2 = __shfl(gnode, src), d2 = __shfl(gdepth, src);
         if (take) {
             owner = own2;
@@ -636,7 +646,7 @@ __device__ __forceinline__ void process_ray_unordered(const tr_bvh_view& b, cons
     float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
     if (in_range) fetch_ray(rf, i, o, d);
     tr_ray r;
-    const bool valid = tr_ray_setup(r, o[0], o[1], o[2], d[0], d[1], d[2]) && in_range;
+    const bool valid = tr_ray_setup_q(r, b.frame, o[0], o[1], o[2], d[0], d[1], d[2]) && in_range;
     tr_result res;
     if (Q == TR_Q_LOCATION) {
         tr_topk<0> top;
@@ -774,7 +784,7 @@ __device__ __forceinline__ void query_direct_body(const tr_bvh_view& b, const Ra
         float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
         if (in_range) fetch_ray(rf, i, o, d);
         tr_ray r;
-        const bool valid = tr_ray_setup(r, o[0], o[1], o[2], d[0], d[1], d[2]) && in_range;
+        const bool valid = tr_ray_setup_q(r, b.frame, o[0], o[1], o[2], d[0], d[1], d[2]) && in_range;
         tr_result res;
         if constexpr (Q == TR_Q_LOCATION) {
             tr_topk<0> top;
@@ -848,8 +858,13 @@ __device__ __forceinline__ void query_direct_body(const tr_bvh_view& b, const Ra
 
 // MODE: 0 fused ordered trip, 1 fused trip + intra-wave work stealing, 2 unordered two-phase schedule,
 // 3 unordered + stealing (query_direct_body)
+#ifdef TR_DIRECT_WAVES
+#define TR_DIRECT_OCC __attribute__((amdgpu_waves_per_eu(TR_DIRECT_WAVES, TR_DIRECT_WAVES)))
+#else
+#define TR_DIRECT_OCC
+#endif
 template <int Q, bool STATS, bool COMPACT, int BS, int MODE = 0, bool DEEP = false, bool QN = false, bool LT = false>
-__global__ __launch_bounds__(BS) void k_query_direct(tr_bvh_view b, RayFetch rf, QueryOut out,
+__global__ __launch_bounds__(BS) TR_DIRECT_OCC void k_query_direct(tr_bvh_view b, RayFetch rf, QueryOut out,
                                                       int xcd_map, int scramble, int tile_w, int steal_min,
                                                       const uint32_t* __restrict__ order, int order_split,
                                                       uint32_t* __restrict__ cost,
@@ -1156,7 +1171,7 @@ __device__ __forceinline__ void query_stream_body(const tr_bvh_view& b, const Ra
     tr_topk<1> top;
     tr_state_init(fs);
     tr_result_init(res);
-    tr_ray_setup(r, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f);
+    tr_ray_setup_q(r, b.frame, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f);
     for (;;) {
         if (!exhausted && next >= end) {
             unsigned long long base = 0;
@@ -1183,7 +1198,7 @@ __device__ __forceinline__ void query_stream_body(const tr_bvh_view& b, const Ra
                     rid = cand;
                     float o[3], d[3];
                     fetch_ray(rf, cand, o, d);
-                    const bool valid = tr_ray_setup(r, o[0], o[1], o[2], d[0], d[1], d[2]);
+                    const bool valid = tr_ray_setup_q(r, b.frame, o[0], o[1], o[2], d[0], d[1], d[2]);
                     tr_state_init(fs);
                     tr_result_init(res);
                     if (b.num_tris >= 2) busy = valid;
@@ -1235,8 +1250,13 @@ __device__ __forceinline__ void query_stream_body(const tr_bvh_view& b, const Ra
 // (Round 3 ran the compact instantiations at 8 waves per SIMD, 64 registers: -2...-7 %.  Round 4's sign-selected slab
 // test needs three registers more and is worth about as much on these fabric-bound launches -- C3 any -1.7 %, C5(ii)
 // shard -1 %, count +1.5 % at 7 waves: profiles/r04_ab_qsign.txt -- so every instantiation keeps the compiler's budget.)
+#ifdef TR_STREAM_WAVES
+#define TR_STREAM_OCC __attribute__((amdgpu_waves_per_eu(TR_STREAM_WAVES, TR_STREAM_WAVES)))
+#else
+#define TR_STREAM_OCC
+#endif
 template <int Q, bool STATS, bool COMPACT, int BS, bool DEEP = false>
-__global__ __launch_bounds__(BS) void k_query_stream(tr_bvh_view b, RayFetch rf, QueryOut out,
+__global__ __launch_bounds__(BS) TR_STREAM_OCC void k_query_stream(tr_bvh_view b, RayFetch rf, QueryOut out,
                                                      int rays_per_wave, int refill_min, int xcd_map,
                                                      unsigned long long* stats, const int* __restrict__ sel,
                                                      unsigned long long* work) {
@@ -2021,15 +2041,21 @@ bool sched_acquire(const tr_bvh* bvh, const tr_options& opt, hipStream_t stream,
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         const bool capturing = hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
         if (capturing) (void)hipGetLastError();
-        // the costs of the last sort can be resampled when both shapes are images and nothing is being captured
-        const bool lend = opt.order_transfer && slot->prev_valid && slot->prev_w > 0 && want.w > 0 && !capturing;
-        // second launch of this batch shape (the first ran `plain` and its costs are the ones kept): on to `want`;
-        // anything else -- a fresh slot, another resolution -- starts in `plain`
-        const bool second = lend && !same_shape && matches(plain) && slot->prev_nblocks == nblocks && slot->prev_w == want.w &&
-                            slot->prev_h == want.h && slot->prev_lgh == plain.lgh;
+        // Second launch of this batch shape (the first ran `plain`, the slot is stamped with it): on to `want`; anything
+        // else -- a fresh slot, another resolution -- starts in `plain`.  (Round 4 made this step depend on `lend` below:
+        // a batch that is not image-shaped -- a flat [n, 3] batch with split slots -- or a launch issued under stream
+        // capture never left the plain shape, never got an order and re-measured behind every launch: ADVICE r04.)
+        const bool second = !same_shape && matches(plain);
         use = (second || same_shape) ? &want : &plain;
+        const bool can_sort = opt.order_transfer && slot->prev_valid && !capturing;
+        // the costs of the last sort can be resampled when both shapes are images and nothing is being captured
+        const bool lend = can_sort && slot->prev_w > 0 && want.w > 0;
+        // ... and taken as they are when the wanted shape has the very blocks they were measured on: the second launch
+        // of a batch whose plain and wanted shapes share the block -> ray map (a flat batch: only the split slots differ)
+        const bool reuse = can_sort && !lend && second && slot->prev_nblocks == nblocks && slot->prev_w == want.w &&
+                           slot->prev_h == want.h && slot->prev_lgh == want.lgh;
+        uint32_t* prev = slot->buf + TR_SCHED_PREV;
         if (lend) {
-            uint32_t* prev = slot->buf + TR_SCHED_PREV;
             hipLaunchKernelGGL(k_sched_rescale, dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, stream, prev, slot->prev_nblocks,
                                slot->prev_w, slot->prev_h, slot->prev_lgh, slot->buf, nblocks, use->w, use->h, use->lgh);
             // borrowed costs only ORDER the launch: no block is split on their word (outlier threshold out of reach: the
@@ -2040,6 +2066,15 @@ bool sched_acquire(const tr_bvh* bvh, const tr_options& opt, hipStream_t stream,
             hipLaunchKernelGGL(k_sched_sort, dim3(1), dim3(1024), 0, stream, slot->buf, slot->buf + TR_SCHED_MAX, (int)nblocks, use->xc,
                                (int)use->split, (int)use->split4, 1 << 20, use->floor_ticks, (const int*)nullptr, (uint32_t*)nullptr);
             if (hipGetLastError() == hipSuccess) *order = slot->buf + TR_SCHED_MAX;
+        } else if (reuse) {
+            // measured on these blocks, nothing split, nothing resampled: they order the launch AND pick its split set
+            if (hipMemcpyAsync(slot->buf, prev, sizeof(uint32_t) * (size_t)nblocks, hipMemcpyDeviceToDevice, stream) == hipSuccess) {
+                hipLaunchKernelGGL(k_sched_sort, dim3(1), dim3(1024), 0, stream, slot->buf, slot->buf + TR_SCHED_MAX, (int)nblocks, use->xc,
+                                   (int)use->split, (int)use->split4, use->outlier8, use->floor_ticks, (const int*)nullptr, (uint32_t*)nullptr);
+                if (hipGetLastError() == hipSuccess) *order = slot->buf + TR_SCHED_MAX;
+            } else {
+                (void)hipGetLastError();
+            }
         }
         slot->prev_valid = false;      // (the costs kept are used up; the sort behind this launch keeps new ones)
     }

@@ -30,7 +30,7 @@ MAX_ANYHIT_SIZE = 8   # LaunchParams.h:8
 MAX_SIZE_LENGTH = 4   # LaunchParams.h:9
 
 _LIB_NAME = "libtriro_hip.so"
-ABI_VERSION = 8     # TR_ABI_VERSION of include/triro_hip.h this binding was written against
+ABI_VERSION = 9     # TR_ABI_VERSION of include/triro_hip.h this binding was written against
 _lib = None
 _lib_error = None
 
@@ -83,6 +83,7 @@ ABI = {
     "tr_bvh_deserialize": (_int, [_vp, _i64, _vp, C.POINTER(_vp)]),
     "tr_bvh_get_info": (_int, [_vp, C.POINTER(TrBvhInfo)]),
     "tr_bvh_last_launch": (_int, [_vp, C.POINTER(TrLaunchInfo)]),
+    "tr_bvh_replica_hash": (_int, [_vp, C.POINTER(C.c_uint64), _vp]),
     "tr_bvh_download": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "tr_bvh_download_qnodes": (_int, [_vp, _vp, _vp, _vp]),
     "tr_intersects_any": (_int, [_vp, C.POINTER(TrRays), _vp, _vp]),
