@@ -114,6 +114,10 @@ def parse(argv=None):
     ap.add_argument("--arrival", choices=["copy", "none"], default="copy",
                     help="--emulate-world: how the peers' records arrive: device copies on a copy stream (pessimistic: blit "
                          "kernels) or not at all (they are simply there: expansion cost only)")
+    ap.add_argument("--exchange", choices=["slot", "packed", "dense", "padded", "staged"], default=None,
+                    help="N > 1: the rung of the exchange ladder to start from (default: slot, or packed with --records packed); the "
+                         "preflight steps down from there (triro.ray.sharded.LADDER)")
+    ap.add_argument("--no-preflight", action="store_true", help="N > 1: skip the checked small batch in front of the run")
     ap.add_argument("--stub", default=None, help="module:factory of a stand-in tracer (only with --backend gloo; tests)")
     return ap.parse_args(argv)
 
@@ -216,6 +220,44 @@ def cpu_baseline(v, f, o, d, budget_s=20.0):
     return res
 
 
+# ---- the parity error bar (static: measured by scripts/watertight_bound.py, kept under profiles/) ---------------
+def parity_error_bars():
+    """How far the contract's answers can be from a watertight reference (OptiX's built-in triangle test is closed and
+    nothing of the reference runs here: parity is UNPINNED at the bit level).  Per BASELINE config: the
+    fraction of rays whose hit mask / triangle index / hit count differ from a float64 Woop-Benthin-Wald test on the same
+    float32 inputs, and the largest relative distance difference on the same triangle (profiles/r0x_watertight_bound.jsonl;
+    the GPU outputs are the contract's bit for bit: tests/test_watertight.py)."""
+    out = {"pinned_bit_exact_against_reference": False,
+           "note": "bit-exact against the CPU oracle (every BASELINE config, full size, incl. loc / uv); against a float64 "
+                   "watertight ray / triangle test the rates below; the reference's own arithmetic (OptiX) is closed and "
+                   "unbuildable here", "configs": {}}
+    for name in ("r05_watertight_bound.jsonl", "r04_watertight_bound.jsonl"):
+        p = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(p):
+            continue
+        try:
+            for ln in open(p):
+                ln = ln.strip()
+                if not ln.startswith("{"):
+                    continue
+                j = json.loads(ln)
+                n = max(int(j.get("rays", 0)), 1)
+                key = j.get("config") or j.get("name")
+                if not key or key in out["configs"]:
+                    continue
+                out["configs"][key] = {
+                    "rays": int(j.get("rays", 0)),
+                    "hit_mask_rate": round((j.get("only_contract", 0) + j.get("only_watertight", 0)) / n, 9),
+                    "tri_idx_rate": round((j.get("tri_diff_same_t", 0) + j.get("tri_diff_other", 0)) / n, 9),
+                    "count_rate": round(j.get("count_diff", 0) / n, 9),
+                    "max_rel_t_diff_same_tri": j.get("max_rel_t_diff_same_tri")}
+            out["source"] = "profiles/" + name
+        except Exception as exc:      # noqa: BLE001
+            out["error"] = str(exc)
+        break
+    return out
+
+
 # ---- one rank --------------------------------------------------------------------------------
 def rotate_y(x, deg):
     import numpy as np
@@ -242,11 +284,98 @@ def stacked_rows(img, world_rows, a, z, roll=7):
     return np.concatenate(parts, axis=0) if parts else img[:0]
 
 
+def build_workload(args, world, rank, dev, v, rad, share, workload, scaling, res, total_rays):
+    """The rays of one benchmark configuration as THIS rank holds them: its shard of the job (`origins`, `dirs`), the
+    bounds of everybody's shard, the shape of the gathered batch, and -- on request, for rank 0 -- the rays of the whole
+    batch (`all_rays()`: what the caller of the reference's API holds, and what 4-byte records are finished from).
+    workload c5i: scaling 'weak' = `world` batches of res x res rays stacked ([world * res, res], cut into row bands),
+    'strong' = ONE res x res batch in `world` row bands; workload c5ii: ONE batch of total_rays hash rays."""
+    import numpy as np
+    import torch
+    import workloads as W
+    from triro.ray.sharded import shard_bounds, dst_bounds
+    pinhole = args.rays == "pinhole" and workload == "c5i"
+    strong_c5i = workload == "c5i" and scaling == "strong" and world > 1
+    wl = {"workload": workload, "scaling": "strong" if (strong_c5i or workload == "c5ii") else "weak", "res": res,
+          "strong_c5i": strong_c5i, "pinhole": pinhole, "o_np": None, "d_np": None, "bshape": None, "row_quantum": None}
+
+    def split_batch(n_rays, quantum):
+        if share is not None and share < 1.0 and world > 1:
+            return dst_bounds(n_rays, world, 0, share, quantum)
+        return [shard_bounds(n_rays, world, k) for k in range(world)]
+
+    def hash_rays(a, z):
+        lo, hi = v.min(0) * 1.5, v.max(0) * 1.5
+        parts_o, parts_d = [], []
+        for s in range(a, z, 1 << 23):                       # bounded temporaries
+            po, pd = W.hash_rays_torch(min(1 << 23, z - s), 99, lo, hi, start=s, device=dev)
+            parts_o.append(po)
+            parts_d.append(pd)
+        if not parts_o:
+            return torch.zeros((0, 3), device=dev), torch.zeros((0, 3), device=dev)
+        return (parts_o[0], parts_d[0]) if len(parts_o) == 1 else (torch.cat(parts_o), torch.cat(parts_d))
+
+    if workload == "c5i":
+        n_total = res * res * (1 if strong_c5i else world)
+        bounds_all = split_batch(n_total, res if pinhole else 1)
+        lo_ray, hi_ray = bounds_all[rank]
+        if pinhole:
+            o_img, d_img = W.pinhole_grid(res, res, distance=2.5 * rad)
+            o_full = np.broadcast_to(o_img, d_img.shape)
+            rows_ok = all(a % res == 0 and z % res == 0 for a, z in bounds_all)       # every rank decides alike
+            if strong_c5i:
+                wl["bshape"] = (res, res)
+                if rows_ok and hi_ray > lo_ray:
+                    o_np, d_np = o_full[lo_ray // res:hi_ray // res], d_img[lo_ray // res:hi_ray // res]
+                else:
+                    o_np, d_np = o_full.reshape(-1, 3)[lo_ray:hi_ray], d_img.reshape(-1, 3)[lo_ray:hi_ray]
+            else:
+                # weak: image k of the stack = the same camera, rolled by k x 7 rows, so that the shards differ
+                wl["bshape"] = (world * res, res)
+                if rows_ok:
+                    d_np = stacked_rows(d_img, world, lo_ray // res, hi_ray // res)
+                    o_np = stacked_rows(o_full, world, lo_ray // res, hi_ray // res, roll=0)
+                else:
+                    d_np = stacked_rows(d_img, world, 0, world * res).reshape(-1, 3)[lo_ray:hi_ray]
+                    o_np = stacked_rows(o_full, world, 0, world * res, roll=0).reshape(-1, 3)[lo_ray:hi_ray]
+            origins = torch.from_numpy(np.ascontiguousarray(o_np)).to(dev)
+            dirs = torch.from_numpy(np.ascontiguousarray(d_np)).to(dev)
+            wl["o_np"], wl["d_np"] = o_np, d_np
+            if rows_ok:
+                wl["row_quantum"] = res
+
+            def all_rays():
+                if strong_c5i:
+                    ao, ad = o_full, d_img
+                else:
+                    ao = stacked_rows(o_full, world, 0, world * res, roll=0)
+                    ad = stacked_rows(d_img, world, 0, world * res)
+                t = (torch.from_numpy(np.ascontiguousarray(ao)).to(dev), torch.from_numpy(np.ascontiguousarray(ad)).to(dev))
+                return t if rows_ok else (t[0].reshape(-1, 3), t[1].reshape(-1, 3))
+        else:
+            wl["bshape"] = (n_total,)
+            origins, dirs = hash_rays(lo_ray, hi_ray)
+
+            def all_rays():
+                return hash_rays(0, n_total)
+    else:
+        n_total = total_rays
+        bounds_all = split_batch(n_total, 1)
+        lo_ray, hi_ray = bounds_all[rank]
+        wl["bshape"] = (n_total,)
+        origins, dirs = hash_rays(lo_ray, hi_ray)
+
+        def all_rays():
+            return hash_rays(0, n_total)
+    wl.update(origins=origins, dirs=dirs, n=hi_ray - lo_ray, n_total=n_total, bounds_all=bounds_all, all_rays=all_rays)
+    return wl
+
+
 def run_rank(args):
     import numpy as np
     import torch
     import workloads as W
-    from triro.ray.sharded import ShardedRayMeshIntersector, shard_bounds, dst_bounds
+    from triro.ray.sharded import ShardedRayMeshIntersector, LADDER
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -266,16 +395,27 @@ def run_rank(args):
         torch.cuda.set_device(local_dev)
         dev = torch.device("cuda", local_dev)
     dist = None
+    ctrl = None
     if dist_on:
+        import datetime
         import torch.distributed as dist
         if gloo:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            # (a collective that never completes ends the run after ten minutes instead of never)
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=10))
         world = dist.get_world_size()          # the ranks the communicator actually has
         if world != args.gpus:
             print(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks; reporting n_gpus={world}",
                   file=sys.stderr)
+        # a gloo CONTROL group beside the RCCL communicator: verdicts of the preflight travel on it (they must not
+        # depend on the transport under test), and on the last rung of the exchange ladder the results themselves
+        if not gloo and (world > 1 or args.force_gather):
+            try:
+                ctrl = dist.new_group(backend="gloo", timeout=datetime.timedelta(minutes=10))
+            except Exception as exc:      # noqa: BLE001
+                print(f"bench.py: no gloo control group ({exc}); the preflight's verdicts use the RCCL communicator", file=sys.stderr)
+                ctrl = None
     elif args.gpus != 1:
         raise SystemExit("internal error: run_rank with --gpus > 1 outside a launcher")
 
@@ -298,73 +438,12 @@ def run_rank(args):
     # ---- workload (synthetic, deterministic) -------------------------------------------------
     v, f = W.headline_mesh(args.subdiv)
     rad = float(np.linalg.norm(v, axis=1).max())
-    o_np = d_np = None
-    strong_c5i = args.workload == "c5i" and args.scaling == "strong" and world > 1
-    bshape = None                      # shape of the gathered batch on rank 0
-    # strong scaling: with --dst-share rank 0 (the destination of the gather, which also expands everybody
-    # else's records) takes a smaller shard
+    # with --dst-share rank 0 (the destination of the gather, which also finishes everybody else's rays) takes a smaller shard
     share = resolve_share(args, world)
-
-    def split_batch(n_rays, quantum):
-        if share is not None and share < 1.0 and world > 1:
-            return dst_bounds(n_rays, world, 0, share, quantum)
-        return [shard_bounds(n_rays, world, k) for k in range(world)]
-    row_quantum = None
-    if strong_c5i:
-        # ONE res x res batch, rank r traces its band of rows (whole rows, so the band keeps the image
-        # launch shapes) -- or its flat range when the rows do not divide
-        n_total = args.res * args.res
-        bounds_all = split_batch(n_total, args.res if args.rays == "pinhole" else 1)
-        lo_ray, hi_ray = bounds_all[rank]
-        n = hi_ray - lo_ray
-        bshape = (args.res, args.res)
-        if args.rays == "pinhole":
-            o_np, d_np = W.pinhole_grid(args.res, args.res, distance=2.5 * rad)
-            rows_ok = all(a % args.res == 0 and z % args.res == 0 for a, z in bounds_all)   # every rank decides alike
-            if rows_ok and hi_ray > lo_ray:
-                o_np, d_np = o_np[lo_ray // args.res:hi_ray // args.res], d_np[lo_ray // args.res:hi_ray // args.res]
-            else:
-                o_np, d_np = o_np.reshape(-1, 3)[lo_ray:hi_ray], d_np.reshape(-1, 3)[lo_ray:hi_ray]
-            origins = torch.from_numpy(np.ascontiguousarray(o_np)).to(dev)
-            dirs = torch.from_numpy(np.ascontiguousarray(d_np)).to(dev)
-        else:
-            lo, hi = v.min(0) * 1.5, v.max(0) * 1.5
-            origins, dirs = W.hash_rays_torch(n, 99, lo, hi, start=lo_ray, device=dev)
-    elif args.workload == "c5i":
-        # weak scaling: the job is `world` batches of res x res rays (stacked: [world * res, res]); with even
-        # shards every rank traces one of them, with --dst-share the destination rank takes fewer ROWS of the
-        # stack and the others more (same total, cut at whole rows)
-        n_total = args.res * args.res * world
-        bounds_all = split_batch(n_total, args.res if args.rays == "pinhole" else 1)
-        lo_ray, hi_ray = bounds_all[rank]
-        n = hi_ray - lo_ray
-        bshape = (world * args.res, args.res) if args.rays == "pinhole" else (n_total,)
-        if args.rays == "pinhole":
-            o_np, d_np = W.pinhole_grid(args.res, args.res, distance=2.5 * rad)
-            # image k of the stack: same camera, rolled by k rows x 7 so shards differ
-            d_np = stacked_rows(d_np, world, lo_ray // args.res, hi_ray // args.res)
-            o_np = stacked_rows(np.broadcast_to(o_np, (args.res, args.res, 3)), world, lo_ray // args.res, hi_ray // args.res, roll=0)
-            origins = torch.from_numpy(np.ascontiguousarray(o_np)).to(dev)
-            dirs = torch.from_numpy(np.ascontiguousarray(d_np)).to(dev)
-        else:
-            lo, hi = v.min(0) * 1.5, v.max(0) * 1.5
-            origins, dirs = W.hash_rays_torch(n, 99, lo, hi, start=lo_ray, device=dev)
-    else:
-        n_total = args.total_rays
-        bounds_all = split_batch(n_total, 1)
-        lo_ray, hi_ray = bounds_all[rank]
-        n = hi_ray - lo_ray
-        lo, hi = v.min(0) * 1.5, v.max(0) * 1.5
-        parts_o, parts_d = [], []
-        for s in range(lo_ray, hi_ray, 1 << 23):                       # bounded temporaries
-            po, pd = W.hash_rays_torch(min(1 << 23, hi_ray - s), 99, lo, hi, start=s, device=dev)
-            parts_o.append(po)
-            parts_d.append(pd)
-        origins = torch.cat(parts_o) if parts_o else torch.zeros((0, 3), device=dev)
-        dirs = torch.cat(parts_d) if parts_d else torch.zeros((0, 3), device=dev)
-        del parts_o, parts_d
-    if args.rays == "pinhole" and args.workload == "c5i" and all(a % args.res == 0 and z % args.res == 0 for a, z in bounds_all):
-        row_quantum = args.res
+    wl = build_workload(args, world, rank, dev, v, rad, share, args.workload, args.scaling, args.res, args.total_rays)
+    strong_c5i = wl["strong_c5i"]
+    origins, dirs, n, n_total, bounds_all = wl["origins"], wl["dirs"], wl["n"], wl["n_total"], wl["bounds_all"]
+    o_np, d_np = wl["o_np"], wl["d_np"]
     vt, ft = torch.from_numpy(v).to(dev), torch.from_numpy(f).to(dev)
     sync()
     t0 = time.perf_counter()
@@ -374,57 +453,49 @@ def run_rank(args):
     info = r.bvh_info()
 
     gather_on = dist_on and (world > 1 or args.force_gather) and not args.no_gather
-    S = ShardedRayMeshIntersector(r, force_collectives=args.force_gather, dst_share=share) if dist_on else None
-    lead = origins.dim() - 1
-    packed_ok = gather_on and S._can_pack()       # the real tracer; stand-ins take the per-output exchange
-    # 4-byte records: rank 0 (the caller of the reference's API: it hands in the whole batch) holds ALL rays and finishes
-    # the peers' rays from (ray, slot); resident before the clock starts like every other input
-    slot_rec = packed_ok and args.records == "slot" and S.slot_records
-    all_rays = None
-    if slot_rec and rank == 0:
-        if args.workload == "c5i" and args.rays == "pinhole":
-            o_img, d_img = W.pinhole_grid(args.res, args.res, distance=2.5 * rad)
-            if strong_c5i:
-                ao, ad = np.broadcast_to(o_img, d_img.shape), d_img
-            else:
-                ao = stacked_rows(np.broadcast_to(o_img, d_img.shape), world, 0, world * args.res, roll=0)
-                ad = stacked_rows(d_img, world, 0, world * args.res)
-            all_rays = (torch.from_numpy(np.ascontiguousarray(ao)).to(dev), torch.from_numpy(np.ascontiguousarray(ad)).to(dev))
-            if row_quantum is None:
-                all_rays = (all_rays[0].reshape(-1, 3), all_rays[1].reshape(-1, 3))
-        else:
-            lo_b, hi_b = v.min(0) * 1.5, v.max(0) * 1.5
-            po_, pd_ = [], []
-            for s_ in range(0, n_total, 1 << 23):
-                a_o, a_d = W.hash_rays_torch(min(1 << 23, n_total - s_), 99, lo_b, hi_b, start=s_, device=dev)
-                po_.append(a_o)
-                pd_.append(a_d)
-            all_rays = (torch.cat(po_), torch.cat(pd_))
-            del po_, pd_
-    pending = []
+    S = ShardedRayMeshIntersector(r, force_collectives=args.force_gather, dst_share=share, ctrl_group=ctrl) if dist_on else None
+    if S is not None and args.exchange:
+        S.set_exchange_mode(args.exchange)
+    elif S is not None and args.records == "packed" and S.exchange_mode == "slot":
+        S.set_exchange_mode("packed")
 
-    def flat(x):
-        return x.reshape(n, *x.shape[lead:])
+    class Runner:
+        """one workload through the exchange mode S is in: step() / drain() as the timed loop calls them"""
 
-    def step():
-        """one call; with the gather on, the pipeline is double-buffered: step k's exchange + expansion
-        (RCCL stream, side stream) overlap step k+1's trace, and step() hands back step k-1's outputs"""
-        if not gather_on:
-            return r.intersects_closest(origins, dirs)
-        if not packed_ok:
-            out = r.intersects_closest(origins, dirs)
-            # chunks land in slices of rank 0's full-size outputs (c5ii / strong: ONE batch; weak: world x n rows)
-            return [S._gather_fixed(flat(x), n_total, 0, bounds_all) for x in out]
-        pending.append(S.closest_of_shard_async(origins, dirs, n_total, batch_shape=bshape, dst=0,
-                                                chunks=args.chunks or None, bounds=bounds_all, row_quantum=row_quantum,
-                                                records="slot" if slot_rec else "packed", all_rays=all_rays))
-        return pending.pop(0).wait() if len(pending) > 1 else None
+        def __init__(self, w, chunks):
+            self.w, self.chunks, self.pending = w, chunks, []
+            self.lead = w["origins"].dim() - 1
+            self.packed_ok = gather_on and S._can_pack()       # the real tracer; stand-ins take the per-output exchange
+            # 4-byte records: rank 0 (the caller of the reference's API: it hands in the whole batch) holds ALL rays and
+            # finishes the peers' rays from (ray, slot); resident before the clock starts like every other input
+            self.slot_rec = self.packed_ok and S.exchange_mode == "slot"
+            self.all_rays = w["all_rays"]() if (self.slot_rec and rank == 0) else None
 
-    def drain():
-        out = None
-        while pending:
-            out = pending.pop(0).wait()
-        return out
+        def step(self):
+            """one call; with the gather on, the pipeline is double-buffered: step k's exchange + expansion
+            (RCCL stream, side stream) overlap step k+1's trace, and step() hands back step k-1's outputs"""
+            w = self.w
+            if not gather_on:
+                return r.intersects_closest(w["origins"], w["dirs"])
+            if not self.packed_ok:
+                out = r.intersects_closest(w["origins"], w["dirs"])
+                # chunks land in slices of rank 0's full-size outputs (c5ii / strong: ONE batch; weak: world x n rows)
+                res_ = [S._gather_fixed(x.reshape(w["n"], *x.shape[self.lead:]), w["n_total"], 0, w["bounds_all"]) for x in out]
+                if res_[0] is None:
+                    return None
+                b = w["bshape"]
+                return [res_[0].view(b), res_[1].view(b), res_[2].view(b), res_[3].view(*b, 3), res_[4].view(*b, 2)]
+            self.pending.append(S.closest_of_shard_async(w["origins"], w["dirs"], w["n_total"], batch_shape=w["bshape"], dst=0,
+                                                         chunks=self.chunks or None, bounds=w["bounds_all"],
+                                                         row_quantum=w["row_quantum"], records="slot" if self.slot_rec else "packed",
+                                                         all_rays=self.all_rays))
+            return self.pending.pop(0).wait() if len(self.pending) > 1 else None
+
+        def drain(self):
+            out = None
+            while self.pending:
+                out = self.pending.pop(0).wait()
+            return out
 
     def barrier():
         if dist_on:
@@ -449,16 +520,104 @@ def run_rank(args):
         sync()
         return [a.elapsed_time(b) for a, b in ev] if not stub else [0.0] * count
 
+    def max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if gloo else dev)
+        if dist_on:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed_region(run, steps, warmup, min_warmup_ms, stride=None):
+        """W untimed steps (and, when min_warmup_ms > 0, as many more as that much time takes), then EXACTLY `steps`
+        timed steps between barrier + synchronize on both sides; the time is the MAX over the ranks.  Sampled HIP event
+        pairs on the launch stream give the per-step GPU time."""
+        import gc
+        if stride is None:
+            stride = max(1, int(args.event_stride)) if args.event_stride else max(1, steps // min(64, max(6, steps // 3)))
+            if not args.event_stride and stride % 2 == 0:
+                stride += 1          # (odd: the block-cost sort runs behind every 4th launch -- the samples must not lock onto it)
+        ev = [event_pair() if k % stride == 0 else None for k in range(steps)]
+        gc.collect()
+        gc.disable()            # a step is ~0.3 ms: keep collector pauses out of the timed region
+        t_w = time.perf_counter()
+        w_done = 0
+        out = None
+        while w_done < warmup or (time.perf_counter() - t_w) * 1e3 < min_warmup_ms:
+            o_k = run.step()
+            out = o_k if o_k is not None else out
+            w_done += 1
+            if w_done % 8 == 0:
+                sync()
+        o_k = run.drain()
+        out = o_k if o_k is not None else out
+        barrier()
+        t0_ = time.perf_counter()
+        for k in range(steps):
+            if ev[k]:
+                ev[k][0].record()
+            o_k = run.step()
+            out = o_k if o_k is not None else out
+            if ev[k]:
+                ev[k][1].record()
+        if run.pending:
+            out = run.drain()                 # the last step's exchange is inside the timed region
+        barrier()
+        el = time.perf_counter() - t0_
+        gc.enable()
+        kms = [p_[0].elapsed_time(p_[1]) for p_ in ev if p_] if not stub else [el / steps * 1e3] * steps
+        return {"elapsed": max_over_ranks(el), "kernel_ms": sorted(kms), "warmup_done": w_done, "out": out, "steps": steps}
+
     # bring the communicator up BEFORE the warm-up (the first collective builds the RCCL rings: hundreds
     # of milliseconds with an idle GPU); the barrier in front of the timed region is then a few tens of
     # microseconds and does not let the clocks drop
     barrier()
     barrier()
+
+    # ---- preflight (VERDICT r04 "next" #1): the exchange this run is about to time, on a small batch, checked -------
+    # One small batch of the same family (same sharding rule, same record form, two steps in flight) through the
+    # exchange mode in force; rank 0 compares what it gathered with its own trace of the whole small batch.  A mismatch
+    # or an exception on any rank moves every rank one rung down the ladder slot -> packed -> dense -> padded -> staged
+    # (triro.ray.sharded.preflight: the verdict is all-reduced on the gloo control group), and the run is timed in the
+    # mode that passed: a first contact with N real GPUs that misbehaves costs bandwidth, not the bench line.
+    exchange = None
+    if gather_on and not args.no_preflight:
+        small_res = max(64, min(args.res, 256) // 8 * 8)
+        wl_s = build_workload(args, world, rank, dev, v, rad, share, args.workload, args.scaling, small_res,
+                              min(args.total_rays, 1 << 18))
+        expected_s = []
+
+        def pf_run():
+            rn = Runner(wl_s, args.chunks)
+            got = None
+            for _ in range(3):
+                o_k = rn.step()
+                got = o_k if o_k is not None else got
+            o_k = rn.drain()
+            return o_k if o_k is not None else got
+
+        def pf_expected():
+            if not expected_s:
+                ao, ad = wl_s["all_rays"]()
+                b = wl_s["bshape"]
+                expected_s.append([x.reshape(*b, *x.shape[ao.dim() - 1:]) for x in r.intersects_closest(ao, ad)])
+            return expected_s[0]
+        try:
+            exchange = S.preflight(dst=0, run=pf_run, expected=pf_expected)
+        except Exception as exc:      # noqa: BLE001 -- no rung passed: say so, and time the run WITHOUT a gather rather than not at all
+            exchange = {"exchange_mode_used": None, "requested": None, "attempts": getattr(S, "preflight_log", [{}])[-1].get("attempts", []),
+                        "error": f"{type(exc).__name__}: {exc}"}
+            gather_on = False
+            print(f"bench.py: no exchange mode passed the preflight ({exc}); the run is timed WITHOUT the result gather", file=sys.stderr)
+        del wl_s, expected_s
+        if not stub:
+            torch.cuda.empty_cache()
+    run = Runner(wl, args.chunks)
+    packed_ok, slot_rec = run.packed_ok, run.slot_rec
+
     sync()
     t_first = time.perf_counter()
-    out = step()                      # very first call: lazy initialisation + no learned launch order yet
-    if pending:
-        out = drain()
+    out = run.step()                  # very first call: lazy initialisation + no learned launch order yet
+    if run.pending:
+        out = run.drain()
     sync()
     first_call_ms = (time.perf_counter() - t_first) * 1e3
     # what the cold call returned: the steady-state launches of the timed region must reproduce it bit for bit
@@ -469,53 +628,63 @@ def run_rank(args):
     # 20-step run ever sees (measured: 0.275 instead of 0.256 ms per launch).
     # (the event pairs bracket every `stride`-th step: an event is a packet of its own in the queue, two per step cost
     # the wall clock -- from which `value` is computed -- a few microseconds of every 200; short runs keep every step)
-    ev_stride = max(1, int(args.event_stride)) if args.event_stride else max(1, args.steps // min(64, max(6, args.steps // 3)))
-    if not args.event_stride and ev_stride % 2 == 0:
-        ev_stride += 1          # (odd: the block-cost sort runs behind every 4th launch -- the samples must not lock onto it)
-    ev = [event_pair() if k % ev_stride == 0 else None for k in range(args.steps)]
-    import gc
-    gc.collect()
-    gc.disable()            # a step is ~0.3 ms: keep collector pauses out of the timed region
-    # warm-up: W steps AND at least --min-warmup-ms of work, so that a short driver run (--steps 20
-    # --warmup 5) starts its timed region in the same steady state as a long one
-    t_w = time.perf_counter()
-    w_done = 0
-    while w_done < args.warmup or (time.perf_counter() - t_w) * 1e3 < args.min_warmup_ms:
-        out = step()
-        w_done += 1
-        if w_done % 8 == 0:
-            sync()
-    drain()
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        if ev[k]:
-            ev[k][0].record()
-        o_k = step()
-        out = o_k if o_k is not None else out
-        if ev[k]:
-            ev[k][1].record()
-    if pending:
-        out = drain()                 # the last step's exchange is inside the timed region
-    barrier()
-    elapsed = time.perf_counter() - t0
-    gc.enable()
-    kernel_ms = [p_[0].elapsed_time(p_[1]) for p_ in ev if p_] if not stub else [elapsed / args.steps * 1e3] * args.steps
+    #
+    # The protocol SURVEY.md 8(d) names -- W warm-ups, then K timed steps, nothing else -- first: on this batch shape
+    # the library is still learning its launch order then (the first launches of a shape measure block costs and try
+    # both node flavours), so this is what a caller gets on calls W+1 ... W+K of a new batch; `value` below is the
+    # steady state after at least --min-warmup-ms of the same call.  Both are in the line (VERDICT r04 "next" #3).
+    proto = None
+    if args.min_warmup_ms > 0 and not stub:
+        proto = timed_region(run, args.steps, args.warmup, 0.0)
+    main_ = timed_region(run, args.steps, args.warmup if proto is None else 0, args.min_warmup_ms)
+    elapsed, kernel_ms, out = main_["elapsed"], main_["kernel_ms"], main_["out"] if main_["out"] is not None else out
+    w_done = main_["warmup_done"] + ((proto["warmup_done"] + proto["steps"]) if proto else 0)
+    # what an event pair costs with nothing between its two records: the interval a pair reports holds that much more
+    # than the kernel (rocprofv3's dispatch time does not), which is how kernel_avg_ms could exceed ms_per_step
+    empty_pair_ms = 0.0
+    if not stub:
+        eps = timed_steps(200, lambda k: None)
+        empty_pair_ms = float(np.median(eps))
     if os.environ.get("TRIRO_BENCH_TRACE") and rank == 0:   # per-step durations, launch order
         print("per-step ms:", " ".join(f"{x:.3f}" for x in kernel_ms), file=sys.stderr)
-    kernel_ms.sort()
-    kernel_avg_ms = float(np.mean(kernel_ms))
-
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if gloo else dev)
-    if dist_on:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
+    kernel_raw_ms = float(np.mean(kernel_ms))
+    kernel_avg_ms = max(kernel_raw_ms - empty_pair_ms, 1e-6)
 
     # the last timed step against the cold first call (different launch order, split set, tiles and
     # node flavour; same rays): any difference is a bug in a "speed only" mechanism
     verified = None
     if first_out is not None and out is not None and out[0] is not None:
         verified = all(torch.equal(a, b) for a, b in zip(out, first_out))
+
+    # ---- N > 1: the other scaling of the same metric, in the same line (VERDICT r04 "next" #1b) -------------------
+    companions_n = {}
+    if gather_on and world > 1 and not args.no_companions:
+        def companion(name, workload, scaling, chunks, steps):
+            try:
+                w2 = build_workload(args, world, rank, dev, v, rad, resolve_share(args, world), workload, scaling, args.res, args.total_rays)
+                rn = Runner(w2, chunks)
+                o1 = rn.step()
+                o1 = rn.drain() if rn.pending else o1
+                first2 = [x.clone() for x in o1] if o1 is not None and o1[0] is not None else None
+                m2 = timed_region(rn, steps, max(args.warmup, 10), args.min_warmup_ms)
+                ok2 = None
+                if first2 is not None and m2["out"] is not None and m2["out"][0] is not None:
+                    ok2 = all(torch.equal(a, b) for a, b in zip(m2["out"], first2))
+                companions_n[name] = {"value": round(w2["n_total"] * steps / m2["elapsed"] / 1e6, 2), "unit": "Mrays/s",
+                                      "ms_per_step": round(m2["elapsed"] / steps * 1e3, 4), "steps": steps,
+                                      "rays_total": w2["n_total"], "shard_rays": [z_ - a_ for a_, z_ in w2["bounds_all"]],
+                                      "chunks": chunks or "auto", "verified": ok2}
+                del w2, rn
+            except Exception as exc:      # noqa: BLE001 -- a companion must never cost the bench line
+                companions_n[name] = {"error": f"{type(exc).__name__}: {exc}"}
+        if args.workload == "c5i" and not strong_c5i:
+            companion("strong_1024" if args.res == 1024 else f"strong_{args.res}", "c5i", "strong", args.chunks, min(args.steps, 200))
+        elif args.workload == "c5i":
+            companion("weak", "c5i", "weak", args.chunks, min(args.steps, 200))
+        else:
+            if args.chunks != 0:      # (chunks 0 IS the library's rule: nothing to put beside it)
+                companion("default_chunks", "c5ii", "strong", 0, min(args.steps, 10))
+    run.all_rays = None
     if rank == 0:
         value = n_total * args.steps / elapsed / 1e6
         # the node array the timed launches walked: the exact 64-byte nodes or the 32-byte grid nodes
@@ -557,19 +726,21 @@ def run_rank(args):
             gather_txt = ", results gathered to rank 0 inside the timed region"
             if args.force_gather and world == 1:
                 gather_txt += " [--force-gather: the exchange is a self-gather in a one-rank communicator]"
+            via = "gloo, host-staged" if (gloo or (S is not None and S.exchange_mode == "staged")) else "RCCL"
             if packed_ok:
-                via = "gloo, host-staged" if gloo else "RCCL"
                 gather_txt += (f" (4 B/ray slot records over {via}, finished on rank 0 from its copy of the rays, " if slot_rec else
                                f" (12 B/ray packed records over {via}, expanded on rank 0, ") + "exchange of step k overlaps trace of step k+1)"
+            else:
+                gather_txt += f" (26 B/ray dense outputs over {via}, exchange mode '{S.exchange_mode}')"
         metric = "Mrays/s closest-hit, 1M-tri mesh, 1024^2 ray batch"
         kernel_name = "k_query_direct<CLOSEST>"
         if strong_c5i:
-            wl = (f"C5(i): icosphere({args.subdiv})+displacement seed 0, {len(f)} tris; ONE {args.res}x{args.res} "
+            wl_txt = (f"C5(i): icosphere({args.subdiv})+displacement seed 0, {len(f)} tris; ONE {args.res}x{args.res} "
                   f"{args.rays} batch cut into {world} row bands; intersects_closest (stream_compaction=False)")
             par = f"ray-sharded x{world}, BVH replicated" + gather_txt
             scaling = "strong"
         elif args.workload == "c5i":
-            wl = (f"C5(i): icosphere({args.subdiv})+displacement seed 0, {len(f)} tris; {args.res}x{args.res} "
+            wl_txt = (f"C5(i): icosphere({args.subdiv})+displacement seed 0, {len(f)} tris; {args.res}x{args.res} "
                   f"{args.rays} rays per GPU; intersects_closest (stream_compaction=False)")
             par = f"ray-sharded x{world}, BVH replicated" + gather_txt
             if world > 1 and share is not None:
@@ -579,7 +750,7 @@ def run_rank(args):
         else:
             metric = "Mrays/s closest-hit, 1M-tri mesh, 100M-ray batch (BASELINE.json config 5; not the 1024^2 headline batch)"
             kernel_name = "k_query_stream<CLOSEST>"
-            wl = (f"C5(ii): icosphere({args.subdiv})+displacement seed 0, {len(f)} tris; ONE batch of {n_total} hash rays "
+            wl_txt = (f"C5(ii): icosphere({args.subdiv})+displacement seed 0, {len(f)} tris; ONE batch of {n_total} hash rays "
                   f"(seed 99) in {world} contiguous shard(s); intersects_closest (stream_compaction=False)")
             par = f"ray-sharded x{world}, BVH replicated" + gather_txt
             scaling = "strong"
@@ -587,29 +758,38 @@ def run_rank(args):
             "metric": metric,
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "value_warmup_requested": round(n_total * proto["steps"] / proto["elapsed"] / 1e6, 2) if proto else None,
+            "ms_per_step_warmup_requested": round(proto["elapsed"] / proto["steps"] * 1e3, 4) if proto else None,
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32",
             "data": "stub tracer: launcher self-test, NOT a measurement" if stub else
                     ("synthetic; FUNCTIONAL RUN over gloo (ranks share GPUs, results staged through the host): NOT a measurement"
                      if gloo else "synthetic"),
             "verified": verified,
-            "config": {"workload": wl, "rays_per_gpu": n, "rays_total": n_total, "triangles": int(len(f)),
+            "config": {"workload": wl_txt, "rays_per_gpu": n, "rays_total": n_total, "triangles": int(len(f)),
                        "parallelism": par, "dst_share": share if world > 1 else None,
                        "shard_rays": [z_ - a_ for a_, z_ in bounds_all] if world > 1 else None, "warmup_steps_done": w_done,
+                       "warmup_note": ("`value` = the steady state: `warmup_steps_done` launches of this batch shape precede its timed region "
+                                       f"(the requested {args.warmup}, the {args.steps} timed steps of `value_warmup_requested`, and "
+                                       f"--min-warmup-ms {args.min_warmup_ms:g} of further launches); `value_warmup_requested` = exactly "
+                                       f"--warmup {args.warmup} launches, then {args.steps} timed steps (SURVEY.md 8d's protocol)") if proto else None,
+                       "exchange_mode_used": (exchange or {}).get("exchange_mode_used") if gather_on or exchange else None,
+                       "exchange": exchange,
                        "bvh_depth": info["depth"], "bvh_bytes": int(bvh_bytes), "bvh_build_ms": round(build_ms, 2),
                        "hit_fraction": round(float(hit0.float().mean().item()), 4) if hit0 is not None else None},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kernel_name, "kernel_avg_ms": round(kernel_avg_ms, 4),
-                         "kernel_min_ms": round(kernel_ms[0], 4), "kernel_samples": len(kernel_ms), "first_call_ms": round(first_call_ms, 4),
+                         "kernel_event_interval_ms": round(kernel_raw_ms, 4), "empty_event_pair_ms": round(empty_pair_ms, 4),
+                         "kernel_min_ms": round(max(kernel_ms[0] - empty_pair_ms, 0.0), 4), "kernel_samples": len(kernel_ms), "first_call_ms": round(first_call_ms, 4),
                          "algorithmic_bytes": int(algo_bytes),
                          "node_flavour": "32-byte grid nodes" if grid_nodes else "exact 64-byte nodes",
                          "frac_on_exact_node_bytes": round(algo_bytes_exact / (kernel_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
                          "compulsory_frac": round(compulsory / HBM_PEAK_GBPS, 5),
                          "note": "achieved = (50 B/ray compulsory I/O + one read of the node and triangle arrays the launch walks) per launch / "
-                                 "event-timed kernel_avg_ms (kernel_samples event pairs spread over the timed region; the interval "
-                                 "between a pair holds the kernel and a few microseconds of packet latency -- rocprofv3: 195 us "
-                                 "for the headline kernel, profiles/r04m_summary.md -- so it can exceed ms_per_step, the wall clock "
-                                 "of back-to-back launches); compulsory_frac counts the 50 B/ray only; the path is "
+                                 "kernel_avg_ms = the mean interval of kernel_samples HIP event pairs spread over the timed region "
+                                 "(kernel_event_interval_ms) minus what a pair reports with NOTHING between its records "
+                                 "(empty_event_pair_ms, the median of 200 measured in this run): the rocprofv3 dispatch time of "
+                                 "the same command is in profiles/r05m_summary.md; compulsory_frac counts the 50 B/ray only; the path is "
                                  "cache-latency / instruction-issue bound, not HBM-bandwidth bound (DESIGN.md 5); "
                                  "frac_on_exact_node_bytes = the same time against round 1's numerator (64-byte nodes), "
                                  "for comparison across rounds only"},
@@ -618,6 +798,15 @@ def run_rank(args):
             res["roofline"]["note"] += ("; kernel_avg_ms here is the caller-stream time of a step (trace; the exchange and the "
                                         "expansion run on RCCL's and a side stream)" if packed_ok else
                                         "; kernel_avg_ms here includes the result gather")
+        for name_, comp_ in companions_n.items():
+            res[name_] = comp_
+        if companions_n:
+            res["scaling_note"] = ("`value` is the " + scaling + "-scaling figure of this run; "
+                                   + ", ".join(companions_n) + " = the same ranks, exchange mode and metric on the other split of the "
+                                   "work (strong_<res>: ONE res^2 batch cut into N row bands -- the metric's literal batch; weak: N such "
+                                   "batches per step; default_chunks: the chunking ONE library call uses instead of bench.py's one chunk "
+                                   "per shard with two steps in flight)")
+        res["parity"] = parity_error_bars()
         single = world == 1 and not stub
         if single and not args.no_companions and args.workload == "c5i":
             # honest companions of the steady-state figure: the same launch

@@ -39,6 +39,49 @@ def classify(op):
     return "other"
 
 
+def instructions(lines):
+    """[(address, text)] of a kernel's disassembly lines"""
+    ins = []
+    for l in lines:
+        body = l.split("//")[0].strip()
+        m = re.search(r"//\s*([0-9A-F]+):", l)
+        if body:
+            ins.append((int(m.group(1), 16) if m else None, body))
+    return ins
+
+
+def loops(ins):
+    """[(first, last)] instruction index spans closed by a backward branch"""
+    addr_idx = {a: i for i, (a, _) in enumerate(ins)}
+    out = []
+    for i, (a, b) in enumerate(ins):
+        m = re.match(r"(s_cbranch_\w+|s_branch)\s+(\d+)", b)
+        if not m or int(m.group(2)) < 32768:
+            continue
+        j = addr_idx.get(a + 4 + (int(m.group(2)) - 65536) * 4)
+        if j is not None:
+            out.append((j, i))
+    return out
+
+
+def scratch_in_trip_loops(so, want, marker="v_perm_b32"):
+    """scratch instructions inside the innermost loops that hold a `marker` instruction (the grid nodes' box test = the
+    traversal trips), per kernel whose demangled name contains `want`: {name: [instruction text]}"""
+    res = {}
+    for name, lines in disassemble(so, want):
+        ins = instructions(lines)
+        lp = loops(ins)
+        spans = set()
+        for p, (_, b) in enumerate(ins):
+            if not b.startswith(marker):
+                continue
+            inner = [sp for sp in lp if sp[0] <= p <= sp[1]]
+            if inner:
+                spans.add(min(inner, key=lambda sp: sp[1] - sp[0]))
+        res[name] = [ins[i][1] for (a, z) in spans for i in range(a, z + 1) if ins[i][1].startswith("scratch_")]
+    return res
+
+
 def main():
     want = sys.argv[1]
     here = os.path.dirname(os.path.abspath(__file__))

@@ -88,6 +88,44 @@ def test_gpus2_gathers_by_default_and_strong_scaling_of_one_image():
     assert "gathered" not in r["config"]["parallelism"] and r["verified"] is True
 
 
+@pytest.mark.timeout(300)
+def test_gpus2_preflight_names_the_exchange_mode_and_both_scalings_are_in_the_line():
+    """VERDICT r04 "next" #1: the N-rank line carries the exchange mode the preflight settled on (and why), the weak AND
+    the strong figure; a rung that fails -- here on purpose -- costs bandwidth, not the line."""
+    common = ["--gpus", "2", "--backend", "gloo", "--stub", "bench_stub:make", "--subdiv", "2", "--res", "64",
+              "--steps", "3", "--warmup", "1", "--min-warmup-ms", "0"]
+    p = run_bench(*common)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads(p.stdout.strip().splitlines()[-1])
+    assert r["config"]["exchange_mode_used"] == "slot" and r["config"]["exchange"]["attempts"] == [{"mode": "slot", "ok": True, "reason": ""}]
+    assert r["scaling"] == "weak" and r["strong_64"]["rays_total"] == 64 * 64 and r["strong_64"]["verified"] is True and r["strong_64"]["value"] > 0
+    assert "parity" in r and r["parity"]["pinned_bit_exact_against_reference"] is False
+    env = dict(os.environ)
+    os.environ["TRIRO_PREFLIGHT_FAIL"] = "slot,packed,dense"
+    try:
+        p = run_bench(*common, "--scaling", "strong")
+    finally:
+        os.environ.clear()
+        os.environ.update(env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads(p.stdout.strip().splitlines()[-1])
+    ex = r["config"]["exchange"]
+    assert r["config"]["exchange_mode_used"] == "padded" and [a["mode"] for a in ex["attempts"]] == ["slot", "packed", "dense", "padded"]
+    assert all("TRIRO_PREFLIGHT_FAIL" in a["reason"] for a in ex["attempts"][:3]) and ex["attempts"][3]["ok"]
+    assert r["verified"] is True and "exchange mode 'padded'" in r["config"]["parallelism"] and r["weak"]["verified"] is True
+    # every rung fails: the run is still timed -- without the gather -- and says so
+    os.environ["TRIRO_PREFLIGHT_FAIL"] = "slot,packed,dense,padded,staged"
+    try:
+        p = run_bench(*common)
+    finally:
+        os.environ.clear()
+        os.environ.update(env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads(p.stdout.strip().splitlines()[-1])
+    assert r["config"]["exchange_mode_used"] is None and "no exchange mode passed" in r["config"]["exchange"]["error"]
+    assert "gathered" not in r["config"]["parallelism"] and r["value"] > 0
+
+
 @pytest.mark.skipif(torch.cuda.device_count() >= 2, reason="needs a node with fewer than 2 GPUs")
 def test_gpus2_refuses_when_fewer_devices_are_visible():
     p = run_bench("--gpus", "2", "--steps", "2", "--warmup", "1")

@@ -10,20 +10,33 @@ sys.path.insert(0, os.path.join(ROOT, "scripts"))
 
 
 def test_no_query_kernel_of_the_shipped_library_spills():
-    """VERDICT r03 #7a: every k_query_* instantiation in the shipped code object has vgpr_spill_count 0 (the
-    no occupancy attribute forces a register budget a kernel does not fit) and uses no scratch"""
+    """VERDICT r03 #7a: every k_query_* instantiation in the shipped code object has vgpr_spill_count 0 and uses no scratch
+    -- with ONE documented exception since round 5: the streaming launches ask for one wave per SIMD more than the
+    compiler's own budget gives them (binary nodes: six waves, 80 registers against 85-89; 8-wide nodes: five waves, 96
+    against 101-106 -- the fused box test's constants live across the refill path), which costs them 2-7 registers of
+    kernel-lifetime values (stored once in the prologue, read once per refill: profiles/r05_ab_stream_waves.txt,
+    r05_ab_wide_waves.txt); the test pins that: at most 8 registers, and NO scratch instruction inside the traversal trips."""
     import code_object_notes as con
+    sys.path.insert(0, os.path.join(ROOT, "scripts", "round5"))
+    import isa_loops
     so = os.path.join(ROOT, "trimesh-ray-optix_amd", "lib", "libtriro_hip.so")
     if not os.path.exists(so) or not os.path.exists(con.READELF):
         pytest.skip("library not built / llvm-readelf not available")
     ks = [k for k in con.kernels(so) if "k_query" in k["name"]]
     assert len(ks) > 50
-    bad = [(k["name"], k["vgpr_spill"], k["scratch"]) for k in ks if k["vgpr_spill"] != 0 or k["scratch"] != 0]
+    stream = [k for k in ks if k["name"].startswith("void k_query_stream<") or k["name"].startswith("void k_query_wide<")]
+    bad = [(k["name"], k["vgpr_spill"], k["scratch"]) for k in ks if k not in stream and (k["vgpr_spill"] != 0 or k["scratch"] != 0)]
     assert not bad, bad
-    # the stealing closest launch of the headline stays within 7 waves per SIMD (72 registers)
+    assert stream and all(k["vgpr_spill"] <= 8 and k["vgpr"] <= 96 for k in stream), [(k["name"], k["vgpr"], k["vgpr_spill"]) for k in stream]
+    inside = isa_loops.scratch_in_trip_loops(so, "k_query_stream<")
+    assert inside and not any(inside.values()), inside
+    inside = isa_loops.scratch_in_trip_loops(so, "k_query_wide<", marker="v_cvt_f32_ubyte")      # (the 8-bit planes' decode)
+    assert inside and not any(inside.values()), inside
+    # the stealing closest launch of the headline: six waves per SIMD since round 5 (76 registers: the fused box test's
+    # per-ray constants; measured +7 % over the 69-register kernel of round 4, and better than forcing 72: r05_ab_fuse.txt)
     for k in ks:
         if k["name"].startswith("void k_query_direct<2, false, true, 128, 1, false, true, false>"):
-            assert k["vgpr"] <= 72, k
+            assert k["vgpr"] <= 80, k
 
 
 def test_cpu_baseline_scales_with_threads():

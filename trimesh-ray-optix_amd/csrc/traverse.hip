@@ -1250,17 +1250,34 @@ __device__ __forceinline__ void query_stream_body(const tr_bvh_view& b, const Ra
 // (Round 3 ran the compact instantiations at 8 waves per SIMD, 64 registers: -2...-7 %.  Round 4's sign-selected slab
 // test needs three registers more and is worth about as much on these fabric-bound launches -- C3 any -1.7 %, C5(ii)
 // shard -1 %, count +1.5 % at 7 waves: profiles/r04_ab_qsign.txt -- so every instantiation keeps the compiler's budget.)
-#ifdef TR_STREAM_WAVES
+// Round 5: the fused box test's per-ray constants (tr_ray_fuse) put the kernel's refill path -- every lane's traversal
+// state live across a ray fetch, a set-up and a result write -- at 85-89 registers, five waves per SIMD; asked for six
+// (80 registers) the compiler parks 2-5 kernel-lifetime values in scratch (stored once in the prologue, read once per
+// refill, nothing inside the trips: tests/test_round4_cpu.py) and the launch is as fast or faster than both the
+// five-wave build and round 4's 72-register kernel without the fused test (C3 any 0.892 -> 0.847 ms, C5(ii) shard
+// 1.845 -> 1.851, shard count 2.505 -> 2.427; seven waves: slower again -- profiles/r05_ab_stream_waves.txt).
+#ifndef TR_STREAM_WAVES
+#define TR_STREAM_WAVES 6
+#endif
+#if TR_STREAM_WAVES > 0
 #define TR_STREAM_OCC __attribute__((amdgpu_waves_per_eu(TR_STREAM_WAVES, TR_STREAM_WAVES)))
 #else
 #define TR_STREAM_OCC
 #endif
-template <int Q, bool STATS, bool COMPACT, int BS, bool DEEP = false>
+template <int Q, bool COMPACT, int BS, bool DEEP = false>
 __global__ __launch_bounds__(BS) TR_STREAM_OCC void k_query_stream(tr_bvh_view b, RayFetch rf, QueryOut out,
                                                      int rays_per_wave, int refill_min, int xcd_map,
                                                      unsigned long long* stats, const int* __restrict__ sel,
                                                      unsigned long long* work) {
-    query_stream_body<Q, STATS, COMPACT, BS, DEEP>(b, rf, out, rays_per_wave, refill_min, xcd_map, stats, sel, work);
+    query_stream_body<Q, false, COMPACT, BS, DEEP>(b, rf, out, rays_per_wave, refill_min, xcd_map, stats, sel, work);
+}
+// the instrumented launch (tr_trace_stats_query: three more live counters): the compiler's own register budget
+template <int Q, bool COMPACT, int BS, bool DEEP = false>
+__global__ __launch_bounds__(BS) void k_query_stream_stats(tr_bvh_view b, RayFetch rf, QueryOut out,
+                                                           int rays_per_wave, int refill_min, int xcd_map,
+                                                           unsigned long long* stats, const int* __restrict__ sel,
+                                                           unsigned long long* work) {
+    query_stream_body<Q, true, COMPACT, BS, DEEP>(b, rf, out, rays_per_wave, refill_min, xcd_map, stats, sel, work);
 }
 // ---- multi-hit second pass (shaders.cu:196-246) ----------------------------------------------
 template <int K>
@@ -2265,14 +2282,18 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
                     // from 3 M triangles on (5.2 M triangles: closest -10 %) and count launches from 1 M triangles on
                     // (C5(ii) shard count -9 %); on the 1.31 M-triangle headline mesh closest / any are equal within
                     // 1 %, on the 82 k-triangle C2 mesh the binary walk wins by 5...22 % (profiles/r04_ab_wide.txt)
-                    const bool wide_auto = bvh->num_tris >= 3000000 || (Q == TR_Q_COUNT && bvh->num_tris >= 1000000);
+                    // (round 5, with the fused box test and five waves per SIMD: the wide walk wins from 1 M triangles on for
+                    // every query -- C5(ii) shard closest 1.845 -> 1.786 ms, count 2.419 -> 2.242 -- and still loses on the
+                    // 82 k-triangle C2 / C3 mesh, any-hit 0.841 -> 0.929: profiles/r05_ab_wide_waves.txt)
+                    const bool wide_auto = bvh->num_tris >= 1000000;
                     const tr_wnode* wn = ((opt.wide == 1 || (opt.wide == 2 && wide_auto)) && addr32) ? ensure_wide(bvh, stream) : nullptr;
                     if (wn) {
                         static std::atomic<int> wocc_a{0};   // per instantiation <Q, STATS>
                         int wocc = wocc_a.load(std::memory_order_relaxed);
                         if (wocc == 0) {
                             int nb = 0;
-                            hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_query_wide<Q, STATS>, 128, 0);
+                            hipError_t e = STATS ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_query_wide_stats<Q>, 128, 0)
+                                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_query_wide<Q>, 128, 0);
                             wocc = (e == hipSuccess && nb > 0) ? nb : 8;
                             wocc_a.store(wocc, std::memory_order_relaxed);
                         }
@@ -2284,22 +2305,31 @@ int launch_query(const tr_bvh* bvh, const tr_rays* rays, const QueryOut& out,
                         const int spill_cap = need > lds_cap ? need - lds_cap : 0;
                         int32_t* spill = spill_cap > 0 ? wide_spill(bvh, stream, (size_t)wgrid * 128 * (size_t)spill_cap) : nullptr;
                         if (spill_cap == 0 || spill) {
-                            hipLaunchKernelGGL((k_query_wide<Q, STATS>), dim3(wgrid), dim3(128), 0, stream, view, wn, rf, out, rpw,
-                                               opt.stream_refill, sel, work, spill, spill_cap, lds_cap, d_stats);
+                            if constexpr (STATS)
+                                hipLaunchKernelGGL((k_query_wide_stats<Q>), dim3(wgrid), dim3(128), 0, stream, view, wn, rf, out, rpw,
+                                                   opt.stream_refill, sel, work, spill, spill_cap, lds_cap, d_stats);
+                            else
+                                hipLaunchKernelGGL((k_query_wide<Q>), dim3(wgrid), dim3(128), 0, stream, view, wn, rf, out, rpw,
+                                                   opt.stream_refill, sel, work, spill, spill_cap, lds_cap, d_stats);
                             wide_launched = true;
                         }
                     }
                 }
                 if (wide_launched) {
-                } else if (compact)
-                    hipLaunchKernelGGL((k_query_stream<Q, STATS, true, 128>), dim3(grid), dim3(128), 0, stream,
-                                       view, rf, out, rpw, opt.stream_refill, sxc, d_stats, sel, work);
-                else if (addr32)
-                    hipLaunchKernelGGL((k_query_stream<Q, STATS, true, 128, true>), dim3(grid), dim3(128), 0, stream,
-                                       view, rf, out, rpw, opt.stream_refill, sxc, d_stats, sel, work);
-                else
-                    hipLaunchKernelGGL((k_query_stream<Q, STATS, false, 128>), dim3(grid), dim3(128), 0, stream,
-                                       view, rf, out, rpw, opt.stream_refill, sxc, d_stats, sel, work);
+                } else {
+#define TR_LAUNCH_STREAM(KERNEL)                                                                                        \
+    do {                                                                                                                \
+        if (compact) hipLaunchKernelGGL((KERNEL<Q, true, 128>), dim3(grid), dim3(128), 0, stream, view, rf, out, rpw,   \
+                                        opt.stream_refill, sxc, d_stats, sel, work);                                   \
+        else if (addr32) hipLaunchKernelGGL((KERNEL<Q, true, 128, true>), dim3(grid), dim3(128), 0, stream, view, rf,   \
+                                            out, rpw, opt.stream_refill, sxc, d_stats, sel, work);                     \
+        else hipLaunchKernelGGL((KERNEL<Q, false, 128>), dim3(grid), dim3(128), 0, stream, view, rf, out, rpw,          \
+                                opt.stream_refill, sxc, d_stats, sel, work);                                           \
+    } while (0)
+                    if constexpr (STATS) TR_LAUNCH_STREAM(k_query_stream_stats);
+                    else TR_LAUNCH_STREAM(k_query_stream);
+#undef TR_LAUNCH_STREAM
+                }
                 TR_HIP_TRY(hipGetLastError());
                 if (!sel) return TR_OK;
             }

@@ -304,20 +304,32 @@ class ShardedRayMeshIntersector:
         dist.all_reduce(t, op=dist.ReduceOp.MIN, group=g)
         return bool(int(t.item()) == 1)
 
-    def preflight(self, origins: torch.Tensor, directions: torch.Tensor, dst: int = 0, chunks: Optional[int] = None,
-                  ladder: Optional[Sequence[str]] = None) -> dict:
+    def preflight(self, origins: Optional[torch.Tensor] = None, directions: Optional[torch.Tensor] = None, dst: int = 0,
+                  chunks: Optional[int] = None, ladder: Optional[Sequence[str]] = None, run=None, expected=None) -> dict:
         """COLLECTIVE.  Runs the (small) batch `origins`, `directions` -- visible on every rank, like the argument of
         intersects_closest -- through the exchange rung in use; the destination compares the gathered outputs with its
         own trace of the whole batch, bit for bit.  A mismatch or an exception on ANY rank moves EVERY rank one rung down
         the ladder (the verdict is all-reduced) and the batch is run again; the mode that passes stays in force.
+        A caller with its own call path (bench.py: ranks that hold only their shard, two steps in flight) passes
+        `run()` -> the gathered (hit, front, tri, loc, uv) on the destination, None elsewhere -- called once per rung, in
+        the mode under test -- and `expected()` -> the reference outputs, called on the destination only.
         Returns {"exchange_mode_used", "requested", "attempts": [{"mode", "ok", "reason"}...]}.  Raises RuntimeError when
         no rung passes.  An exchange that HANGS cannot be stepped over in-process (the communicator's timeout ends it)."""
+        if run is None:
+            if origins is None or directions is None:
+                raise ValueError("preflight needs a batch (origins, directions) or a run() callable")
+
+            def run():
+                return self.intersects_closest(origins, directions, dst=dst, chunks=chunks)
+        if expected is None:
+            def expected():
+                return self.local.intersects_closest(origins, directions)
         rungs = list(ladder) if ladder is not None else list(LADDER[LADDER.index(self._mode):])
         if "staged" in rungs and self.ctrl_group is None and not self._base_stage[0]:
             rungs.remove("staged")
         requested = self.exchange_mode
         attempts = []
-        expected = None
+        want_out = None
         for mode in rungs:
             self.set_exchange_mode(mode)
             eff = self.exchange_mode          # (what this rung really does here: every rank sees the same)
@@ -326,19 +338,22 @@ class ShardedRayMeshIntersector:
                 continue
             ok, reason = True, ""
             try:
-                got = self.intersects_closest(origins, directions, dst=dst, chunks=chunks)
+                if mode in os.environ.get("TRIRO_PREFLIGHT_FAIL", "").split(","):
+                    # test hook: make a rung fail on purpose (every rank alike), e.g. to rehearse the fallbacks on real hardware
+                    raise RuntimeError(f"injected by TRIRO_PREFLIGHT_FAIL={os.environ['TRIRO_PREFLIGHT_FAIL']}")
+                got = run()
                 if self.rank == dst:
-                    if expected is None:
-                        expected = self.local.intersects_closest(origins, directions)
+                    if want_out is None:
+                        want_out = expected()
                     if got is None:
                         ok, reason = False, "the destination rank received nothing"
                     else:
                         names = ("hit", "front", "tri", "loc", "uv")
-                        bad = [nm for nm, a, b in zip(names, got, expected) if a.shape != b.shape or not torch.equal(a, b)]
+                        bad = [nm for nm, a, b in zip(names, got, want_out) if a.shape != b.shape or not torch.equal(a, b)]
                         if bad:
                             ok, reason = False, "gathered outputs differ from a local trace: " + ", ".join(bad)
-                if torch.cuda.is_available() and origins.is_cuda:
-                    torch.cuda.synchronize(origins.device)
+                if torch.cuda.is_available() and torch.cuda.is_initialized():
+                    torch.cuda.synchronize()
             except Exception as exc:      # noqa: BLE001 -- whatever the rung throws, the next one gets its chance
                 ok, reason = False, f"{type(exc).__name__}: {exc}"
             all_ok = self._agree(ok)
