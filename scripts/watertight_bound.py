@@ -8,7 +8,7 @@ grazes an edge or a vertex.  This script counts those rays per BASELINE config: 
 hit count (oracle, = the HIP path bit for bit, tests/test_gpu_*.py) against the WATERTIGHT float64 test of Woop /
 Benthin / Wald 2013 (oracle/triro_oracle.c, "WATERTIGHT float64 reference"; shares nothing with the contract).
 
-    python scripts/watertight_bound.py [--quick] > profiles/r04_watertight_bound.jsonl        (CPU only)
+    python scripts/watertight_bound.py [--quick] [--full] > profiles/r05_watertight_bound.jsonl        (CPU only)
 
 Per config: rays, and the number of rays whose
   only_contract / only_watertight   hit mask differs (the second is the "crack": a ray lost between two triangles)
@@ -53,7 +53,8 @@ def compare(name, v, f, o, d):
     return res
 
 
-def configs(quick=False):
+def configs(quick=False, full=False):
+    """full (round 5, VERDICT r04 "next" #7): additionally ALL 10 M rays of C3 and one 12.5 M-ray shard of C5(ii)"""
     res = 256 if quick else 1024
     v, f, label = W.bunny_mesh()
     o, d = W.pinhole_grid(res, res, distance=2.5 * float(np.linalg.norm(v, axis=1).max()))
@@ -62,12 +63,21 @@ def configs(quick=False):
         lo, hi = v.min(0) * 1.5, v.max(0) * 1.5
         o3, d3 = W.hash_rays(2_000_000, 1234, lo, hi)
         yield "C3 (first 2M of the 10M hash rays)", v, f, o3, d3
+        if full:
+            o3, d3 = W.hash_rays(10_000_000, 1234, lo, hi)
+            yield "C3 (all 10M hash rays)", v, f, o3, d3
+            del o3, d3
     v, f = W.nested_shells(5 if quick else 7)
     o, d = W.pinhole_grid(res, res)
     yield f"C4 nested shells, {res}^2 pinhole", v, f, o, d
     v, f = W.headline_mesh(6 if quick else 8)
     o, d = W.pinhole_grid(res, res, distance=2.5 * float(np.linalg.norm(v, axis=1).max()))
     yield f"C5(i) headline mesh, {res}^2 pinhole", v, f, o, d
+    if full and not quick:
+        lo, hi = v.min(0) * 1.5, v.max(0) * 1.5
+        o5, d5 = W.hash_rays(12_500_000, 99, lo, hi)
+        yield "C5(ii) shard 0 (12.5M of the 100M hash rays)", v, f, o5, d5
+        del o5, d5
     v, f = W.terrain() if not quick else W.terrain(n=180)
     w, h = (1024, 576) if not quick else (256, 144)
     _, d = W.ref_shape_rays(W.TERRAIN_EYE, W.TERRAIN_TARGET, w, h, 444.0 * w / 640)
@@ -77,5 +87,5 @@ def configs(quick=False):
 
 if __name__ == "__main__":
     quick = "--quick" in sys.argv
-    for name, v, f, o, d in configs(quick):
+    for name, v, f, o, d in configs(quick, "--full" in sys.argv):
         print(json.dumps(compare(name, v, f, np.ascontiguousarray(o, np.float32), np.ascontiguousarray(d, np.float32))), flush=True)

@@ -535,7 +535,7 @@ int tr_arena_alloc(tr_bvh* bvh, int64_t nf) {
 int64_t tr_arena_used_bytes(int64_t nf) { return (int64_t)carve_arena(nullptr, nullptr, nf); }
 
 void tr_bvh_reset(tr_bvh* bvh) {
-    bvh->wide_valid = false;
+    bvh->wide_valid = false; bvh->wide_unavailable = false;
     bvh->frame = tr_qframe{{0.f, 0.f, 0.f}, {1.f, 1.f, 1.f}};
     bvh->num_tris = 0; bvh->num_nodes = 0; bvh->depth = 0; bvh->key_mode = 0;
     for (int k = 0; k < 3; k++) { bvh->aabb_min[k] = 0.f; bvh->aabb_max[k] = 0.f; }
@@ -546,7 +546,7 @@ int tr_build_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_
                   int64_t nf, hipStream_t stream) {
     if (nf < 0 || nv < 0) return tr_fail(TR_ERR_INVALID_ARG, "negative mesh size");
     if (nf >= (int64_t)1 << 31) return tr_fail(TR_ERR_INVALID_ARG, "more than 2^31-1 triangles");
-    bvh->wide_valid = false;      // the wide nodes are derived data: rebuilt by the next streaming query
+    bvh->wide_valid = false; bvh->wide_unavailable = false;      // the wide nodes are derived data: rebuilt by the next streaming query
     // an empty vertex array may be NULL: every face is then out of range and reported as such
     if (nf > 0 && (!d_faces || (!d_vertices && nv > 0))) return tr_fail(TR_ERR_INVALID_ARG, "null mesh pointer");
 
@@ -755,7 +755,7 @@ int tr_build_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_
 int tr_refit_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_t* d_faces,
                   int64_t nf, hipStream_t stream) {
     if (nf != bvh->num_tris) return tr_fail(TR_ERR_INVALID_ARG, "refit needs the same number of faces as the build");
-    bvh->wide_valid = false;
+    bvh->wide_valid = false; bvh->wide_unavailable = false;
     if (nf == 0) return TR_OK;
     if (!d_vertices || !d_faces) return tr_fail(TR_ERR_INVALID_ARG, "null mesh pointer");
     if (nv < 0) return tr_fail(TR_ERR_INVALID_ARG, "negative mesh size");

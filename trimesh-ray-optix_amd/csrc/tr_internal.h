@@ -96,6 +96,7 @@ struct tr_bvh {
     int64_t* widx = nullptr;      // exclusive scan of the flags (+ one word for the total)
     int64_t wtmp_cap = 0;
     bool wide_valid = false;
+    bool wide_unavailable = false;     // the last attempt to build them for THIS hierarchy failed (too large, out of memory): not retried until the next build / refit / load
     hipEvent_t wide_event = nullptr;
     hipStream_t wide_stream = nullptr;
     tr_launch_info last_launch = {};     // tr_bvh_last_launch (written under sched_mutex)

@@ -2656,8 +2656,12 @@ const tr_wnode* ensure_wide(const tr_bvh* cbvh, hipStream_t stream) {
         if (stream != bvh->wide_stream && bvh->wide_event) (void)hipStreamWaitEvent(stream, bvh->wide_event, 0);
         return bvh->wnodes;
     }
+    // (a hierarchy whose wide nodes cannot be built -- 4 GiB of records and more, no memory -- used to run
+    // the marking rounds and a synchronising scan again behind EVERY streaming query; one failed attempt per build now)
+    if (bvh->wide_unavailable) return nullptr;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
+    struct mark_failed { tr_bvh* b; bool ok = false; ~mark_failed() { if (!ok) b->wide_unavailable = true; } } outcome{bvh};
     const int64_t n = bvh->num_nodes;
     if (bvh->wtmp_cap < n) {
         if (bvh->wflag) (void)hipFree(bvh->wflag);
@@ -2691,6 +2695,7 @@ const tr_wnode* ensure_wide(const tr_bvh* cbvh, hipStream_t stream) {
     bvh->wide_stream = stream;
     bvh->wcount = nw;
     bvh->wide_valid = true;
+    outcome.ok = true;
     return bvh->wnodes;
 }
 
