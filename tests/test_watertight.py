@@ -16,6 +16,7 @@ sys.path.insert(0, os.path.join(ROOT, "scripts"))
 MAX_HIT_MASK_DIFF = 5e-5
 MAX_REAL_DISAGREEMENT = 1e-4
 MAX_COUNT_DIFF = 1e-3
+MAX_REL_T_DIFF = 1e-4      # (see the comment above test_committed_error_bars...)
 
 
 def test_watertight_reference_on_hand_cases():
@@ -43,7 +44,35 @@ def test_contract_stays_close_to_the_watertight_reference_small():
         assert r["hit_mask_diff_rate"] <= 2e-4, r           # (64 k rays: one ray = 1.5e-5)
         assert r["real_disagreement_rate"] <= 2e-4, r
         assert r["count_diff"] <= 1e-3 * r["rays"], r
-        assert r["max_rel_t_diff_same_tri"] <= 1e-4, r
+        assert r["max_rel_t_diff_same_tri"] <= MAX_REL_T_DIFF, r
+
+
+# bound on the relative difference of the hit distance on the SAME triangle (float32 Moller-Trumbore against the float64
+# watertight test): measured 4.9e-6 ... 4.8e-5 -- i.e. ABOVE the 1e-5 that BASELINE's north_star allows for t on some rays
+# of every config but C3's first 2 M and the terrain; stated here and in README.md / the bench line, not hidden
+MAX_REL_T_DIFF = 1e-4
+
+
+def test_committed_error_bars_are_the_full_size_ones_and_within_the_stated_bounds():
+    """VERDICT r04 "next" #7: the three rates (hit mask, triangle index, hit count) and the distance bound of EVERY BASELINE
+    config at full size -- all 10 M rays of C3 and a 12.5 M-ray shard of C5(ii) included -- are committed
+    (profiles/r05_watertight_bound.jsonl, written by scripts/watertight_bound.py --full) and stay within the bounds this
+    file states; README.md and bench.py's `parity` block quote the same file."""
+    import json
+    rows = [json.loads(ln) for ln in open(os.path.join(ROOT, "profiles", "r05_watertight_bound.jsonl")) if ln.startswith("{")]
+    names = " | ".join(r["config"] for r in rows)
+    for want in ("C2", "C3 (all 10M", "C4", "C5(i)", "C5(ii) shard", "TERRAIN"):
+        assert want in names, want
+    for r in rows:
+        n = r["rays"]
+        assert (r["only_contract"] + r["only_watertight"]) <= MAX_HIT_MASK_DIFF * n, r
+        assert (r["only_contract"] + r["only_watertight"] + r["tri_diff_other"]) <= MAX_REAL_DISAGREEMENT * n, r
+        assert r["count_diff"] <= MAX_COUNT_DIFF * n, r
+        assert r["max_rel_t_diff_same_tri"] <= MAX_REL_T_DIFF, r
+        assert r["only_contract"] == 0, r          # the contract never reports a hit the watertight test does not see
+    readme = open(os.path.join(ROOT, "README.md")).read()
+    worst = max(r["max_rel_t_diff_same_tri"] for r in rows)
+    assert f"{worst:.1e}" in readme, "README.md must quote the largest distance difference of the committed table"
 
 
 @pytest.mark.gpu

@@ -466,42 +466,7 @@ struct Carver {
     }
 };
 
-// LDS-staged node packets (tr_bvh.h, TR_TOP_LEVELS): slot h of the table = the grid node reached from the
-// root by the bits of h below its leading one (0 -> c0, 1 -> c1); slots whose path runs into a leaf child
-// are never read and hold a node whose children are both "none".
-__global__ __launch_bounds__(TR_TOP_SLOTS) void k_top_table(const tr_qnode* __restrict__ qnodes, int64_t num_nodes,
-                                                            tr_qnode* __restrict__ table) {
-    const uint32_t h = threadIdx.x;
-    tr_qnode out;
-    for (int k = 0; k < 6; k++) out.q[k] = 0u;
-    out.c0 = -1; out.c1 = -1;                 // (as leaf ids these would be slot 0: never followed, see above)
-    bool ok = h >= 1u && num_nodes > 0;
-    int32_t node = 0;
-    if (ok) {
-        const int top = 31 - __builtin_clz(h);
-        for (int bit = top - 1; bit >= 0 && ok; bit--) {
-            const tr_qnode n = qnodes[node];
-            const int32_t c = ((h >> bit) & 1u) ? n.c1 : n.c0;
-            ok = c >= 0;
-            node = c;
-        }
-    }
-    if (ok) out = qnodes[node];
-    table[h] = out;
-}
-
 }  // namespace
-
-int tr_top_table_update(tr_bvh* bvh, hipStream_t stream) {
-    if (bvh->num_nodes <= 0) return TR_OK;
-    if (!bvh->top_table) TR_HIP_TRY(hipMalloc((void**)&bvh->top_table, sizeof(tr_qnode) * TR_TOP_SLOTS));
-    hipLaunchKernelGGL(k_top_table, dim3(1), dim3(TR_TOP_SLOTS), 0, stream, bvh->qnodes, bvh->num_nodes, bvh->top_table);
-    TR_HIP_TRY(hipGetLastError());
-    // build / refit / load return with ALL data of the handle complete: a query on another stream may start at
-    // once, and with lds_top it copies this table (a 128-thread kernel behind an already drained stream)
-    TR_HIP_TRY(hipStreamSynchronize(stream));
-    return TR_OK;
-}
 
 // Arena layout for `nf` triangles; returns total bytes and sets the pointers when base != 0
 static size_t carve_arena(tr_bvh* bvh, char* base, int64_t nf) {
@@ -539,7 +504,7 @@ void tr_bvh_reset(tr_bvh* bvh) {
     bvh->frame = tr_qframe{{0.f, 0.f, 0.f}, {1.f, 1.f, 1.f}};
     bvh->num_tris = 0; bvh->num_nodes = 0; bvh->depth = 0; bvh->key_mode = 0;
     for (int k = 0; k < 3; k++) { bvh->aabb_min[k] = 0.f; bvh->aabb_max[k] = 0.f; }
-    for (int k = 0; k < TR_SCHED_SLOTS; k++) { bvh->sched[k].nblocks = 0; bvh->sched[k].gn_reset(); }
+    for (int k = 0; k < TR_SCHED_SLOTS; k++) { bvh->sched[k].nblocks = 0; }
 }
 
 int tr_build_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_t* d_faces,
@@ -567,7 +532,7 @@ int tr_build_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_
     // `update_raw`) it is one frame stale, which is a far better hint than none -- keep it and
     // measure again on the next launches
     // (the node-flavour tuner starts over: its measurement windows are counted in launches of this mesh)
-    for (int k = 0; k < TR_SCHED_SLOTS; k++) { bvh->sched[k].launches = 0; bvh->sched[k].gn_reset(); }
+    for (int k = 0; k < TR_SCHED_SLOTS; k++) { bvh->sched[k].launches = 0; }
     for (int k = 0; k < 3; k++) { bvh->aabb_min[k] = 0.f; bvh->aabb_max[k] = 0.f; }
     if (nf == 0) return TR_OK;
 
@@ -736,7 +701,6 @@ int tr_build_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_
             memcpy(&bvh->aabb_max[k], &b1, 4);
         }
         tr_qframe_make(bvh->aabb_min, bvh->aabb_max, &bvh->frame);   // == k_qframe's (same function, same bounds)
-        status = tr_top_table_update(bvh, stream);
     }
     int rs = tr_build_temp_release(st);   // the stream is drained: the next build may reuse the buffer
     if (rs != TR_OK && status == TR_OK) status = rs;
@@ -811,7 +775,6 @@ int tr_refit_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_
     if (status == TR_OK && hbad != 0xffffffffu)
         status = tr_fail(TR_ERR_INVALID_ARG, "face " + std::to_string(hbad) + " has a vertex index outside [0, " +
                                                  std::to_string(nv) + ")");
-    if (status == TR_OK) status = tr_top_table_update(bvh, stream);
     if (status != TR_OK) {   // the triangle records are partly rewritten: drop the hierarchy
         const std::string msg = tr_last_error();
         tr_bvh_reset(bvh);

@@ -237,14 +237,7 @@ struct tr_bvh_view {
     int64_t num_tris;
     const tr_qnode* qnodes;   // 32-byte grid nodes of the unordered schedule (same topology as `nodes`)
     tr_qframe frame;
-    const tr_qnode* top;      // the grid nodes of the top TR_TOP_LEVELS levels in heap order (LDS-staged node packets)
 };
-// LDS-staged node packets: the top levels of the hierarchy as a table in heap order -- slot 1 the root,
-// slots 2h / 2h+1 the children c0 / c1 of slot h (a slot whose node does not exist is never reached: a
-// lane only descends into internal children).  127 grid nodes = 4 KiB, copied into LDS once per workgroup.
-#define TR_TOP_LEVELS 7
-#define TR_TOP_SLOTS (1 << TR_TOP_LEVELS)
-
 enum tr_query { TR_Q_ANY = 0, TR_Q_FIRST = 1, TR_Q_CLOSEST = 2, TR_Q_COUNT = 3, TR_Q_LOCATION = 4 };
 
 struct tr_counters {

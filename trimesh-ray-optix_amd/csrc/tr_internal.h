@@ -46,21 +46,9 @@ struct tr_sched_slot {
     int64_t prev_nblocks = 0, prev_w = 0, prev_h = 0;
     int prev_lgh = 0;
     bool used = false;
-    // node-flavour tuner of the stealing closest / first launches (grid_nodes = 1): two launches on
-    // the exact nodes and two on the grid nodes are timed with events, the faster flavour stays
-    int64_t gn_key = 0;     // (block count, query) the state below belongs to
-    int gn_count = 0;       // launches of the measurement in progress
-    int gn_choice = -1;     // -1 measuring, 0 exact nodes, 1 grid nodes
-    int gn_rounds = 0;      // completed measurements (the decision is final after two that agree, or three)
-    int gn_prev = -1;       // result of the previous measurement
-    int gn_since = 0;       // launches since the last decision
-    bool gn_final = false;
-    bool gn_events = false;
-    hipEvent_t gn_ev[16] = {};
     // per-lane stack overflow rows of the wide streaming launch on this stream (k_query_wide; grown on demand)
     int32_t* wspill = nullptr;
     size_t wspill_elems = 0;
-    void gn_reset() { gn_key = 0; gn_count = 0; gn_choice = -1; gn_rounds = 0; gn_prev = -1; gn_since = 0; gn_final = false; }
 };
 
 // the opaque handle ---------------------------------------------------------------------
@@ -80,7 +68,6 @@ struct tr_bvh {
     tr_qframe frame = {{0, 0, 0}, {1, 1, 1}};   // their grid: a function of the bounds below
     float aabb_min[3] = {0, 0, 0};
     float aabb_max[3] = {0, 0, 0};
-    tr_qnode* top_table = nullptr;   // grid nodes of the top TR_TOP_LEVELS levels in heap order (own 4-KiB allocation; derived data)
     void* refit_temp = nullptr;   // boxes + flags of tr_bvh_refit, kept between calls (animation loops)
     size_t refit_temp_bytes = 0;
     // adaptive launch order (speed only, see traverse.hip).  One slot per stream that has
@@ -108,7 +95,7 @@ struct tr_device_state {
     bool ready = false;
     int device = 0;
     int num_cus = 0;
-    int* counters = nullptr;        // ring of work counters for persistent launches
+    int* counters = nullptr;        // ring of scratch words (coherence probe, work counter of the streaming launch) for handles without a free scheduling slot
     unsigned next_counter = 0;
     // builder temporaries (sort buffers, boxes, hierarchy), kept between builds so that a
     // rebuild (`update_raw`) costs no hipMalloc/hipFree.  One build per device at a time.
@@ -143,8 +130,6 @@ int tr_refit_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_
 // the 8-wide nodes of a handle that already has them (bvh->wnodes != NULL) again, now, on `stream` (after update / refit);
 // a handle that never walked them builds them on first use (traverse.hip: ensure_wide)
 void tr_wide_rebuild(tr_bvh* bvh, hipStream_t stream);
-// (re)derive the heap-ordered table of the top levels from the grid nodes (after build, refit, upload)
-int tr_top_table_update(tr_bvh* bvh, hipStream_t stream);
 
 // Makes `device` current for the lifetime of the guard (every entry point that launches on or
 // copies from a handle's arena runs under one: a C caller may be on another current device).
@@ -169,38 +154,30 @@ struct tr_device_guard {
 // ONE snapshot (tr_opts()) and works from that copy, so a concurrent tr_set_option can never be
 // seen half-way through a launch decision.
 struct tr_options {
-    int persistent = 0;
-    int blocks_per_cu = 8;
-    int block_size = 128; // workgroup size of the direct kernel (64, 128 or 256)
     int adaptive = 1;     // start the blocks that were most expensive in the previous launch first
     int compact = 1;      // allow the 32-bit trail / 32-bit offset kernels when the BVH permits
     int xcd_chunk = 128;    // direct kernel: blocks per XCD-local chunk (0 = identity map)
     int steal = 1;        // intra-wave work stealing: 0 off, 1 auto (closest/first/any up to 4 M rays), >= 2 forced with that trip threshold
     int tile = 1;         // image-shaped batches: waves take 8x8 pixel tiles (0 never, 1 from 4 M rays on, 2 always)
     int tile_small = 4;   // image-shaped batches below the `tile` threshold: 0 rows of 64 pixels, 1 = 2x32, 2 = 4x16, 3 = 8x8 tiles, 4 = by triangles per ray
-    int scramble = 1;     // launches without a measured order visit each XCD's blocks in a scrambled order
     int node_layout = 1;  // order of the traversal nodes in memory (build time): 0 Karras numbering, 1 treelets of 3 levels, depth first
     int build_cache = 1;  // keep the builder's temporaries (about 130 B/triangle) per device between builds
     int stream = 1;       // streaming launch with wave-level ray refill: 0 never, 1 large non-image batches, 2 always
     int stream_rays = 256;    // rays per range of the streaming launch (512 was the optimum of the static map)
     int stream_refill = 32;   // idle lanes that trigger a refill
     int stream_dynamic = 1;   // ranges handed out by a work counter to a resident-sized grid (0: one static range per wave)
-    int unordered = 1;    // count / location (2: also any) use the unordered two-phase schedule (queued leaves)
-    int grid_nodes = 1;   // stealing closest / first launches on the 32-byte grid nodes: 0 never, 1 measured (the faster flavour of the first launches of a batch stays), 2 always
+    int grid_nodes = 1;   // stealing closest / first launches on the 32-byte grid nodes: 0 never (the exact 64-byte nodes), 1 yes, 2 any-hit launches as well
     int split = 1;        // block splitting: 0 off, 1 auto, N >= 2: the nblocks >> N most expensive blocks of the previous launch get two launch slots
     int split_steal = 8;  // ... and give subtrees away from this trip on
     int split_outlier = 1;    // ... but only blocks that cost at least N eighths of the mean block cost (0: all of them, 1: N by how full the chip is)
     int split_floor = 40;     // ... and at least this many microseconds (device clock) per wave
     int leaf_vote = 32;   // unordered schedule: lanes with a queued leaf that fire a leaf phase
-    int occ8 = 0;         // stealing closest / first launches on the grid nodes at 8 waves per SIMD (64 registers, slim hand-over scratch): 0 never, 1 from 2 M rays on, 2 always
-    int lds_top = 0;      // LDS-staged node packets for closest / first launches that steal: 0 off, 1 at 128-thread blocks, 2 at 256-thread blocks
     int order_transfer = 1;   // a batch of a new image shape starts from the previous shape's block costs, resampled (0: from the static order)
-    int wide = 2;         // the streaming launch walks 8-wide compressed nodes (tr_wide.h; built on first use): 0 never, 1 always, 2 where measured faster (>= 3 M triangles; count from 1 M triangles on)
+    int wide = 2;         // the streaming launch walks 8-wide compressed nodes (tr_wide.h; built on first use): 0 never, 1 always, 2 where measured faster (from 1 M triangles on)
     int wide_direct = 1;  // the DIRECT launch on the 8-wide nodes (k_query_direct_wide): 0 never, 1 location launches on meshes >= 500 k triangles (where measured faster), 2 count and location, 3 every query
     int wide_stack = 12;  // ... entries of a lane's node stack kept in LDS (<= 12; the rest lives in a global spill row; tests lower it)
-    int expand_cus = 0;   // tr_closest_expand (expand4 = 1): at most this many workgroups per CU, grid-stride beyond (0: one workgroup per 1024 rays)
+    int expand_cus = 0;   // tr_closest_expand: at most this many workgroups per CU, grid-stride beyond (0: one workgroup per 1024 rays)
     int expand_tiles = 1; // tr_closest_expand_slots_rows: 8x8 pixel tiles per wave on image-shaped rows (0: rows of 256 pixels)
-    int expand4 = 1;      // tr_closest_expand: 0 one ray per thread, 1 four rays per thread 256 apart, rows through buffer loads (misses fetch nothing), 2 four adjacent rays with 16-byte accesses, 3 LDS-staged tiles of 1024 rays
     int usteal = 1;       // unordered count launches hand owed subtrees over between lanes and use split launch slots: 0 off, 1 on, >= 2 forced trip threshold
 };
 tr_options tr_opts();   // snapshot by value
