@@ -80,7 +80,7 @@ typedef struct tr_trace_stats {
 /* How the last direct-launch query of a handle was shaped (diagnostics; none of it changes results). */
 typedef struct tr_launch_info {
     int64_t rays;           /* rays of the batch                                              */
-    int64_t blocks;         /* ray blocks of 128 (block_size) rays                            */
+    int64_t blocks;         /* ray blocks of 128 rays                                         */
     int64_t slots;          /* launch slots = blocks + extra slots of split blocks            */
     int32_t query;          /* TR_Q_* of the launch                                           */
     int32_t shape;          /* 0 plain, 1 stealing, 2 unordered two-phase schedule, 3 unordered + stealing */
@@ -256,52 +256,38 @@ int tr_trace_stats_closest(const tr_bvh *bvh, const tr_rays *rays, tr_trace_stat
 int tr_trace_stats_query(const tr_bvh *bvh, const tr_rays *rays, int query, tr_trace_stats *h_stats,
                    void *stream);
 
-/* -- tuning knob (process-wide): kernel variant for the query launchers.
- *    name = "adaptive" (0/1: learn the launch order from the previous launch), "compact",
- *    "xcd_chunk", "persistent" (0/1: 64-ray batches from a work counter instead of one block per
- *    128 rays), "blocks_per_cu" (int), "block_size" (64/128/256 threads of the direct
- *    kernel), "steal" (intra-wave work stealing: 0 off / 1 closest, first and any up to
- *    4 M rays / >= 2 forced, the value is the trip count from which a ray gives subtrees away),
- *    "tile" (0 never / 1 from 4 M rays on / 2 always:
- *    image-shaped batches [..., H, W, 3] with W % 8 == 0 are traced in 8x8 pixel tiles per wave),
- *    "scramble" (0/1: launches without a measured order visit each
- *    XCD's blocks in a scrambled order), "build_cache" (0/1: keep the builder's temporaries, about 130 B/triangle per
- *    device, between builds so a rebuild costs no allocation; default 1), "node_layout" (0/1, read at BUILD time: the
- *    traversal nodes are stored in Karras numbering / in treelets of three levels, depth first; default 1),
- *    "unordered" (0/1/2: count and location -- with 2 also any -- queue box-hit leaves and test
- *    them in separate wave-level leaf phases instead of on every trip; default 1), "leaf_vote"
- *    (1..64 lanes with a queued leaf that trigger such a phase), "tile_small" (0..4: pixel
- *    footprint of a wave for image-shaped batches below the "tile" threshold), "stream" (0/1/2),
- *    "stream_rays", "stream_refill", "stream_dynamic" (streaming launch with wave-level ray refill
- *    for large incoherent batches: rays per range, idle lanes that trigger a refill, ranges handed
- *    out by a work counter instead of one static range per wave), "split" (0 off / 1 auto / N >= 2: the nblocks >> N most expensive blocks of
- *    the learned launch order are traced by two -- the first quarter by four -- launch slots of
- *    half / quarter lane density whose idle lanes steal from trip "split_steal" on; of those blocks only the
- *    ones that cost at least "split_outlier" eighths of the mean block cost and at least "split_floor"
- *    microseconds per wave are really split -- decided on the device from the measured costs).
- *    "usteal" (0 off / 1 on / N >= 2 forced with that trip threshold: count launches of the unordered
- *    schedule hand owed subtrees over between the lanes of a wave and take split launch slots),
- *    "lds_top" (0 off / 1 at 128-thread blocks / 2 at 256-thread blocks: closest and first launches that
- *    steal read the grid nodes of the top 7 levels of the hierarchy from a 4-KiB table staged in LDS
- *    while a wave descends them in lockstep -- the north_star's "LDS-staged node packets"),
- *    "occ8" (0 never -- the default since round 4 -- / 1 from 2 M rays on / 2 always: stealing closest / first launches on
- *    the grid nodes take the hand-over that needs half the LDS scratch; round 3 also capped them at 64 registers for an
- *    eighth wave per SIMD, which the sign-selected slab test of round 4 no longer fits and outweighs).
- *    "grid_nodes" (0 never / 1 measured on the first launches of a batch size / 2 always: closest and first launches that steal walk the
- *    32-byte grid nodes -- two 16-byte loads per visit -- instead of the exact 64-byte nodes).
- *    "order_transfer" (0/1: the first launch of a new image resolution on a (handle, stream) starts from the block costs
- *    measured at the previous resolution, resampled onto its blocks, instead of the static order),
- *    "wide" (0 never / 1 always / 2 where measured faster -- meshes from 3 M triangles on, count launches from 1 M on: the streaming launch walks 8-wide nodes with 8-bit child boxes -- three levels of the binary
- *    hierarchy collapsed into one 96-byte record, built on the first streaming query after a build / refit / load),
- *    "wide_direct" (0 never / 1 multi-hit list launches on meshes from 500 k triangles on / 2 count and location / 3 every query: the direct launch -- tiles, learned order -- walks
- *    the 8-wide nodes with the per-lane two-stack walk of the streaming launch), "wide_stack" (1..12: entries of a lane's node stack kept in LDS; the rest spills to global memory).
- *    "expand4" (tr_closest_expand: 0 one ray per thread / 1 four rays per thread, 256 apart, mesh rows through buffer
- *    loads so that misses fetch nothing / 2 four adjacent rays per thread with 16-byte accesses where the rows are
- *    aligned / 3 tiles of 1024 rays staged through LDS), "expand_cus" (0 = one workgroup per 1024 rays; N = at most N
- *    workgroups per CU, grid-stride beyond: an expansion that runs beside a trace), "expand_tiles" (0/1:
- *    tr_closest_expand_slots_rows takes 8x8 pixel tiles per wave on image-shaped rows).
- *    None of them changes results.  Returns TR_ERR_INVALID_ARG for unknown names or values out
- *    of range.                                                                             */
+/* -- tuning knobs (process-wide; none of them changes results).  Returns TR_ERR_INVALID_ARG for unknown names or values
+ *    out of range.  Launch shapes:
+ *      "adaptive" (0/1: learn the launch order -- most expensive blocks first, per XCD -- from the measured block costs of the
+ *        previous launch of the same batch shape on the same (handle, stream)), "order_transfer" (0/1: the first launch of a
+ *        new image resolution starts from the previous resolution's costs, resampled), "xcd_chunk" (blocks of 256 rays per
+ *        XCD-local chunk of the block -> ray map, 0 = identity), "compact" (0/1: 32-bit offsets / trail words where the
+ *        hierarchy permits),
+ *      "steal" (intra-wave work stealing: 0 off / 1 closest, first and any up to 4 M rays / N >= 2 forced, N = the trip from
+ *        which a ray gives subtrees away), "usteal" (the same for count launches: 0 / 1 / N forced),
+ *      "split" (0 off / 1 auto / N >= 2: the nblocks >> N most expensive blocks of the learned order run as two -- the first
+ *        quarter as four -- launch slots of half / quarter lane density whose idle lanes steal from trip "split_steal" on;
+ *        really split are the blocks that cost at least "split_outlier" eighths of the mean block cost (0 all, 1 by how full
+ *        the chip is) and at least "split_floor" microseconds per wave),
+ *      "tile" (0 never / 1 auto / 2 always: image-shaped batches [..., H, W, 3] with W % 8 == 0 are traced in 8x8 pixel tiles
+ *        per wave), "tile_small" (0..4: footprint of a wave for images below the tile threshold: rows, 2x32, 4x16, 8x8, auto),
+ *      "leaf_vote" (1..64 lanes with a queued leaf that trigger a leaf phase of count / location launches),
+ *      "grid_nodes" (0: stealing closest / first / any launches walk the exact 64-byte nodes; 1 (default) / 2: the 32-byte
+ *        grid nodes -- two 16-byte loads per visit, one fused multiply-add per box plane),
+ *      "stream" (0 never / 1 auto: batches of 2 M rays and more that a probe on the device finds incoherent / 2 always: the
+ *        streaming launch with wave-level ray refill), "stream_rays", "stream_refill", "stream_dynamic" (rays per range,
+ *        idle lanes that trigger a refill, ranges handed out by a work counter),
+ *      "wide" (0 never / 1 always / 2 from 1 M triangles on: the streaming launch walks 8-wide nodes with 8-bit child boxes,
+ *        built on the first query that wants them), "wide_direct" (0 never / 1 multi-hit list launches on meshes from 500 k
+ *        triangles on / 2 count and location / 3 every query: the direct launch on the 8-wide nodes), "wide_stack" (1..12:
+ *        entries of a lane's node stack kept in LDS; the rest spills to global memory),
+ *      "expand_cus" (0 = one workgroup per 1024 records; N = at most N workgroups per CU: an expansion that runs beside a
+ *        trace), "expand_tiles" (0/1: tr_closest_expand_slots_rows takes blocks of 8 rows x 32 pixels per wave).
+ *    Builder: "build_cache" (0/1: keep the builder's temporaries, about 130 B/triangle per device, between builds),
+ *      "node_layout" (0/1, read at BUILD time: nodes in Karras numbering / in treelets of three levels, depth first).
+ *    Retired names are accepted and ignored (their launch shapes were measured out: DESIGN_experiments.md): "persistent",
+ *      "blocks_per_cu", "block_size", "scramble", "unordered", "occ8", "lds_top", "expand4", "tail_split", "refill",
+ *      "refill_min", "xcd_segments", "leaf_min".                                                                 */
 int tr_set_option(const char *name, int64_t value);
 
 #ifdef __cplusplus

@@ -253,7 +253,9 @@ def test_options_may_change_while_other_threads_query(device):
         for k_, v_ in {"steal": 1, "adaptive": 1, "block_size": 128, "xcd_chunk": 128, "tile": 1}.items():
             hops.set_option(k_, v_)
     with pytest.raises(ValueError):
-        hops.set_option("block_size", 100)
+        hops.set_option("stream_rays", 7)           # out of range
+    hops.set_option("block_size", 100)              # retired in round 5: accepted and ignored, like every retired name
+    hops.set_option("lds_top", 2)
     with pytest.raises(ValueError):
         hops.set_option("no_such_option", 1)
 
@@ -536,7 +538,7 @@ def test_last_launch_reports_the_shape_and_the_measured_node_flavour(device):
             assert li["rays"] == 320 * 256 and li["blocks"] == 640 and li["query"] == 2 and li["shape"] == 1
             assert li["learned_order"] == 1 and li["slots"] >= li["blocks"] and li["addressing"] in (1, 2)
             if gn == 0: assert li["grid_nodes"] == 0
-            if gn == 2: assert li["grid_nodes"] == 1
+            if gn >= 1: assert li["grid_nodes"] == 1      # (round 5: no tuner, grid nodes from the first launch on)
         r.intersects_count(ot, dt)
         li = r.as_wrapper.last_launch()
         # (shape 3 = the unordered schedule with hand-over between lanes, round 3; 2 with usteal = 0)

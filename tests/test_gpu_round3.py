@@ -77,8 +77,8 @@ def test_c5i_steady_state_launches_match_the_oracle(headline, device):
     assert last["learned_order"] == 1 and last["split_blocks"] > 0, last
     assert last["tile_rows_lg"] == 3 and last["shape"] == 1 and last["blocks"] == 8192, last
     assert last["slots"] > last["blocks"]
-    # the node-flavour tuner ran both flavours on the way (launches 0-4 exact, 5-8 grid)
-    assert {i["grid_nodes"] for i in infos} == {0, 1}, [i["grid_nodes"] for i in infos]
+    # round 5: no node-flavour tuner any more -- the grid nodes (fused box test) from the first launch on
+    assert {i["grid_nodes"] for i in infos} == {1}, [i["grid_nodes"] for i in infos]
 
 
 def test_c5i_moving_camera_sequence_matches_the_oracle(headline, device):

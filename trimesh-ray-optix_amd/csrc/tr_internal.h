@@ -166,7 +166,7 @@ struct tr_options {
     int stream_rays = 256;    // rays per range of the streaming launch (512 was the optimum of the static map)
     int stream_refill = 32;   // idle lanes that trigger a refill
     int stream_dynamic = 1;   // ranges handed out by a work counter to a resident-sized grid (0: one static range per wave)
-    int grid_nodes = 1;   // stealing closest / first launches on the 32-byte grid nodes: 0 never (the exact 64-byte nodes), 1 yes, 2 any-hit launches as well
+    int grid_nodes = 1;   // stealing closest / first / any launches on the 32-byte grid nodes: 0 never (the exact 64-byte nodes), 1 / 2 yes
     int split = 1;        // block splitting: 0 off, 1 auto, N >= 2: the nblocks >> N most expensive blocks of the previous launch get two launch slots
     int split_steal = 8;  // ... and give subtrees away from this trip on
     int split_outlier = 1;    // ... but only blocks that cost at least N eighths of the mean block cost (0: all of them, 1: N by how full the chip is)
