@@ -64,7 +64,7 @@ def loops(ins):
     return out
 
 
-def scratch_in_trip_loops(so, want, marker="v_perm_b32"):
+def scratch_in_trip_loops(so, want, marker="v_perm_b32", smallest_only=False):
     """scratch instructions inside the innermost loops that hold a `marker` instruction (the grid nodes' box test = the
     traversal trips), per kernel whose demangled name contains `want`: {name: [instruction text]}"""
     res = {}
@@ -78,6 +78,8 @@ def scratch_in_trip_loops(so, want, marker="v_perm_b32"):
             inner = [sp for sp in lp if sp[0] <= p <= sp[1]]
             if inner:
                 spans.add(min(inner, key=lambda sp: sp[1] - sp[0]))
+        if smallest_only and spans:       # (a marker may also sit outside the trips, e.g. the root visit of a refill)
+            spans = {min(spans, key=lambda sp: sp[1] - sp[0])}
         res[name] = [ins[i][1] for (a, z) in spans for i in range(a, z + 1) if ins[i][1].startswith("scratch_")]
     return res
 
