@@ -396,14 +396,16 @@ def run_rank(args):
         dev = torch.device("cuda", local_dev)
     dist = None
     ctrl = None
+    nccl_ok = True
     if dist_on:
         import datetime
         import torch.distributed as dist
         if gloo:
             dist.init_process_group("gloo")
         else:
-            # (a collective that never completes ends the run after ten minutes instead of never)
-            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=10))
+            # (a collective that never completes ends the run after ten minutes instead of never; no device_id: the RCCL
+            # communicator is created by the first collective -- the smoke test below --, where a failure can be caught)
+            dist.init_process_group("nccl", timeout=datetime.timedelta(minutes=10))
         world = dist.get_world_size()          # the ranks the communicator actually has
         if world != args.gpus:
             print(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks; reporting n_gpus={world}",
@@ -416,6 +418,24 @@ def run_rank(args):
             except Exception as exc:      # noqa: BLE001
                 print(f"bench.py: no gloo control group ({exc}); the preflight's verdicts use the RCCL communicator", file=sys.stderr)
                 ctrl = None
+        # RCCL smoke test: one 4-byte all-reduce + a device synchronisation, verdict agreed on the control group.  If the
+        # communicator cannot even do that on some rank, the whole run -- barriers, timing reduction, data -- moves to the
+        # gloo group (exchange mode "staged"): a slow line instead of no line.
+        if not gloo and ctrl is not None:
+            ok_ = True
+            try:
+                t_ = torch.ones(1, dtype=torch.int32, device=dev)
+                dist.all_reduce(t_)
+                torch.cuda.synchronize()
+                ok_ = int(t_.item()) == world
+            except Exception as exc:      # noqa: BLE001
+                ok_ = False
+                print(f"bench.py: rank {rank}: RCCL smoke test failed: {type(exc).__name__}: {exc}", file=sys.stderr)
+            v_ = torch.tensor([1 if ok_ else 0], dtype=torch.int32)
+            dist.all_reduce(v_, op=dist.ReduceOp.MIN, group=ctrl)
+            nccl_ok = bool(int(v_.item()) == 1)
+            if not nccl_ok and rank == 0:
+                print("bench.py: RCCL is unusable on this node: the run falls back to gloo (results staged through the host)", file=sys.stderr)
     elif args.gpus != 1:
         raise SystemExit("internal error: run_rank with --gpus > 1 outside a launcher")
 
@@ -454,7 +474,9 @@ def run_rank(args):
 
     gather_on = dist_on and (world > 1 or args.force_gather) and not args.no_gather
     S = ShardedRayMeshIntersector(r, force_collectives=args.force_gather, dst_share=share, ctrl_group=ctrl) if dist_on else None
-    if S is not None and args.exchange:
+    if S is not None and not nccl_ok:
+        S.set_exchange_mode("staged")
+    elif S is not None and args.exchange:
         S.set_exchange_mode(args.exchange)
     elif S is not None and args.records == "packed" and S.exchange_mode == "slot":
         S.set_exchange_mode("packed")
@@ -499,7 +521,7 @@ def run_rank(args):
 
     def barrier():
         if dist_on:
-            dist.barrier()
+            dist.barrier(group=None if nccl_ok else ctrl)
         sync()
 
     def event_pair():
@@ -521,9 +543,10 @@ def run_rank(args):
         return [a.elapsed_time(b) for a, b in ev] if not stub else [0.0] * count
 
     def max_over_ranks(x):
-        t = torch.tensor([x], dtype=torch.float64, device="cpu" if gloo else dev)
+        cpu_ = gloo or not nccl_ok
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if cpu_ else dev)
         if dist_on:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=None if nccl_ok else ctrl)
         return float(t.item())
 
     def timed_region(run, steps, warmup, min_warmup_ms, stride=None):
@@ -773,6 +796,7 @@ def run_rank(args):
                                        f"--min-warmup-ms {args.min_warmup_ms:g} of further launches); `value_warmup_requested` = exactly "
                                        f"--warmup {args.warmup} launches, then {args.steps} timed steps (SURVEY.md 8d's protocol)") if proto else None,
                        "exchange_mode_used": (exchange or {}).get("exchange_mode_used") if gather_on or exchange else None,
+                       "rccl_ok": (nccl_ok if (dist_on and not gloo) else None),
                        "exchange": exchange,
                        "bvh_depth": info["depth"], "bvh_bytes": int(bvh_bytes), "bvh_build_ms": round(build_ms, 2),
                        "hit_fraction": round(float(hit0.float().mean().item()), 4) if hit0 is not None else None},
@@ -967,7 +991,7 @@ def run_rank(args):
         print("bench.py: the last timed step's outputs differ from the first call's -- a scheduling hint changed results",
               file=sys.stderr)
     if dist_on:
-        dist.barrier()
+        dist.barrier(group=None if nccl_ok else ctrl)
         dist.destroy_process_group()
     return 3 if verified is False else 0
 
@@ -1244,6 +1268,7 @@ def run_emulation(args):
 
 
 def main(argv=None):
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes on this driver), before anything touches HIP
     argv = sys.argv[1:] if argv is None else list(argv)
     args = parse(argv)
     if args.gpus < 1:

@@ -276,7 +276,7 @@ int tr_trace_stats_query(const tr_bvh *bvh, const tr_rays *rays, int query, tr_t
  *        grid nodes -- two 16-byte loads per visit, one fused multiply-add per box plane),
  *      "stream" (0 never / 1 auto: batches of 2 M rays and more that a probe on the device finds incoherent / 2 always: the
  *        streaming launch with wave-level ray refill), "stream_rays", "stream_refill", "stream_dynamic" (rays per range,
- *        idle lanes that trigger a refill, ranges handed out by a work counter),
+ *        idle lanes that trigger a refill -- 0 = by query: 28 closest / first, 20 any / count --, ranges handed out by a work counter),
  *      "wide" (0 never / 1 always / 2 from 1 M triangles on: the streaming launch walks 8-wide nodes with 8-bit child boxes,
  *        built on the first query that wants them), "wide_direct" (0 never / 1 multi-hit list launches on meshes from 500 k
  *        triangles on / 2 count and location / 3 every query: the direct launch on the 8-wide nodes), "wide_stack" (1..12:

@@ -18,7 +18,7 @@ dev = torch.device("cuda:0")
 T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
 DEFAULTS = {"steal": 1, "tile": 1, "block_size": 128, "adaptive": 1, "xcd_chunk": 128, "compact": 1, "scramble": 1,
             "persistent": 0, "blocks_per_cu": 8,
-            "tile_small": 4, "unordered": 1, "leaf_vote": 32, "stream": 1, "stream_rays": 256, "stream_refill": 32, "stream_dynamic": 1,
+            "tile_small": 4, "unordered": 1, "leaf_vote": 32, "stream": 1, "stream_rays": 256, "stream_refill": 0, "stream_dynamic": 1,
             "split": 1, "split_steal": 8, "grid_nodes": 1, "split_outlier": 1, "split_floor": 40, "usteal": 1, "lds_top": 0, "occ8": 0,
             "wide": 2, "wide_stack": 12, "wide_direct": 1, "expand4": 1, "expand_cus": 0, "expand_tiles": 1}
 bad = 0
@@ -62,7 +62,7 @@ for it in range(a.iters):
             # streaming launch with wave-level ray refill (2 = forced at any size and shape)
             "tile_small": int(rng.choice([0, 1, 2, 3, 4])),
             "stream": int(rng.choice([0, 1, 2, 2])), "stream_rays": int(rng.choice([64, 100, 512, 4096])),
-            "stream_refill": int(rng.choice([1, 8, 16, 40, 64])), "stream_dynamic": int(rng.choice([0, 1, 1])),
+            "stream_refill": int(rng.choice([0, 1, 8, 16, 40, 64])), "stream_dynamic": int(rng.choice([0, 1, 1])),
             # block splitting of the stealing launch shapes (from the second launch of a batch on)
             "split": int(rng.choice([0, 1, 1, 2, 3, 4])), "split_steal": int(rng.choice([0, 2, 8, 64])),
             "grid_nodes": int(rng.choice([0, 1, 2, 2])),

@@ -382,7 +382,7 @@ def test_streaming_launch_with_ray_refill_matches_the_oracle(device, rays_per_wa
     finally:
         hops.set_option("stream", 1)
         hops.set_option("stream_rays", 256)
-        hops.set_option("stream_refill", 32)
+        hops.set_option("stream_refill", 0)
         hops.set_option("stream_dynamic", 1)
 
 

@@ -20,7 +20,7 @@ def opts():
             saved.setdefault(k, None)
             hops.set_option(k, v)
     yield set_
-    defaults = {"stream": 1, "wide": 2, "wide_stack": 12, "stream_rays": 256, "stream_refill": 32, "wide_direct": 1, "adaptive": 1}
+    defaults = {"stream": 1, "wide": 2, "wide_stack": 12, "stream_rays": 256, "stream_refill": 0, "wide_direct": 1, "adaptive": 1}
     for k in saved:
         hops.set_option(k, defaults[k])
 

@@ -32,7 +32,7 @@ const opt_desc OPTS[] = {
     {"node_layout", &tr_options::node_layout, 0, 1, true},
     {"stream", &tr_options::stream, 0, 2, false},
     {"stream_rays", &tr_options::stream_rays, 64, 1 << 20, false},
-    {"stream_refill", &tr_options::stream_refill, 1, 64, false},
+    {"stream_refill", &tr_options::stream_refill, 0, 64, false},
     {"stream_dynamic", &tr_options::stream_dynamic, 0, 1, false},
     {"leaf_vote", &tr_options::leaf_vote, 1, 64, false},
     {"grid_nodes", &tr_options::grid_nodes, 0, 2, false},

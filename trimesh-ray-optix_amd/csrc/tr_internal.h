@@ -164,7 +164,7 @@ struct tr_options {
     int build_cache = 1;  // keep the builder's temporaries (about 130 B/triangle) per device between builds
     int stream = 1;       // streaming launch with wave-level ray refill: 0 never, 1 large non-image batches, 2 always
     int stream_rays = 256;    // rays per range of the streaming launch (512 was the optimum of the static map)
-    int stream_refill = 32;   // idle lanes that trigger a refill
+    int stream_refill = 0;    // idle lanes that trigger a refill (0 = by query: 28 closest / first, 20 any / count)
     int stream_dynamic = 1;   // ranges handed out by a work counter to a resident-sized grid (0: one static range per wave)
     int grid_nodes = 1;   // stealing closest / first / any launches on the 32-byte grid nodes: 0 never (the exact 64-byte nodes), 1 / 2 yes
     int split = 1;        // block splitting: 0 off, 1 auto, N >= 2: the nblocks >> N most expensive blocks of the previous launch get two launch slots
