@@ -46,7 +46,9 @@ BYTES_PER_RAY_CLOSEST = 50      # 24 B in + 26 B out
 # (expansion alone / trace, measured on one MI355X: profiles/r04_emulate_records.jsonl, + a margin for the receive):
 # c5i: 0.2 ms per M pinhole rays against 0.0127 (4-byte records + the ray) / 0.0092 (12-byte records) ms per M records;
 # c5ii: 0.137 ms per M incoherent rays against 0.0150 / 0.0132
-AUTO_RHO = {("c5i", "slot"): 0.08, ("c5i", "packed"): 0.06, ("c5ii", "slot"): 0.11, ("c5ii", "packed"): 0.10}
+# (round 5: the trace got 7 % faster -- the fused box test --, the expansion did not: the ratios moved accordingly, re-derived
+# from the emulated rank-0 / peer steps of profiles/r05_emulate_final.jsonl and r05_emulate_records.jsonl)
+AUTO_RHO = {("c5i", "slot"): 0.092, ("c5i", "packed"): 0.064, ("c5ii", "slot"): 0.121, ("c5ii", "packed"): 0.101}
 
 
 def resolve_share(args, world):
