@@ -89,7 +89,7 @@ typedef struct tr_launch_info {
     int32_t learned_order;  /* 1: the launch used a learned launch order                      */
     int32_t grid_nodes;     /* 1: the launch walked the 32-byte grid nodes, 0: the exact ones */
     int32_t addressing;     /* 0: 64-bit, 1: 32-bit offsets + 32-bit trail, 2: 32-bit offsets + 64-bit trail */
-    int32_t reserved;
+    int32_t sort_carried;   /* 1: the launch carried the deferred sort of the last measured block costs (option sort_inline) */
 } tr_launch_info;
 
 /* -- runtime bring-up: replaces initOptix/createOptixContext/createOptixModule/
@@ -260,7 +260,9 @@ int tr_trace_stats_query(const tr_bvh *bvh, const tr_rays *rays, int query, tr_t
  *    out of range.  Launch shapes:
  *      "adaptive" (0/1: learn the launch order -- most expensive blocks first, per XCD -- from the measured block costs of the
  *        previous launch of the same batch shape on the same (handle, stream)), "order_transfer" (0/1: the first launch of a
- *        new image resolution starts from the previous resolution's costs, resampled), "xcd_chunk" (blocks of 256 rays per
+ *        new image resolution starts from the previous resolution's costs, resampled), "sort_inline" (0/1: in the steady
+ *        state the sort of the measured costs rides in the next launch of the shape as one workgroup instead of running as
+ *        a kernel behind the measuring launch), "xcd_chunk" (blocks of 256 rays per
  *        XCD-local chunk of the block -> ray map, 0 = identity), "compact" (0/1: 32-bit offsets / trail words where the
  *        hierarchy permits),
  *      "steal" (intra-wave work stealing: 0 off / 1 closest, first and any up to 4 M rays / N >= 2 forced, N = the trip from

@@ -85,3 +85,58 @@ def test_fused_box_test_on_rays_that_stress_its_margins(device, case):
     finally:
         for k, val in {"grid_nodes": 1, "stream": 1, "wide": 2, "wide_direct": 1, "adaptive": 1}.items():
             hops.set_option(k, val)
+
+
+def test_deferred_sort_rides_in_the_next_launch(device):
+    """option sort_inline (default): from a batch shape's fourth launch on, the sort of the measured block costs is not a
+    kernel behind the measuring launch but a workgroup of the NEXT launch of that shape (query_direct_body, tr_sort_job),
+    which still reads the old order.  Every launch equals the oracle; the carrying launches are the ones right after a
+    measuring one; a rebuild, a change of shape or of query between the two runs the pending sort as a kernel; the orders
+    stay valid (learned order + split blocks) throughout; sort_inline = 0 gives the same results."""
+    from triro.backend import ops as hops
+    v, f = W.icosphere(6)
+    v = W.displaced(v, seed=3)
+    res = 256
+    o, d = W.pinhole_grid(res, res, distance=2.5 * float(np.linalg.norm(v, axis=1).max()))
+    exp = OracleIntersector(v, f).intersects_closest(np.ascontiguousarray(o).reshape(-1, 3), d.reshape(-1, 3))
+    exp = [e.reshape(res, res, *e.shape[1:]) for e in exp[:5]]
+    O, D = T(np.ascontiguousarray(o), device), T(d, device)
+    r = make(v, f, device)
+    carried = []
+    for k in range(14):
+        got = r.intersects_closest(O, D)
+        assert_closest_bitexact(got, exp, f"launch {k}")
+        li = r.as_wrapper.last_launch()
+        carried.append(li["sort_carried"])
+        if k >= 2:
+            assert li["learned_order"] == 1 and li["shape"] == 1 and li["grid_nodes"] == 1
+    # launches count from 1 in the slot: the 1st (plain shape) .. then measuring when launches < 3 or launches % 4 == 3
+    assert sum(carried) >= 2 and carried[:4] == [0, 0, 0, 0], carried
+    first = carried.index(1)
+    assert carried[first::4][:2] == [1, 1] and sum(carried[first:first + 4]) == 1, carried
+    # a pending sort meets a launch that cannot carry it: any-hit (another kernel), another shape, a rebuild
+    for _ in range(8):              # on to the launch right after a carrying one ...
+        r.intersects_closest(O, D)
+        if r.as_wrapper.last_launch()["sort_carried"]:
+            break
+    assert r.as_wrapper.last_launch()["sort_carried"] == 1
+    for _ in range(2):              # ... two more without measurement ...
+        r.intersects_closest(O, D)
+    r.intersects_closest(O, D)      # ... and the measuring one: its sort is pending now
+    assert np.array_equal(r.intersects_any(O, D).cpu().numpy(), exp[0])
+    assert_closest_bitexact(r.intersects_closest(O, D), exp, "after an any-hit launch in between")
+    for _ in range(8):
+        assert_closest_bitexact(r.intersects_closest(O[: res // 2], D[: res // 2]), [e[: res // 2] for e in exp], "half image")
+        assert_closest_bitexact(r.intersects_closest(O, D), exp, "full image again")
+    r.update_raw(torch.from_numpy(v).to(device), torch.from_numpy(f).to(device))
+    for k in range(10):
+        assert_closest_bitexact(r.intersects_closest(O, D), exp, f"after the rebuild, launch {k}")
+    assert r.as_wrapper.last_launch()["learned_order"] == 1
+    hops.set_option("sort_inline", 0)
+    try:
+        r2 = make(v, f, device)
+        for k in range(10):
+            assert_closest_bitexact(r2.intersects_closest(O, D), exp, f"sort_inline=0, launch {k}")
+            assert r2.as_wrapper.last_launch()["sort_carried"] == 0
+    finally:
+        hops.set_option("sort_inline", 1)

@@ -44,6 +44,7 @@ const opt_desc OPTS[] = {
     {"expand_cus", &tr_options::expand_cus, 0, 64, false},
     {"expand_tiles", &tr_options::expand_tiles, 0, 1, true},
     {"order_transfer", &tr_options::order_transfer, 0, 1, true},
+    {"sort_inline", &tr_options::sort_inline, 0, 1, true},
     {"wide", &tr_options::wide, 0, 2, false},
     {"wide_stack", &tr_options::wide_stack, 1, 12, false},
     {"wide_direct", &tr_options::wide_direct, 0, 3, false},

@@ -30,7 +30,8 @@ int tr_fail(int code, const std::string& msg);
     } while (0)
 
 // adaptive launch order: per (handle, stream) measured block costs and the order derived from
-// them.  buf = cost[TR_SCHED_MAX] | order[TR_SCHED_MAX]
+// them.  buf = cost[TR_SCHED_MAX] | order 0 + its stamp | launch scratch | costs of the last sort | order 1 + its stamp
+// (launch_policy.inc)
 constexpr int TR_SCHED_MAX = 131072;  // blocks (x256 rays) up to which the order is learned
 constexpr int TR_SCHED_SLOTS = 16;   // (stream, class) pairs per handle: 8 streams x {plain, split} orders
 struct tr_sched_slot {
@@ -46,6 +47,13 @@ struct tr_sched_slot {
     int64_t prev_nblocks = 0, prev_w = 0, prev_h = 0;
     int prev_lgh = 0;
     bool used = false;
+    // Two order buffers: launches read order_buf(cur) while a sort writes the other one.  A sort that was DEFERRED
+    // (`pending`: the costs of the last measuring launch are still unsorted) rides in the next launch of the same shape
+    // as an extra workgroup (tr_sort_job, query_direct_body) or, if that launch cannot carry it, runs as k_sched_sort
+    // before it; p_* = what that sort needs.
+    int cur = 0;
+    bool pending = false;
+    int p_nblocks = 0, p_xc = 0, p_split = 0, p_split4 = 0, p_outlier8 = 0, p_floor = 0;
     // per-lane stack overflow rows of the wide streaming launch on this stream (k_query_wide; grown on demand)
     int32_t* wspill = nullptr;
     size_t wspill_elems = 0;
@@ -173,6 +181,7 @@ struct tr_options {
     int split_floor = 40;     // ... and at least this many microseconds (device clock) per wave
     int leaf_vote = 32;   // unordered schedule: lanes with a queued leaf that fire a leaf phase
     int order_transfer = 1;   // a batch of a new image shape starts from the previous shape's block costs, resampled (0: from the static order)
+    int sort_inline = 1;      // the steady-state sort of the block costs rides in the next launch as a workgroup (0: a kernel behind every measuring launch)
     int wide = 2;         // the streaming launch walks 8-wide compressed nodes (tr_wide.h; built on first use): 0 never, 1 always, 2 where measured faster (from 1 M triangles on)
     int wide_direct = 1;  // the DIRECT launch on the 8-wide nodes (k_query_direct_wide): 0 never, 1 location launches on meshes >= 500 k triangles (where measured faster), 2 count and location, 3 every query
     int wide_stack = 12;  // ... entries of a lane's node stack kept in LDS (<= 12; the rest lives in a global spill row; tests lower it)

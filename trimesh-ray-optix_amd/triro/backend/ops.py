@@ -52,7 +52,7 @@ class TrLaunchInfo(C.Structure):
     _fields_ = [("rays", C.c_int64), ("blocks", C.c_int64), ("slots", C.c_int64), ("query", C.c_int32),
                 ("shape", C.c_int32), ("tile_rows_lg", C.c_int32), ("split_blocks", C.c_int32),
                 ("learned_order", C.c_int32), ("grid_nodes", C.c_int32), ("addressing", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("sort_carried", C.c_int32)]
 
 
 class TrTraceStats(C.Structure):

@@ -343,7 +343,7 @@ class OptixAccelStructureWrapper:
         """shape of the last query that took the direct launch (diagnostics; tr_bvh_last_launch)"""
         li = hops.TrLaunchInfo()
         hops._check(hops.get_module().tr_bvh_last_launch(self._inner, C.byref(li)))
-        return {k: int(getattr(li, k)) for k, _ in li._fields_ if k != "reserved"}
+        return {k: int(getattr(li, k)) for k, _ in li._fields_}
 
     def info(self) -> dict:
         inf = hops.TrBvhInfo()
