@@ -114,7 +114,7 @@ def test_deferred_sort_rides_in_the_next_launch(device):
     assert sum(carried) >= 2 and carried[:4] == [0, 0, 0, 0], carried
     first = carried.index(1)
     assert carried[first::4][:2] == [1, 1] and sum(carried[first:first + 4]) == 1, carried
-    # a pending sort meets a launch that cannot carry it: any-hit (another kernel), another shape, a rebuild
+    # a pending sort meets another query, another shape, a rebuild
     for _ in range(8):              # on to the launch right after a carrying one ...
         r.intersects_closest(O, D)
         if r.as_wrapper.last_launch()["sort_carried"]:
@@ -128,6 +128,11 @@ def test_deferred_sort_rides_in_the_next_launch(device):
     for _ in range(8):
         assert_closest_bitexact(r.intersects_closest(O[: res // 2], D[: res // 2]), [e[: res // 2] for e in exp], "half image")
         assert_closest_bitexact(r.intersects_closest(O, D), exp, "full image again")
+    flags = []
+    for k in range(12):             # any-hit launches carry it too (their own instantiation of the carrying kernel)
+        assert np.array_equal(r.intersects_any(O, D).cpu().numpy(), exp[0]), f"any-hit launch {k}"
+        flags.append(r.as_wrapper.last_launch()["sort_carried"])
+    assert sum(flags) >= 2, flags
     r.update_raw(torch.from_numpy(v).to(device), torch.from_numpy(f).to(device))
     for k in range(10):
         assert_closest_bitexact(r.intersects_closest(O, D), exp, f"after the rebuild, launch {k}")
