@@ -20,7 +20,7 @@ DEFAULTS = {"steal": 1, "tile": 1, "block_size": 128, "adaptive": 1, "xcd_chunk"
             "persistent": 0, "blocks_per_cu": 8,
             "tile_small": 4, "unordered": 1, "leaf_vote": 32, "stream": 1, "stream_rays": 256, "stream_refill": 0, "stream_dynamic": 1,
             "split": 1, "split_steal": 8, "grid_nodes": 1, "split_outlier": 1, "split_floor": 40, "usteal": 1, "lds_top": 0, "occ8": 0,
-            "wide": 2, "wide_stack": 12, "wide_direct": 1, "expand4": 1, "expand_cus": 0, "expand_tiles": 1}
+            "wide": 2, "wide_stack": 12, "wide_direct": 1, "expand4": 1, "expand_cus": 0, "expand_tiles": 1, "sort_inline": 1}
 bad = 0
 for it in range(a.iters):
     kind = rng.integers(0, 5)
@@ -71,12 +71,14 @@ for it in range(a.iters):
             "usteal": int(rng.choice([0, 1, 1, 2, 8, 64])), "lds_top": int(rng.choice([0, 0, 1, 2])), "occ8": int(rng.choice([0, 1, 2, 2])),
             # round 4: 8-wide compressed nodes (streaming launch, direct launch), their stack split, the expansion kernels
             "wide": int(rng.choice([0, 1, 1, 2])), "wide_stack": int(rng.choice([1, 2, 5, 12])), "wide_direct": int(rng.choice([0, 1, 2, 3, 3])),
-            "expand4": int(rng.choice([0, 1, 1, 2, 3])), "expand_cus": int(rng.choice([0, 0, 1, 3])), "expand_tiles": int(rng.choice([0, 1]))}
+            "expand4": int(rng.choice([0, 1, 1, 2, 3])), "expand_cus": int(rng.choice([0, 0, 1, 3])), "expand_tiles": int(rng.choice([0, 1])),
+            # round 5: the deferred sort of the learned order as a workgroup of the next launch
+            "sort_inline": int(rng.choice([0, 1, 1, 1]))}
     for k, val in opts.items(): hops.set_option(k, val)
     try:
         r = RayMeshIntersector(vertices=T(v), faces=T(f)); R = OracleIntersector(v, f, 1)
         ot, dt = T(o), T(d); of, df = o.reshape(-1, 3), d.reshape(-1, 3)
-        for rep in range(3):
+        for rep in range(5 if (opts["adaptive"] and o.size >= 3 * 8192) else 3):     # (enough launches of a shape for its steady state: deferred sorts)
             hit, front, tri, loc, uv = [x.cpu().numpy() for x in r.intersects_closest(ot, dt)]
             eh, ef, et, el, eu = R.closest_raw(of, df)[:5]
             ok = (np.array_equal(hit.reshape(-1), eh) and np.array_equal(front.reshape(-1), ef) and np.array_equal(tri.reshape(-1), et)
