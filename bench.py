@@ -557,9 +557,10 @@ def run_rank(args):
         pairs on the launch stream give the per-step GPU time."""
         import gc
         if stride is None:
-            stride = max(1, int(args.event_stride)) if args.event_stride else max(1, steps // min(64, max(6, steps // 3)))
+            stride = max(1, int(args.event_stride)) if args.event_stride else max(1, steps // min(64, max(4, steps // 5)))
             if not args.event_stride and stride % 2 == 0:
-                stride += 1          # (odd: the block-cost sort runs behind every 4th launch -- the samples must not lock onto it)
+                stride += 1          # (odd: every 4th launch measures its block costs, the one behind it carries their sort -- the samples must not
+                                     # lock onto either; a 20-step run keeps 4 pairs: a pair costs the wall clock ~5 us, 7 of them were 1 % of such a run)
         ev = [event_pair() if k % stride == 0 else None for k in range(steps)]
         gc.collect()
         gc.disable()            # a step is ~0.3 ms: keep collector pauses out of the timed region
