@@ -25,14 +25,8 @@ def test_no_query_kernel_of_the_shipped_library_spills():
     ks = [k for k in con.kernels(so) if "k_query" in k["name"]]
     assert len(ks) > 50
     stream = [k for k in ks if k["name"].startswith("void k_query_stream<") or k["name"].startswith("void k_query_wide<")]
-    # ... and a second one: the unordered count launch with stealing asks for seven waves (72 registers against 78), 5-11
-    # kernel-lifetime values in scratch, none inside the trips (profiles/r05_ab_count_waves.txt)
-    count7 = [k for k in ks if k["name"].startswith("void k_query_count_steal<")]
-    bad = [(k["name"], k["vgpr_spill"], k["scratch"]) for k in ks if k not in stream and k not in count7 and (k["vgpr_spill"] != 0 or k["scratch"] != 0)]
+    bad = [(k["name"], k["vgpr_spill"], k["scratch"]) for k in ks if k not in stream and (k["vgpr_spill"] != 0 or k["scratch"] != 0)]
     assert not bad, bad
-    assert len(count7) == 3 and all(k["vgpr_spill"] <= 12 and k["vgpr"] <= 72 for k in count7), [(k["name"], k["vgpr"], k["vgpr_spill"]) for k in count7]
-    inside = isa_loops.scratch_in_trip_loops(so, "k_query_count_steal<")
-    assert inside and not any(inside.values()), inside
     assert stream and all(k["vgpr_spill"] <= 8 and k["vgpr"] <= 96 for k in stream), [(k["name"], k["vgpr"], k["vgpr_spill"]) for k in stream]
     inside = isa_loops.scratch_in_trip_loops(so, "k_query_stream<")
     assert inside and not any(inside.values()), inside
