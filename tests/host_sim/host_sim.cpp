@@ -246,14 +246,15 @@ int sim_key_mode(void* h) { return ((SimBvh*)h)->key_mode; }
 int64_t sim_num_nodes(void* h) { return (int64_t)((SimBvh*)h)->nodes.size(); }
 void sim_get_qnodes(void* h, void* qnodes, float* frame6) {
     SimBvh* b = (SimBvh*)h;
-    if (qnodes) memcpy(qnodes, b->qnodes.data(), b->qnodes.size() * sizeof(tr_qnode));
+    if (qnodes && !b->qnodes.empty()) memcpy(qnodes, b->qnodes.data(), b->qnodes.size() * sizeof(tr_qnode));
     for (int k = 0; k < 3; k++) { frame6[k] = b->frame.base[k]; frame6[3 + k] = b->frame.scale[k]; }
 }
 void sim_get(void* h, void* nodes, void* links, void* tris) {
     SimBvh* b = (SimBvh*)h;
-    if (nodes) memcpy(nodes, b->nodes.data(), b->nodes.size() * sizeof(tr_node));
-    if (links) memcpy(links, b->links.data(), b->links.size() * sizeof(tr_link));
-    if (tris) memcpy(tris, b->tris.data(), b->tris.size() * sizeof(tr_tri));
+    // (a single-triangle mesh has no nodes: memcpy from a null pointer is undefined even for zero bytes)
+    if (nodes && !b->nodes.empty()) memcpy(nodes, b->nodes.data(), b->nodes.size() * sizeof(tr_node));
+    if (links && !b->links.empty()) memcpy(links, b->links.data(), b->links.size() * sizeof(tr_link));
+    if (tris && !b->tris.empty()) memcpy(tris, b->tris.data(), b->tris.size() * sizeof(tr_tri));
 }
 }  // extern "C"
 
