@@ -499,6 +499,20 @@ def test_large_meshes_deep_trees_and_arrays_above_4gib(device, subdiv):
     o2, d2 = W.hash_rays_torch(2_200_000, 5, v.min(0) * 1.5, v.max(0) * 1.5, device=device)   # streaming launch
     h2 = r.intersects_closest(o2, d2)
     assert torch.equal(h2[0], r.intersects_any(o2, d2)) and torch.equal(h2[2], r.intersects_first(o2, d2))
+    # the same batch through the streaming launch on the BINARY nodes (option wide = 0: the instantiations for hierarchies
+    # of more than 32 levels, which run at a forced occupancy with a few spilled registers since round 5) and through the
+    # direct launch (stream = 0): the same bits
+    from triro.backend import ops as hops
+    c2 = r.intersects_count(o2, d2)
+    for name, val in (("wide", 0), ("stream", 0)):
+        hops.set_option(name, val)
+        try:
+            g2 = r.intersects_closest(o2, d2)
+            assert all(torch.equal(a, b) for a, b in zip(g2, h2)), name
+            assert torch.equal(r.intersects_any(o2, d2), h2[0]) and torch.equal(r.intersects_first(o2, d2), h2[2])
+            assert torch.equal(r.intersects_count(o2, d2), c2)
+        finally:
+            hops.set_option(name, 2 if name == "wide" else 1)
     r2 = make(v, f, device)
     hit2, front2, tri2, loc2, uv2 = r2.intersects_closest(ot, dt)
     assert torch.equal(tri2, tri) and torch.equal(loc2, loc) and torch.equal(uv2, uv) and torch.equal(front2, front)
