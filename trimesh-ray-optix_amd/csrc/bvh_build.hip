@@ -530,8 +530,8 @@ int tr_build_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_
     bvh->key_mode = 0;
     // A learned launch order describes the rays, not the mesh: after a rebuild (an animation step,
     // `update_raw`) it is one frame stale, which is a far better hint than none -- keep it and
-    // measure again on the next launches
-    // (the node-flavour tuner starts over: its measurement windows are counted in launches of this mesh)
+    // measure again on the next launches (a deferred sort of the last measurement, if one is pending, runs before them:
+    // sched_acquire)
     for (int k = 0; k < TR_SCHED_SLOTS; k++) { bvh->sched[k].launches = 0; }
     for (int k = 0; k < 3; k++) { bvh->aabb_min[k] = 0.f; bvh->aabb_max[k] = 0.f; }
     if (nf == 0) return TR_OK;
