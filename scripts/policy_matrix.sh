@@ -5,7 +5,7 @@
 CFG=${1:-terrain}
 RESES=${2:-"640 1024 1920"}
 for RES in $RESES; do
-for O in "" "--opt split=0" "--opt tile=0 --opt tile_small=0" "--opt tile=2" "--opt grid_nodes=0" "--opt grid_nodes=2" "--opt steal=0" "--opt adaptive=0" "--opt split_outlier=0" "--opt occ8=2" "--opt wide_direct=3" ""; do
+for O in "" "--opt split=0" "--opt tile=0 --opt tile_small=0" "--opt tile=2" "--opt grid_nodes=0" "--opt grid_nodes=2" "--opt steal=0" "--opt adaptive=0" "--opt split_outlier=0" "--opt sort_inline=0" "--opt wide_direct=3" ""; do
   timeout 180 python scripts/run_query.py --config $CFG --query closest --res $RES --steps 100 --warmup 40 $O 2>/dev/null | python3 -c "import sys,json; r=json.loads(sys.stdin.read()); print('$CFG', r['rays'], 'closest', '$O' or 'auto', r['ms_mean'], r['ms_min'])"
 done
 done
