@@ -10,6 +10,10 @@ import numpy as np, torch
 import workloads as W
 from triro.ray.ray_optix import RayMeshIntersector
 dev = torch.device("cuda:0")
+from triro.backend import ops as hops
+OPTS = [a for a in sys.argv[1:] if "=" in a]
+for a in OPTS:
+    k, val = a.split("="); hops.set_option(k, int(val))
 v, f = W.headline_mesh(8)
 r = RayMeshIntersector(vertices=torch.from_numpy(v).to(dev), faces=torch.from_numpy(f).to(dev))
 rad = float(np.linalg.norm(v, axis=1).max())
@@ -48,4 +52,5 @@ for rep in range(2):
     res.setdefault("eight_copies_stride0_origin_ms", []).append(round(loop(copies_b, list(range(8))), 4))
     res.setdefault("moving_camera_ping_pong_ms", []).append(round(loop(moving, pp), 4))
     res.setdefault("moving_camera_frame3_only_ms", []).append(round(loop(moving, [3]), 4))
+res["opts"] = OPTS
 print(json.dumps(res))
