@@ -83,7 +83,7 @@ typedef struct tr_launch_info {
     int64_t blocks;         /* ray blocks of 128 rays                                         */
     int64_t slots;          /* launch slots = blocks + extra slots of split blocks            */
     int32_t query;          /* TR_Q_* of the launch                                           */
-    int32_t shape;          /* 0 plain, 1 stealing, 2 unordered two-phase schedule, 3 unordered + stealing */
+    int32_t shape;          /* 0 plain, 1 stealing, 2 unordered two-phase schedule, 3 unordered + stealing, 4 direct launch on the 8-wide nodes */
     int32_t tile_rows_lg;   /* 0: 64 rays of one row per wave, 1: 2x32, 2: 4x16, 3: 8x8 tiles  */
     int32_t split_blocks;   /* blocks per XCD that were dealt to 2 / 4 launch slots           */
     int32_t learned_order;  /* 1: the launch used a learned launch order                      */
