@@ -145,3 +145,47 @@ def test_deferred_sort_rides_in_the_next_launch(device):
             assert r2.as_wrapper.last_launch()["sort_carried"] == 0
     finally:
         hops.set_option("sort_inline", 1)
+
+
+def test_a_graph_recorded_while_a_sort_is_pending(device):
+    """A launch recorded into a HIP graph right after a measuring launch (its sort deferred, pending on that stream) neither
+    carries that sort nor gets it recorded in front of it: the sort waits for the next launch that is really enqueued.
+    Replays and eager launches on the stream keep giving the oracle's bits, and the learned order survives."""
+    v, f = W.icosphere(6)
+    v = W.displaced(v, seed=4)
+    res = 256
+    o, d = W.pinhole_grid(res, res, distance=2.5 * float(np.linalg.norm(v, axis=1).max()))
+    exp = [e.reshape(res, res, *e.shape[1:]) for e in
+           OracleIntersector(v, f).intersects_closest(np.ascontiguousarray(o).reshape(-1, 3), d.reshape(-1, 3))[:5]]
+    O, D = T(np.ascontiguousarray(o), device), T(d, device)
+    r = make(v, f, device)
+    side = torch.cuda.Stream(device=device)
+    side.wait_stream(torch.cuda.current_stream(device))
+    with torch.cuda.stream(side):
+        for _ in range(12):                      # on to the launch right after a carrying one, then to the next measuring one
+            r.intersects_closest(O, D)
+            if r.as_wrapper.last_launch()["sort_carried"]:
+                break
+        assert r.as_wrapper.last_launch()["sort_carried"] == 1
+        for _ in range(3):
+            r.intersects_closest(O, D)           # the third of these measures: its sort is pending now
+    side.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        out = r.intersects_closest(O, D)
+    assert r.as_wrapper.last_launch()["sort_carried"] == 0        # the recorded launch did not take it
+    for k in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        assert_closest_bitexact(out, exp, f"replay {k}")
+    with torch.cuda.stream(side):
+        got = r.intersects_closest(O, D)         # the next real launch on the stream carries the pending sort
+        assert r.as_wrapper.last_launch()["sort_carried"] == 1
+        for k in range(6):
+            got = r.intersects_closest(O, D)
+            assert r.as_wrapper.last_launch()["learned_order"] == 1
+    side.synchronize()
+    assert_closest_bitexact(got, exp, "eager launches after the recording")
+    g.replay()
+    torch.cuda.synchronize()
+    assert_closest_bitexact(out, exp, "replay after more eager launches")
