@@ -1,7 +1,7 @@
 #!/bin/bash
 # end-of-round validation: the whole GPU suite, smoke, the bench lines (default and the driver's arguments), the rocprof summary r05n,
 # the other configs, the builder, the emulated N-rank bounds at the final tree
-OUT=gpurun_out/r05_final2
+OUT=gpurun_out/r05_final3
 mkdir -p $OUT
 timeout 2400 python -m pytest tests -m gpu -q -p no:cacheprovider > $OUT/pytest_gpu_full.txt 2>&1
 echo "pytest rc=$?" >> $OUT/pytest_gpu_full.txt; tail -5 $OUT/pytest_gpu_full.txt
@@ -21,7 +21,7 @@ for extra in "" "--arrival copy" "--scaling strong" "--workload c5ii --steps 10 
 done
 python - <<'PY'
 import json
-for ln in open('gpurun_out/r05_final2/emulate.jsonl'):
+for ln in open('gpurun_out/r05_final3/emulate.jsonl'):
     r = json.loads(ln); e = r["emulation"]; c = r["config"]
     print(c["workload"][:11], r["emulated_world"], "share", c["dst_share"], "arr", c["arrival"], "| plain", e["plain_1gpu_ms_per_step"], "rank0", e["rank0_ms_per_step"],
           "peer", e["peer_trace_ms_per_step"], "expand", e["expansion_alone_ms"], "| implied", e["implied_scaling_vs_1gpu"], "ok", r["verified"])
