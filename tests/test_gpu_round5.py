@@ -133,6 +133,13 @@ def test_deferred_sort_rides_in_the_next_launch(device):
         assert np.array_equal(r.intersects_any(O, D).cpu().numpy(), exp[0]), f"any-hit launch {k}"
         flags.append(r.as_wrapper.last_launch()["sort_carried"])
     assert sum(flags) >= 2, flags
+    cnt_exp = OracleIntersector(v, f).intersects_count(np.ascontiguousarray(o).reshape(-1, 3), d.reshape(-1, 3)).reshape(res, res)
+    flags = []
+    for k in range(14):             # ... and the count launches that steal
+        assert np.array_equal(r.intersects_count(O, D).cpu().numpy(), cnt_exp), f"count launch {k}"
+        li = r.as_wrapper.last_launch()
+        flags.append(li["sort_carried"])
+    assert li["shape"] == 3 and sum(flags) >= 2, (flags, li)
     r.update_raw(torch.from_numpy(v).to(device), torch.from_numpy(f).to(device))
     for k in range(10):
         assert_closest_bitexact(r.intersects_closest(O, D), exp, f"after the rebuild, launch {k}")
