@@ -37,6 +37,7 @@ ap.add_argument("--subdiv", type=int, default=8, help="c5i / c5s: icosphere subd
 ap.add_argument("--flat", action="store_true", help="pass image-shaped rays as a flat [N, 3] batch")
 ap.add_argument("--stats", action="store_true", help="also run the instrumented kernel (traversal counters)")
 ap.add_argument("--each", action="store_true", help="also print the time of every step")
+ap.add_argument("--rays", type=int, default=0, help="c3 / c5s: number of hash rays instead of the config's 10 M / 12.5 M")
 ap.add_argument("--presort", type=int, default=0, help="c3 / c5s: sort the rays by (origin cell with this many bits per axis, direction octant) BEFORE the timed region")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -60,10 +61,10 @@ else:
 r = RayMeshIntersector(vertices=T(v), faces=T(f))
 rad = float(np.linalg.norm(v, axis=1).max())
 if a.config == "c3":
-    n = 10_000_000
+    n = a.rays or 10_000_000
     o, d = W.hash_rays_torch(n, 1234, v.min(0) * 1.5, v.max(0) * 1.5, device=dev)
 elif a.config == "c5s":
-    n = 100_000_000 // 8
+    n = a.rays or 100_000_000 // 8
     o, d = W.hash_rays_torch(n, 99, v.min(0) * 1.5, v.max(0) * 1.5, device=dev)
 elif a.config in ("room", "terrain", "soup"):
     # the reference's ray shape (16:9, stride-0 origin); --res = image width (default 640; terrain also 1024 ...)
