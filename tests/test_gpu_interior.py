@@ -54,11 +54,11 @@ def test_reference_shaped_camera_inside_the_room(room, device):
 
 
 def test_rays_that_start_inside_at_scale(room, device):
-    """2 M hash rays with origins INSIDE the room (the streaming launch) and 300 000 secondary rays that
+    """4.5 M hash rays with origins INSIDE the room (the streaming launch: above 4 M rays) and 300 000 secondary rays that
     start exactly on surfaces (first hits of a camera trace, reflected): every ray hits the closed room."""
     v, f, r, R = room
     lo, hi = np.array([-3.9, 0.1, -2.9], np.float32), np.array([3.9, 2.9, 2.9], np.float32)
-    n = 2_100_000
+    n = 4_500_000
     o, d = W.hash_rays_torch(n, 7, lo, hi, device=device)
     hit, front, tri, loc, uv = r.intersects_closest(o, d)
     sub = slice(0, n, 8)

@@ -496,7 +496,7 @@ def test_large_meshes_deep_trees_and_arrays_above_4gib(device, subdiv):
     assert float((rec - loc[hit]).abs().max()) <= 1e-5 * rad
     l3, ridx, tidx = r.intersects_location(ot, dt)
     assert len(ridx) == int(cnt.clamp(max=8).sum()) and torch.equal(torch.bincount(ridx.long(), minlength=cnt.numel()), cnt.clamp(max=8).reshape(-1).long())
-    o2, d2 = W.hash_rays_torch(3_000_000, 5, v.min(0) * 1.5, v.max(0) * 1.5, device=device)   # streaming launch (large meshes: from 2.75 M rays on; binary nodes below 8 M rays)
+    o2, d2 = W.hash_rays_torch(4_500_000, 5, v.min(0) * 1.5, v.max(0) * 1.5, device=device)   # streaming launch (above STEAL_MAX_RAYS; binary nodes below 8 M rays)
     h2 = r.intersects_closest(o2, d2)
     assert torch.equal(h2[0], r.intersects_any(o2, d2)) and torch.equal(h2[2], r.intersects_first(o2, d2))
     # the same batch through the streaming launch on the BINARY nodes (option wide = 0: the instantiations for hierarchies

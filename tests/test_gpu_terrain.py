@@ -58,10 +58,10 @@ def test_grazing_camera_over_the_terrain(land, device, w, h, focal):
 
 
 def test_incoherent_rays_over_the_terrain(land, device):
-    """3 M hash rays in a slab around the surface (the streaming launch: 8-wide nodes, from 2.75 M rays on): most of them leave the mesh"""
+    """4.5 M hash rays in a slab around the surface (the streaming launch: above 4 M rays): most of them leave the mesh"""
     v, f, r, R = land
     lo, hi = np.array([-21, -3, -21], np.float32), np.array([21, 5, 21], np.float32)
-    n = 3_000_000
+    n = 4_500_000
     o, d = W.hash_rays_torch(n, 11, lo, hi, device=device)
     hit, front, tri, loc, uv = r.intersects_closest(o, d)
     sub = slice(0, n, 6)
