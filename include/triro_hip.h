@@ -266,7 +266,7 @@ int tr_trace_stats_query(const tr_bvh *bvh, const tr_rays *rays, int query, tr_t
  *        XCD-local chunk of the block -> ray map, 0 = identity), "compact" (0/1: 32-bit offsets / trail words where the
  *        hierarchy permits),
  *      "steal" (intra-wave work stealing: 0 off / 1 closest, first and any up to 4 M rays -- a ray gives subtrees away from its
- *        64th trip on, in a wave of unrelated rays from the 16th -- / N >= 2 forced, N = the trip for every wave), "usteal" (the same for count launches: 0 / 1 / N forced),
+ *        64th trip on, in a wave of unrelated rays from the first look -- / N >= 2 forced, N = the trip for every wave), "usteal" (the same for count launches: 0 / 1 / N forced),
  *      "split" (0 off / 1 auto / N >= 2: the nblocks >> N most expensive blocks of the learned order run as two -- the first
  *        quarter as four -- launch slots of half / quarter lane density whose idle lanes steal from trip "split_steal" on;
  *        really split are the blocks that cost at least "split_outlier" eighths of the mean block cost (0 all, 1 by how full
@@ -276,7 +276,7 @@ int tr_trace_stats_query(const tr_bvh *bvh, const tr_rays *rays, int query, tr_t
  *      "leaf_vote" (1..64 lanes with a queued leaf that trigger a leaf phase of count / location launches),
  *      "grid_nodes" (0: stealing closest / first / any launches walk the exact 64-byte nodes; 1 (default) / 2: the 32-byte
  *        grid nodes -- two 16-byte loads per visit, one fused multiply-add per box plane),
- *      "stream" (0 never / 1 auto: batches of 3 M ... 8 M rays and more -- by query and mesh size -- that a probe on the device finds incoherent / 2 always: the
+ *      "stream" (0 never / 1 auto: batches above 4 M rays (count: from 8 M on) that a probe on the device finds incoherent / 2 always: the
  *        streaming launch with wave-level ray refill), "stream_rays", "stream_refill", "stream_dynamic" (rays per range,
  *        idle lanes that trigger a refill -- 0 = by query: 28 closest / first, 20 any / count --, ranges handed out by a work counter),
  *      "wide" (0 never / 1 always / 2 from 1 M triangles on: the streaming launch walks 8-wide nodes with 8-bit child boxes,
