@@ -276,7 +276,7 @@ int tr_trace_stats_query(const tr_bvh *bvh, const tr_rays *rays, int query, tr_t
  *      "leaf_vote" (1..64 lanes with a queued leaf that trigger a leaf phase of count / location launches),
  *      "grid_nodes" (0: stealing closest / first / any launches walk the exact 64-byte nodes; 1 (default) / 2: the 32-byte
  *        grid nodes -- two 16-byte loads per visit, one fused multiply-add per box plane),
- *      "stream" (0 never / 1 auto: batches above 4 M rays (count: from 8 M on) that a probe on the device finds incoherent / 2 always: the
+ *      "stream" (0 never / 1 auto: batches above 4 M rays (count: from 16 M on) that a probe on the device finds incoherent / 2 always: the
  *        streaming launch with wave-level ray refill), "stream_rays", "stream_refill", "stream_dynamic" (rays per range,
  *        idle lanes that trigger a refill -- 0 = by query: 28 closest / first, 20 any / count --, ranges handed out by a work counter),
  *      "wide" (0 never / 1 always / 2 from 1 M triangles on: the streaming launch walks 8-wide nodes with 8-bit child boxes,
