@@ -49,7 +49,8 @@ BYTES_PER_RAY_CLOSEST = 50      # 24 B in + 26 B out
 # (round 5: the trace got 7 % faster -- the fused box test --, the expansion did not: the ratios moved accordingly, re-derived
 # from the emulated rank-0 / peer steps of profiles/r05_emulate_final.jsonl and r05_emulate_records.jsonl; c5ii / slot once more after
 # the streaming boundary of large meshes moved to 2.75 M rays: rank 0's 2.4 M incoherent rays then take the direct launch, which does not
-# overlap with the expansion on the side stream -- a smaller shard (1.9 M rays) balances the step again: r05_emulate_final_tree.jsonl)
+# overlap with the expansion on the side stream -- a smaller shard (1.9 M rays) balances the step again: r05_emulate_final_tree.jsonl;
+# with the early stealing of unrelated rays that shard's trace takes 0.33 ms: rank 0 1.68 ms, a peer 1.78 -- 6.6x / 6.2x)
 AUTO_RHO = {("c5i", "slot"): 0.092, ("c5i", "packed"): 0.064, ("c5ii", "slot"): 0.125, ("c5ii", "packed"): 0.101}
 
 
