@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define TR_ABI_VERSION 9
+#define TR_ABI_VERSION 10
 #define TR_MAX_ANYHIT_SIZE 8 /* LaunchParams.h:8  (per-ray cap of intersects_location) */
 #define TR_MAX_SIZE_LENGTH 4 /* LaunchParams.h:9  (ray tensors have <= 4 dims)         */
 #define TR_MAX_HITS_CAP 32   /* largest `cap` tr_intersects_location_fill accepts      */
@@ -151,16 +151,19 @@ int tr_intersects_count(const tr_bvh *bvh, const tr_rays *rays, int32_t *d_count
 /* -- closest hit in 12 bytes per ray (ABI 6; no counterpart in the reference, which is single-GPU:
  *    base.cpp:15-17).  A ray-sharded run gathers results over xGMI; the five dense outputs of
  *    intersectsClosest (ray.cpp:231-289) are 26 B/ray, but everything in them is a function of
- *    (triangle, front flag, u, v) and the mesh:  tri = face index | front << 30, 0xffffffff on a miss
- *    (face indices must be below 2^30); u, v = barycentric weights of face vertices 1 and 2.
+ *    (triangle, front flag, w0, w1) and the mesh:  tri = face index | front << 30, 0xffffffff on a miss
+ *    (face indices must be below 2^30); w0, w1 = barycentric weights of face vertices 0 and 1 = the uv the
+ *    reference returns ((1-u-v, u) of OptiX' barycentrics, shaders.cu:149) -- since ABI 10 (round 6: both are
+ *    float32 roundings of float64 quotients; until ABI 9 the record held the weights of vertices 1 and 2).
+ *    A miss: any record with bit 31 of tri set (the kernels write 0xffffffff, 0, 0); its w0, w1 are ignored.
  *    tr_closest_expand turns such records back into hit / front / tri / loc / uv with the operations
- *    tr_intersects_closest itself uses (loc = u*V1 + v*V2 + (1-u-v)*V0, uv = (1-u-v, u):
+ *    tr_intersects_closest itself uses (w2 = (1-w0)-w1, loc = w0*V0 + w1*V1 + w2*V2, uv = (w0, w1):
  *    shaders.cu:143-149) on d_vertices [nv,3] / d_faces [nf,3] -- the arrays the BVH was built
  *    from -- so expand(packed) is bit-identical to the dense outputs.  Any output may be NULL.
  *    Works on whatever device the pointers live on (no BVH handle involved).                    */
 typedef struct tr_packed_hit {
     uint32_t tri;
-    float u, v;
+    float w0, w1;
 } tr_packed_hit;
 int tr_intersects_closest_packed(const tr_bvh *bvh, const tr_rays *rays, tr_packed_hit *d_packed,
                                  void *stream);

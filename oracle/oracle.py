@@ -54,7 +54,8 @@ def lib():
     L.oracle_location_fill.argtypes = [C.c_void_p, fp, fp, C.c_int64, C.c_int, C.c_int,
                                        C.c_int32, i64p, fp, ip, ip, fp]
     L.oracle_fetch_rays.argtypes = [fp, fp, i64p, i64p, i64p, C.c_int64, fp, fp]
-    L.oracle_watertight.argtypes = [C.c_void_p, fp, fp, C.c_int64, C.c_int, ip, C.POINTER(C.c_double), ip]
+    L.oracle_watertight.argtypes = [C.c_void_p, fp, fp, C.c_int64, C.c_int, ip, C.POINTER(C.c_double), ip,
+                                    C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.oracle_num_threads.restype = C.c_int
     _LIB = L
     return L
@@ -165,16 +166,22 @@ class OracleIntersector:
             el += time.perf_counter() - t0
         return el
 
-    def watertight(self, origins, directions):
+    def watertight(self, origins, directions, with_bary=False):
         """(tri[*b] int32 (-1 miss), t[*b] float64, count[*b] int32) under the WATERTIGHT float64 test of
-        Woop / Benthin / Wald 2013 -- not the contract: the yardstick for how far Moller-Trumbore in float32
-        can be from a watertight reference (triro_oracle.c, "WATERTIGHT float64 reference")"""
+        Woop / Benthin / Wald 2013 in its published form (shear with a division, per-ray permutation) -- an
+        implementation of its own beside the contract's float64 part: the yardstick for the contract's hit mask and,
+        with_bary, for what the API returns: + (uvw[*b,3], loc[*b,3]) float64 barycentric weights / location of
+        the hit (triro_oracle.c, "WATERTIGHT float64 reference")"""
         b, o, d = self._rays(origins, directions)
         n = len(o)
         tri, cnt = np.empty(n, np.int32), np.empty(n, np.int32)
         t = np.empty(n, np.float64)
+        uvw = np.empty((n, 3), np.float64) if with_bary else None
+        loc = np.empty((n, 3), np.float64) if with_bary else None
         lib().oracle_watertight(self._h, _p(o, C.c_float), _p(d, C.c_float), n, self.threads, _p(tri, C.c_int32),
-                                _p(t, C.c_double), _p(cnt, C.c_int32))
+                                _p(t, C.c_double), _p(cnt, C.c_int32), _p(uvw, C.c_double), _p(loc, C.c_double))
+        if with_bary:
+            return tri.reshape(b), t.reshape(b), cnt.reshape(b), uvw.reshape(*b, 3), loc.reshape(*b, 3)
         return tri.reshape(b), t.reshape(b), cnt.reshape(b)
 
     def intersects_closest(self, origins, directions, stream_compaction=False):

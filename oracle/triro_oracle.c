@@ -33,40 +33,38 @@
  * and anchors it on the hand-derived known answers for the inputs of
  * test/test.py and README.md (tests/golden/known_answers.json).
  *
- * The ray/triangle arithmetic itself (closed source in the reference) is the
- * published Moller-Trumbore test, fixed here as an ARITHMETIC CONTRACT that the
- * HIP kernels follow operation by operation so that integer outputs are
- * bit-exact.  The contract (also in DESIGN.md, "Arithmetic contract"):
+ * The ray/triangle arithmetic itself (closed source in the reference; OptiX documents its built-in triangle test as
+ * WATERTIGHT) is fixed here as an ARITHMETIC CONTRACT (version 3, round 6) that the HIP kernels follow operation by
+ * operation so that every output is bit-exact.  The contract (also in DESIGN.md, "Arithmetic contract"):
  *
  *   ray:   valid iff all six of o,d are finite (else the ray misses everything)
- *          inv_i = 1/d_i (IEEE); if |inv_i| > 3.0e38 -> copysign(3.0e38, d_i)
- *   box of a triangle: l = min(min(a_i,b_i),c_i), h = max(...);  pad(x) = |x|*2^-21 + 2^-100
- *          lo_i = l - pad(l), hi_i = h + pad(h)   (so that a ray lying exactly in a bounding
- *          plane with d_i = 0 is inside the slab on both sides: 2^-100 * 3e38 > TMAX)
- *   slab:  t1 = (lo_i-o_i)*inv_i, t2 = (hi_i-o_i)*inv_i  (sub, then mul)
- *          tn = max_i min(t1,t2); tf = (min_i max(t1,t2)) * (1+2^-22)
- *          box is hit iff tn <= tf && tf >= 0 && tn <= TMAX
- *   MT:    e1=b-a, e2=c-a, p=cross(d,e2), det=dot(e1,p); det==0 -> miss
- *          s=o-a, U=dot(s,p), q=cross(s,e1), V=dot(d,q), T=dot(e2,q)
- *          cross(x,y).x = fma(x.y, y.z, -(x.z*y.y)) (cyclic)
- *          dot(x,y)     = fma(x.z, y.z, fma(x.y, y.y, x.x*y.x))
- *          det>0: U>=0 && V>=0 && U+V<=det ; det<0: U<=0 && V<=0 && U+V>=det
- *          t = T/det (IEEE division)
- *   key:   t_key = min(max(t, tn), tf)   (the MT distance clamped into the
- *          triangle's own slab interval); accepted iff 0 <= t_key <= 1e7
- *   closest = lexicographic minimum of (t_key, tri_idx) over accepted triangles
- *   front  = det > 0  (counter-clockwise seen from the ray origin)
- *   u=U/det, v=V/det, w=(1-u)-v, loc_i = fma(w,a_i, fma(v,c_i, u*b_i)), uv=(w,u)
- *   multi-hit: the (up to) 8 accepted hits with smallest (t_key, tri_idx),
- *          ascending; the reference keeps "the first 8 in traversal order",
- *          which is unspecified (shaders.cu:209-212).
+ *   MT:    e1=b-a, e2=c-a, p=cross(d,e2), det=dot(e1,p), s=o-a, U=dot(s,p), q=cross(s,e1), V=dot(d,q), T=dot(e2,q)
+ *          cross(x,y).x = fma(x.y, y.z, -(x.z*y.y)) (cyclic);  dot(x,y) = fma(x.z, y.z, fma(x.y, y.y, x.x*y.x))
+ *          (Uf,Vf) = (U,V) with the sign bit of det flipped in; D1 = |det| - Uf; Wf = D1 - Vf; m3 = min(min(Uf,Vf),Wf)
+ *   bound: E = (|e1x|+|e1y|+|e1z|) + (|e2x|+|e2y|+|e2z|), Ls = max|s_i|, kd = (|dx|+|dy|+|dz|) * 10*2^-24,
+ *          mm = fma(kd*E, Ls+E, 2^-100)  -- exceeds the rounding error of Uf, Vf, Wf and det (proof: tr_math.h);
+ *          Ls+E > 2^40 or kd > 10*2^-24*2^40 (or NaN) -> the float32 part does not answer (overflow)
+ *   inside: Uf < -mm or D1 < -2mm or Vf < -mm or Wf < -mm -> outside (proven);  m3 > mm -> inside (proven), t = T/det in float32 provided
+ *          |det| >= (kd*E*E)*1024 and |T| >= (Ls*2^-10)*(E*E) (relative error of t < 2^-11);
+ *          anything else (also NaN) -> the EXACT part: Woop / Benthin / Wald 2013 edge functions in float64 from the
+ *          float32 inputs, projective form (woop64 below): inside iff U,V,W all >= 0 or all <= 0 and U+V+W != 0;
+ *          t = (float)(fma(W,Cz, fma(V,Bz, U*Az)) / ((U+V+W) * d[kz]))
+ *   accepted iff 0 <= t <= 1e7;  closest = lexicographic minimum of (t, tri_idx) over accepted triangles
+ *   outputs of the winning triangle from the float64 edge functions: w0 = (float)(U/det64), w1 = (float)(V/det64),
+ *          w2=(1-w0)-w1, loc_i = fma(w0,a_i, fma(w2,c_i, w1*b_i)), uv=(w0,w1); front = (det64 < 0) == (d[kz] < 0)
+ *   multi-hit: the (up to) 8 accepted hits with smallest (t, tri_idx), ascending; the reference keeps "the first 8
+ *          in traversal order", which is unspecified (shaders.cu:209-212).
+ *   boxes (any BVH): pad(x) = |x|*2^-21 + 2^-100 per bound; slab t1 = (lo_i-o_i)*inv_i, t2 = (hi_i-o_i)*inv_i,
+ *          inv_i = 1/d_i clamped to +-3e38; tn = max_i min(t1,t2); tf = (min_i max(t1,t2)) * (1+2^-21);
+ *          a box is entered iff tn <= tf && tf >= 0 && tn <= limit, limit = best_t * (1+2^-10) for closest hits,
+ *          1.001e7 otherwise.
  *
- * Because the predicate is a pure function of (ray, triangle) and every BVH
- * box is a superset of its triangles' boxes, any conservative BVH returns
- * exactly what the brute-force loop returns (slab is monotone under box
- * inclusion, and t_key >= tn of every enclosing box).  Both are here:
- * mode 0 = brute force (ground truth), mode 1 = median-split BVH (fast; used
- * for the CPU baseline and for parity at sizes brute force cannot reach).
+ * The predicate is a pure function of (ray, triangle).  Any conservative BVH returns what the brute-force loop
+ * returns because (a) the slab test accepts every box the ray's line truly meets within [0, limit] (the exit pad
+ * 1 + 8u covers the three roundings of an entry and of an exit distance), and a triangle that is hit lies in its
+ * padded box, and (b) culling leaves 2^-10 of slack where a float32 distance can be off by 2^-11.  Both are here:
+ * mode 0 = brute force (ground truth), mode 1 = median-split BVH (fast; used for the CPU baseline and for parity at
+ * sizes brute force cannot reach).
  *
  * Build:  see oracle/Makefile (gcc -O2 -ffp-contract=off -mfma -fopenmp).
  */
@@ -80,13 +78,19 @@
 
 #define TR_TMAX 1.0e7f
 #define TR_HUGE 3.0e38f
-#define TR_SLAB_PAD 1.00000023841857910156f /* 1 + 2^-22 */
+#define TR_SLAB_PAD 1.000000476837158203125f /* 1 + 2^-21 */
+#define TR_CULL_SLACK 1.0009765625f         /* 1 + 2^-10 */
+#define TR_TLIM 1.001e7f                    /* > TR_TMAX * TR_CULL_SLACK */
 #define TR_MAX_HITS_CAP 64
 #define TR_PAD_REL 4.76837158203125e-07f  /* 2^-21  */
 #define TR_PAD_ABS 7.888609052210118e-31f /* 2^-100 */
+#define TR_BAND_K 5.9604644775390625e-07f  /* 10 u, u = 2^-24 */
+#define TR_BAND_ABS 7.888609052210118e-31f /* 2^-100 */
+#define TR_BAND_MAXLEN 1.099511627776e12f  /* 2^40 */
 
 typedef struct {
     float o[3], d[3], inv[3];
+    float kd; /* 2^-20 * |d|_1: the ray's factor of the band margin (contract v2) */
     int valid;
 } ray_t;
 
@@ -128,11 +132,12 @@ static void ray_setup(ray_t *r, const float *o, const float *d) {
         if (fabsf(inv) > TR_HUGE) inv = copysignf(TR_HUGE, d[i]);
         r->inv[i] = inv;
     }
+    r->kd = ((fabsf(d[0]) + fabsf(d[1])) + fabsf(d[2])) * TR_BAND_K;
     r->valid = ok;
 }
 
-/* slab test; returns 1 if the (padded) interval is non-empty and overlaps [0,TMAX] */
-static inline int slab(const ray_t *r, const float *lo, const float *hi, float *tn_out,
+/* robust slab test (Ize 2013); returns 1 if the (padded) interval is non-empty and overlaps [0, limit] */
+static inline int slab(const ray_t *r, const float *lo, const float *hi, float limit, float *tn_out,
                        float *tf_out) {
     float tn = -INFINITY, tf = INFINITY;
     for (int i = 0; i < 3; i++) {
@@ -144,11 +149,11 @@ static inline int slab(const ray_t *r, const float *lo, const float *hi, float *
     tf = tf * TR_SLAB_PAD;
     *tn_out = tn;
     *tf_out = tf;
-    return (tn <= tf) && (tf >= 0.0f) && (tn <= TR_TMAX);
+    return (tn <= tf) && (tf >= 0.0f) && (tn <= limit);
 }
 
 typedef struct {
-    float t, U, V, det;
+    float t; /* the key: distance clamped into the triangle's own slab interval */
 } hit_t;
 
 /* box of a triangle, padded outward by |x|*2^-21 + 2^-100 per bound (see contract) */
@@ -163,12 +168,56 @@ static inline void tri_box_padded(const float *a, const float *b, const float *c
     }
 }
 
-/* the hit predicate: pure function of (ray, triangle) */
+/* ---- contract v2 (round 6): Moller-Trumbore decides where it provably can, float64 edge functions elsewhere ---- */
+/* The EXACT part: Woop / Benthin / Wald 2013 edge functions in float64 from the float32 inputs, in projective form
+ * (multiplied through by d[kz]: no division).  kz = the dominant axis of the direction, (kx, ky, kz) cyclic.  A vertex P
+ * becomes P' = P - o (float64), Ph = (P'x*dz - dx*P'z, P'y*dz - dy*P'z): a function of (vertex, ray) alone, so the two
+ * triangles of a shared edge see the same two points; an edge function is the DIFFERENCE OF TWO ROUNDED PRODUCTS -- its
+ * sign is the exact sign of the 2D orientation of the rounded points or zero (rounding is monotone), and swapping the
+ * end points negates it exactly.  A ray therefore cannot pass between two triangles that share an edge. */
+typedef struct {
+    double U, V, W;    /* weights of a, b, c (unnormalised; all >= 0 or all <= 0 inside) */
+    double Az, Bz, Cz; /* P'z of the three vertices */
+    double dz;
+} woop_t;
+
+static inline void woop64(const float *o, const float *d, const float *a, const float *b, const float *c,
+                          woop_t *w) {
+    int kz = 0;
+    if (fabsf(d[1]) > fabsf(d[kz])) kz = 1;
+    if (fabsf(d[2]) > fabsf(d[kz])) kz = 2;
+    const int kx = (kz + 1) % 3, ky = (kz + 2) % 3;
+    const double dx = d[kx], dy = d[ky], dz = d[kz];
+    const double ox = o[kx], oy = o[ky], oz = o[kz];
+    const double Ax = (double)a[kx] - ox, Ay = (double)a[ky] - oy, Az = (double)a[kz] - oz;
+    const double Bx = (double)b[kx] - ox, By = (double)b[ky] - oy, Bz = (double)b[kz] - oz;
+    const double Cx = (double)c[kx] - ox, Cy = (double)c[ky] - oy, Cz = (double)c[kz] - oz;
+    const double ahx = fma(-dx, Az, Ax * dz), ahy = fma(-dy, Az, Ay * dz);
+    const double bhx = fma(-dx, Bz, Bx * dz), bhy = fma(-dy, Bz, By * dz);
+    const double chx = fma(-dx, Cz, Cx * dz), chy = fma(-dy, Cz, Cy * dz);
+    w->U = chx * bhy - chy * bhx;
+    w->V = ahx * chy - ahy * chx;
+    w->W = bhx * ahy - bhy * ahx;
+    w->Az = Az; w->Bz = Bz; w->Cz = Cz;
+    w->dz = dz;
+}
+
+/* inside test of the exact part (both windings; zero counts as inside: a ray through a shared edge hits both) */
+static inline int woop_inside(const woop_t *w, double *det_out) {
+    const double U = w->U, V = w->V, W = w->W;
+    if ((U < 0.0 || V < 0.0 || W < 0.0) && (U > 0.0 || V > 0.0 || W > 0.0)) return 0;
+    const double det = (U + V) + W;
+    *det_out = det;
+    return det != 0.0;
+}
+
+
+/* diagnostics (-DORACLE_STATS build, oracle_band_stats): leaf tests that reach the inside decision / that take the float64 part */
+static long long g_leaf_tests, g_band_tests;
+
+/* the hit predicate: a pure function of (ray, triangle) -- no box, no clamp */
 static inline int tri_hit(const ray_t *r, const float *a, const float *b, const float *c,
                           hit_t *h) {
-    float lo[3], hi[3], tn, tf;
-    tri_box_padded(a, b, c, lo, hi);
-    if (!slab(r, lo, hi, &tn, &tf)) return 0;
     float e1[3], e2[3], s[3], p[3], q[3];
     for (int i = 0; i < 3; i++) {
         e1[i] = b[i] - a[i];
@@ -177,23 +226,52 @@ static inline int tri_hit(const ray_t *r, const float *a, const float *b, const 
     }
     cross3(r->d, e2, p);
     float det = dot3(e1, p);
-    if (det == 0.0f) return 0;
     float U = dot3(s, p);
-    cross3(s, e1, q);
-    float V = dot3(r->d, q);
-    if (det > 0.0f) {
-        if (!(U >= 0.0f && V >= 0.0f && (U + V) <= det)) return 0;
-    } else {
-        if (!(U <= 0.0f && V <= 0.0f && (U + V) >= det)) return 0;
+    /* both orientations at once: flip by the sign BIT of det */
+    const int neg = signbit(det) != 0;
+    const float Uf = neg ? -U : U;
+    /* proven bound on |computed - exact| of Uf, Vf, D1, Wf (+ that of det): 10 u |d|_1 E (|s|_inf + E) + 2^-100,
+     * E = |e1|_1 + |e2|_1 */
+    const float E = ((fabsf(e1[0]) + fabsf(e1[1])) + fabsf(e1[2])) + ((fabsf(e2[0]) + fabsf(e2[1])) + fabsf(e2[2]));
+    const float Ls = maxf_(maxf_(fabsf(s[0]), fabsf(s[1])), fabsf(s[2]));
+    const float kE = r->kd * E;
+    const float LsE = Ls + E;
+    const float mm = fmaf(kE, LsE, TR_BAND_ABS);
+    const float D1 = fabsf(det) - Uf; /* = Vf + Wf */
+#ifdef ORACLE_STATS
+    __atomic_fetch_add(&g_leaf_tests, 1, __ATOMIC_RELAXED);
+#endif
+    /* lengths beyond 2^40 (overflow) and NaN: the float32 part does not answer */
+    int exact = !(LsE <= TR_BAND_MAXLEN && r->kd <= TR_BAND_K * TR_BAND_MAXLEN);
+    float V = 0.0f, Vf = 0.0f, Wf = 0.0f;
+    if (!exact) {
+        if (Uf < -mm || D1 < -(mm + mm)) return 0; /* proven outside, known before V is */
+        cross3(s, e1, q);
+        V = dot3(r->d, q);
+        Vf = neg ? -V : V;
+        Wf = D1 - Vf;
+        if (Vf < -mm || Wf < -mm) return 0;        /* proven outside */
+        exact = !(minf_(minf_(Uf, Vf), Wf) > mm); /* not proven inside */
     }
-    float T = dot3(e2, q);
-    float t = T / det;
-    float tk = minf_(maxf_(t, tn), tf);
-    if (!(tk >= 0.0f && tk <= TR_TMAX)) return 0;
-    h->t = tk;
-    h->U = U;
-    h->V = V;
-    h->det = det;
+    float t = 0.0f;
+    if (!exact) {
+        const float T = dot3(e2, q);
+        /* the float32 distance only where |T| and |det| exceed 2^12 x their error bounds: relative error < 2^-11 */
+        exact = !(fabsf(det) >= (kE * E) * 1024.0f) || !(fabsf(T) >= (Ls * 9.765625e-4f) * (E * E));
+        if (!exact) t = T / det;
+    }
+    if (exact) {
+#ifdef ORACLE_STATS
+        __atomic_fetch_add(&g_band_tests, 1, __ATOMIC_RELAXED);
+#endif
+        woop_t w;
+        double det64;
+        woop64(r->o, r->d, a, b, c, &w);
+        if (!woop_inside(&w, &det64)) return 0;
+        t = (float)(fma(w.W, w.Cz, fma(w.V, w.Bz, w.U * w.Az)) / (det64 * w.dz));
+    }
+    if (!(t >= 0.0f && t <= TR_TMAX)) return 0;
+    h->t = t;
     return 1;
 }
 
@@ -311,7 +389,6 @@ typedef struct {
     int found;
     float t;
     int32_t tri;
-    float U, V, det;
 } best_t;
 
 static inline void consider(best_t *b, const hit_t *h, int32_t f) {
@@ -319,9 +396,6 @@ static inline void consider(best_t *b, const hit_t *h, int32_t f) {
         b->found = 1;
         b->t = h->t;
         b->tri = f;
-        b->U = h->U;
-        b->V = h->V;
-        b->det = h->det;
     }
 }
 
@@ -331,7 +405,6 @@ typedef struct {
     int64_t total;
     float t[TR_MAX_HITS_CAP];
     int32_t tri[TR_MAX_HITS_CAP];
-    float U[TR_MAX_HITS_CAP], V[TR_MAX_HITS_CAP], det[TR_MAX_HITS_CAP];
 } hitlist_t;
 
 static inline void hl_insert(hitlist_t *l, const hit_t *h, int32_t f) {
@@ -349,16 +422,10 @@ static inline void hl_insert(hitlist_t *l, const hit_t *h, int32_t f) {
            (h->t < l->t[pos - 1] || (h->t == l->t[pos - 1] && f < l->tri[pos - 1]))) {
         l->t[pos] = l->t[pos - 1];
         l->tri[pos] = l->tri[pos - 1];
-        l->U[pos] = l->U[pos - 1];
-        l->V[pos] = l->V[pos - 1];
-        l->det[pos] = l->det[pos - 1];
         pos--;
     }
     l->t[pos] = h->t;
     l->tri[pos] = f;
-    l->U[pos] = h->U;
-    l->V[pos] = h->V;
-    l->det[pos] = h->det;
 }
 
 /* closest hit */
@@ -382,8 +449,8 @@ static void closest_ray(const omesh_t *m, const ray_t *r, int mode, best_t *best
     while (sp > 0) {
         const onode_t *n = &m->nodes[stack[--sp]];
         float tn, tf;
-        if (!slab(r, n->lo, n->hi, &tn, &tf)) continue;
-        if (best->found && tn > best->t) continue;
+        /* culled only beyond best * (1 + 2^-10): a float32 distance can be 2^-11 off (contract, TR_CULL_SLACK) */
+        if (!slab(r, n->lo, n->hi, best->found ? best->t * TR_CULL_SLACK : TR_TLIM, &tn, &tf)) continue;
         if (n->right < 0) {
             for (int32_t k = 0; k < -n->right; k++) {
                 int32_t f = m->prim[n->left + k];
@@ -417,7 +484,7 @@ static void allhits_ray(const omesh_t *m, const ray_t *r, int mode, hitlist_t *l
     while (sp > 0) {
         const onode_t *n = &m->nodes[stack[--sp]];
         float tn, tf;
-        if (!slab(r, n->lo, n->hi, &tn, &tf)) continue;
+        if (!slab(r, n->lo, n->hi, TR_TLIM, &tn, &tf)) continue;
         if (n->right < 0) {
             for (int32_t k = 0; k < -n->right; k++) {
                 int32_t f = m->prim[n->left + k];
@@ -431,19 +498,27 @@ static void allhits_ray(const omesh_t *m, const ray_t *r, int mode, hitlist_t *l
     }
 }
 
-static inline void hit_outputs(const omesh_t *m, int32_t f, float U, float V, float det,
-                               float *loc, float *uv, uint8_t *front) {
+/* outputs of a hit: the barycentrics of the WINNING triangle from the float64 edge functions of (ray, triangle) --
+ * w0, w1 = the weights of face vertices 0 and 1 = the reference's uv (shaders.cu:149: (1-u-v, u)), each the float32
+ * rounding of a float64 quotient --, then float32: w2 = (1 - w0) - w1, loc = fma(w0, a, fma(w2, c, w1 * b)) (:143-146).
+ * front (optixIsFrontFaceHit, :151) = counter-clockwise seen from the origin = d . ((b-a) x (c-a)) < 0: the sign of the
+ * edge functions' sum times that of d[kz]. */
+static inline void hit_outputs(const omesh_t *m, const ray_t *r, int32_t f, float *loc, float *uv,
+                               uint8_t *front) {
     const float *a, *b, *c;
     tri_verts(m, f, &a, &b, &c);
-    float u = U / det, v = V / det;
-    float w = (1.0f - u) - v;
+    woop_t wq;
+    woop64(r->o, r->d, a, b, c, &wq);
+    const double det = (wq.U + wq.V) + wq.W;
+    const float w0 = (float)(wq.U / det), w1 = (float)(wq.V / det);
+    const float w2 = (1.0f - w0) - w1;
     if (loc)
-        for (int i = 0; i < 3; i++) loc[i] = fmaf(w, a[i], fmaf(v, c[i], u * b[i]));
+        for (int i = 0; i < 3; i++) loc[i] = fmaf(w0, a[i], fmaf(w2, c[i], w1 * b[i]));
     if (uv) {
-        uv[0] = w;
-        uv[1] = u;
+        uv[0] = w0;
+        uv[1] = w1;
     }
-    if (front) *front = det > 0.0f;
+    if (front) *front = (det < 0.0) == (wq.dz < 0.0);
 }
 
 static void set_threads(int nthreads) {
@@ -469,7 +544,7 @@ int oracle_closest(const void *mesh, const float *o, const float *d, int64_t n, 
         closest_ray(m, &r, mode, &b);
         float l3[3] = {0, 0, 0}, uv2[2] = {0, 0};
         uint8_t fr = 0;
-        if (b.found) hit_outputs(m, b.tri, b.U, b.V, b.det, l3, uv2, &fr);
+        if (b.found) hit_outputs(m, &r, b.tri, l3, uv2, &fr);
         if (hit) hit[i] = (uint8_t)b.found;
         if (front) front[i] = fr;
         if (tri) tri[i] = b.found ? b.tri : -1;
@@ -515,7 +590,7 @@ int oracle_location_fill(const void *mesh, const float *o, const float *d, int64
         allhits_ray(m, &r, mode, &l);
         for (int32_t k = 0; k < l.n; k++) {
             int64_t g = offsets[i] + k;
-            hit_outputs(m, l.tri[k], l.U[k], l.V[k], l.det[k], loc + 3 * g, NULL, NULL);
+            hit_outputs(m, &r, l.tri[k], loc + 3 * g, NULL, NULL);
             ray_idx[g] = (int32_t)i;
             tri_idx[g] = l.tri[k];
             if (t_out) t_out[g] = l.t[k];
@@ -564,7 +639,7 @@ static void wray_setup(wray_t *w, const float *o, const float *d) {
     w->Sz = 1.0 / w->d[kz];
 }
 
-static inline int wt_tri(const wray_t *w, const float *a, const float *b, const float *c, double *t_out) {
+static inline int wt_tri(const wray_t *w, const float *a, const float *b, const float *c, double *t_out, double *bary) {
     const int kx = w->kx, ky = w->ky, kz = w->kz;
     const double A[3] = {a[0] - w->o[0], a[1] - w->o[1], a[2] - w->o[2]};
     const double B[3] = {b[0] - w->o[0], b[1] - w->o[1], b[2] - w->o[2]};
@@ -580,6 +655,7 @@ static inline int wt_tri(const wray_t *w, const float *a, const float *b, const 
     const double t = (U * Az + V * Bz + W * Cz) / det;
     if (!(t >= 0.0 && t <= (double)TR_TMAX)) return 0;
     *t_out = t;
+    if (bary) { bary[0] = U / det; bary[1] = V / det; bary[2] = W / det; }   /* weights of a, b, c */
     return 1;
 }
 
@@ -601,9 +677,11 @@ static inline int wt_box(const wray_t *w, const float *lo, const float *hi, doub
     return tn <= tf * (1.0 + 1e-12) + 1e-300;
 }
 
-/* closest hit and hit count of every ray under the watertight float64 test; tri = -1 / t = inf on a miss */
+/* closest hit and hit count of every ray under the watertight float64 test; tri = -1 / t = inf on a miss.
+ * uvw (optional, [n,3]): float64 barycentric weights of the hit on face vertices 0, 1, 2; loc (optional, [n,3]): the
+ * float64 location w0 V0 + w1 V1 + w2 V2 -- the yardstick for the uv / loc the contract returns (0 on a miss). */
 int oracle_watertight(const void *mesh, const float *o, const float *d, int64_t n, int nthreads,
-                      int32_t *tri, double *t, int32_t *count) {
+                      int32_t *tri, double *t, int32_t *count, double *uvw, double *loc) {
     const omesh_t *m = (const omesh_t *)mesh;
     set_threads(nthreads);
 #pragma omp parallel for schedule(dynamic, 256)
@@ -611,7 +689,7 @@ int oracle_watertight(const void *mesh, const float *o, const float *d, int64_t 
         wray_t w;
         wray_setup(&w, o + 3 * i, d + 3 * i);
         int32_t best = -1, cnt = 0;
-        double bt = INFINITY;
+        double bt = INFINITY, bb[3] = {0, 0, 0};
         if (w.valid && m->nf > 0) {
             int32_t stack[128];
             int sp = 0;
@@ -624,10 +702,10 @@ int oracle_watertight(const void *mesh, const float *o, const float *d, int64_t 
                         const int32_t f = m->prim[nd->left + k];
                         const float *a, *b, *c;
                         tri_verts(m, f, &a, &b, &c);
-                        double th;
-                        if (wt_tri(&w, a, b, c, &th)) {
+                        double th, ba[3];
+                        if (wt_tri(&w, a, b, c, &th, ba)) {
                             cnt++;
-                            if (th < bt || (th == bt && f < best)) { bt = th; best = f; }
+                            if (th < bt || (th == bt && f < best)) { bt = th; best = f; bb[0] = ba[0]; bb[1] = ba[1]; bb[2] = ba[2]; }
                         }
                     }
                 } else {
@@ -639,6 +717,16 @@ int oracle_watertight(const void *mesh, const float *o, const float *d, int64_t 
         if (tri) tri[i] = best;
         if (t) t[i] = bt;
         if (count) count[i] = cnt;
+        if (uvw) { uvw[3 * i] = bb[0]; uvw[3 * i + 1] = bb[1]; uvw[3 * i + 2] = bb[2]; }
+        if (loc) {
+            double l3[3] = {0, 0, 0};
+            if (best >= 0) {
+                const float *a, *b, *c;
+                tri_verts(m, best, &a, &b, &c);
+                for (int k = 0; k < 3; k++) l3[k] = bb[0] * (double)a[k] + bb[1] * (double)b[k] + bb[2] * (double)c[k];
+            }
+            loc[3 * i] = l3[0]; loc[3 * i + 1] = l3[1]; loc[3 * i + 2] = l3[2];
+        }
     }
     return 0;
 }
@@ -667,6 +755,16 @@ int oracle_fetch_rays(const float *obase, const float *dbase, const int64_t shap
         }
     }
     return 0;
+}
+
+/* out = {inside decisions, of which in float64}; zero unless built with -DORACLE_STATS (make stats) */
+void oracle_band_stats(long long out[2], int reset) {
+    out[0] = __atomic_load_n(&g_leaf_tests, __ATOMIC_RELAXED);
+    out[1] = __atomic_load_n(&g_band_tests, __ATOMIC_RELAXED);
+    if (reset) {
+        __atomic_store_n(&g_leaf_tests, 0, __ATOMIC_RELAXED);
+        __atomic_store_n(&g_band_tests, 0, __ATOMIC_RELAXED);
+    }
 }
 
 int oracle_num_threads(void) {

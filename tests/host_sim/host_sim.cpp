@@ -293,13 +293,13 @@ static void run_query(const tr_bvh_view& v, const float* o, const float* d, int6
             if (valid && (g_fused & 4)) {
                 // the streaming launch's flavour: 32-byte grid nodes, no intervals in the leaf FIFO
                 if ((g_fused & 3) == 1) {
-                    tr_state_t<uint64_t, false> fs; tr_state_init(fs);
+                    tr_state_t<uint64_t> fs; tr_state_init(fs);
                     while (!tr_done(fs)) {
                         tr_fused_step<Q, 1, true, false, uint64_t, false, true, true>(v, r, fs, res, top, &cnt, ring);
                         if (!tr_done(fs)) tr_fused_step<Q, 1, true, false, uint64_t, false, false, true>(v, r, fs, res, top, &cnt, ring);
                     }
                 } else {
-                    tr_state_t<uint32_t, false> fs; tr_state_init(fs);
+                    tr_state_t<uint32_t> fs; tr_state_init(fs);
                     while (!tr_done(fs)) {
                         tr_fused_step<Q, 1, true, true, uint32_t, false, true, true>(v, r, fs, res, top, &cnt, ring);
                         if (!tr_done(fs)) tr_fused_step<Q, 1, true, true, uint32_t, false, false, true>(v, r, fs, res, top, &cnt, ring);
@@ -326,8 +326,8 @@ static void run_query(const tr_bvh_view& v, const float* o, const float* d, int6
             res.best_face = -1; res.count = 0; res.best_t = TR_TMAX;
             if (valid && v.num_tris == 1) {
                 const tr_tri& t = v.tris[0]; tr_hit h;
-                if (tr_tri_hit(r, t.ax, t.ay, t.az, t.bx, t.by, t.bz, t.cx, t.cy, t.cz, h)) {
-                    res.best_t = h.t; res.best_face = t.face; res.best_slot = 0; res.U = h.U; res.V = h.V; res.det = h.det; res.count = 1;
+                if (tr_tri_test(r, t.ax, t.ay, t.az, t.bx, t.by, t.bz, t.cx, t.cy, t.cz, h)) {
+                    res.best_t = h.t; res.best_face = t.face; res.best_slot = 0; res.count = 1;
                 }
             }
         }
@@ -340,9 +340,7 @@ static void run_query(const tr_bvh_view& v, const float* o, const float* d, int6
             hit[i] = res.best_face >= 0; front[i] = 0; tri[i] = res.best_face;
             if (res.best_face >= 0) {
                 const tr_tri& t = v.tris[res.best_slot];
-                tr_hit h; h.t = res.best_t; h.U = res.U; h.V = res.V; h.det = res.det;
-                tr_hit_outputs(h, t.ax, t.ay, t.az, t.bx, t.by, t.bz, t.cx, t.cy, t.cz, l3, u2);
-                front[i] = res.det > 0.f;
+                front[i] = tr_hit_outputs(r, t.ax, t.ay, t.az, t.bx, t.by, t.bz, t.cx, t.cy, t.cz, l3, u2);
             }
             memcpy(loc + 3 * i, l3, 12); memcpy(uv + 2 * i, u2, 8);
         }
@@ -441,8 +439,8 @@ void sim_packet_stats(const void* nodes_, int64_t nf, const float* o, const floa
                 float tn0, tf0, tn1, tf1;
                 const tr_f4* np = reinterpret_cast<const tr_f4*>(&N);
                 tr_node_slabs(rays[k], np[0], np[1], np[2], tn0, tf0, tn1, tf1);
-                if (tr_slab_hit(tn0, tf0, TR_TMAX)) h0 |= 1ull << k;
-                if (tr_slab_hit(tn1, tf1, TR_TMAX)) h1 |= 1ull << k;
+                if (tr_slab_hit(tn0, tf0, TR_TLIM)) h0 |= 1ull << k;
+                if (tr_slab_hit(tn1, tf1, TR_TLIM)) h1 |= 1ull << k;
             }
             const int32_t cs[2] = {N.c0, N.c1};
             const uint64_t hs[2] = {h0, h1};
@@ -464,7 +462,7 @@ void sim_packet_stats(const void* nodes_, int64_t nf, const float* o, const floa
 
 // The fused box test of the grid nodes (tr_ray_fuse / tr_qnode_slabs, round 5) against the contract's three-step form
 // on the same decoded boxes: for every (ray, grid node, child) the fused interval must CONTAIN what tr_slab_hit can
-// see of the contract's --  tn' <= max(tn, 0)  and  tf' >= min(tf, TR_TMAX)  -- so that the fused traversal visits a
+// see of the contract's --  tn' <= max(tn, 0)  and  tf' >= min(tf, TR_TLIM)  -- so that the fused traversal visits a
 // superset of the nodes.  Returns the number of violations; out[0] = pairs checked, out[1] = children the fused test
 // accepts, out[2] = children the contract's test accepts (the looseness paid for one fma per plane).
 int64_t sim_check_fused(const void* qnodes_, int64_t nnodes, const float* f6, const float* o, const float* d, int64_t n,
@@ -484,9 +482,9 @@ int64_t sim_check_fused(const void* qnodes_, int64_t nnodes, const float* f6, co
             const float fn[2] = {a0, a1}, ff[2] = {b0, b1}, cn[2] = {c0, c1}, cf[2] = {e0, e1};
             for (int c = 0; c < 2; c++) {
                 pairs++;
-                if (!(fn[c] <= fmaxf(cn[c], 0.0f)) || !(ff[c] >= fminf(cf[c], TR_TMAX))) bad++;
-                acc_f += tr_slab_hit(fn[c], ff[c], TR_TMAX) ? 1 : 0;
-                acc_c += tr_slab_hit(cn[c], cf[c], TR_TMAX) ? 1 : 0;
+                if (!(fn[c] <= fmaxf(cn[c], 0.0f)) || !(ff[c] >= fminf(cf[c], TR_TLIM))) bad++;
+                acc_f += tr_slab_hit(fn[c], ff[c], TR_TLIM) ? 1 : 0;
+                acc_c += tr_slab_hit(cn[c], cf[c], TR_TLIM) ? 1 : 0;
             }
         }
     }
@@ -541,9 +539,9 @@ int64_t sim_check_fused_wide(const void* nodes_, int64_t nnodes, const float* f6
                 }
                 cf *= TR_SLAB_PAD;
                 pairs++;
-                if (!(tn <= fmaxf(cn, 0.0f)) || !(tf >= fminf(cf, TR_TMAX))) bad++;
-                acc_f += tr_slab_hit(tn, tf, TR_TMAX) ? 1 : 0;
-                acc_c += tr_slab_hit(cn, cf, TR_TMAX) ? 1 : 0;
+                if (!(tn <= fmaxf(cn, 0.0f)) || !(tf >= fminf(cf, TR_TLIM))) bad++;
+                acc_f += tr_slab_hit(tn, tf, TR_TLIM) ? 1 : 0;
+                acc_c += tr_slab_hit(cn, cf, TR_TLIM) ? 1 : 0;
             }
         }
     }
@@ -569,4 +567,41 @@ void sim_location(const void* nodes, const void* links, const void* tris, int64_
         for (int k = 0; k < 8 && k < cap; k++) { tri_out[i * cap + k] = k < res.count ? top.face[k] : -1; t_out[i * cap + k] = top.t[k]; }
     }
 }
+}
+
+// ---- the float32 part of the hit predicate against the float64 part, pair by pair (tests/test_host_sim.py) -----------
+// For (ray i, triangle i): code = tr_tri_fast's answer (0 proven miss / out of range, 1 proven hit, 2 undecided) and its
+// distance; the exact part's answer and distance; and an INDEPENDENT classification in long double of the three edge
+// functions (Plucker-style triple products of the exact float32 inputs, 64-bit mantissas: signs are right unless a value
+// is below 1e-17 of its terms): inside = 1, outside = 0, too close to call = 2 -- the arbiter of "proven".
+extern "C" void sim_tri_fast_vs_exact(const float* o, const float* d, const float* tri, int64_t n, int32_t* code_fast,
+                                      float* t_fast, int32_t* hit_exact, float* t_exact, int32_t* truth) {
+    for (int64_t i = 0; i < n; i++) {
+        tr_ray r;
+        tr_ray_setup(r, o[3 * i], o[3 * i + 1], o[3 * i + 2], d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+        const float* t = tri + 9 * i;
+        tr_hit h; h.t = 0.f;
+        code_fast[i] = tr_tri_fast(r, t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], h);
+        t_fast[i] = h.t;
+        tr_hit he; he.t = 0.f;
+        hit_exact[i] = tr_tri_exact(r, t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], he) ? 1 : 0;
+        t_exact[i] = he.t;
+        // long double triple products d . ((P - o) x (Q - o)) for the three edges
+        long double P[3][3];
+        for (int k = 0; k < 3; k++) for (int c = 0; c < 3; c++) P[k][c] = (long double)t[3 * k + c] - (long double)o[3 * i + c];
+        const long double D[3] = {d[3 * i], d[3 * i + 1], d[3 * i + 2]};
+        int pos = 0, neg = 0, amb = 0;
+        for (int e = 0; e < 3; e++) {
+            const long double* A = P[(e + 1) % 3];
+            const long double* B = P[(e + 2) % 3];
+            const long double cx = A[1] * B[2] - A[2] * B[1], cy = A[2] * B[0] - A[0] * B[2], cz = A[0] * B[1] - A[1] * B[0];
+            const long double v = D[0] * cx + D[1] * cy + D[2] * cz;
+            const long double mag = fabsl(D[0]) * (fabsl(A[1] * B[2]) + fabsl(A[2] * B[1])) + fabsl(D[1]) * (fabsl(A[2] * B[0]) + fabsl(A[0] * B[2])) +
+                                    fabsl(D[2]) * (fabsl(A[0] * B[1]) + fabsl(A[1] * B[0]));
+            if (fabsl(v) <= 1e-17L * mag) amb++;
+            else if (v > 0) pos++;
+            else neg++;
+        }
+        truth[i] = amb ? 2 : ((pos && neg) ? 0 : 1);
+    }
 }

@@ -43,8 +43,21 @@ def lib():
         L.sim_check_fused_wide.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
         L.sim_check_fused.restype = C.c_int64
         L.sim_check_fused.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+        L.sim_tri_fast_vs_exact.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p] * 5
         _LIB = L
     return _LIB
+
+
+def tri_fast_vs_exact(o, d, tri):
+    """per (ray, triangle) pair: (code of the float32 part, its t, hit of the float64 part, its t, long-double truth)"""
+    o, d = np.ascontiguousarray(o, np.float32), np.ascontiguousarray(d, np.float32)
+    tri = np.ascontiguousarray(tri, np.float32).reshape(-1, 9)
+    n = len(o)
+    code, he, truth = np.empty(n, np.int32), np.empty(n, np.int32), np.empty(n, np.int32)
+    tf, te = np.empty(n, np.float32), np.empty(n, np.float32)
+    lib().sim_tri_fast_vs_exact(o.ctypes.data, d.ctypes.data, tri.ctypes.data, n, code.ctypes.data, tf.ctypes.data,
+                                he.ctypes.data, te.ctypes.data, truth.ctypes.data)
+    return code, tf, he, te, truth
 
 
 NODE_WORDS, LINK_WORDS, TRI_WORDS = 16, 2, 12

@@ -146,6 +146,32 @@ def _ladder_worker(rank, world, port, q):
             H.local.generation += 1
             H.local.h = 99
             ok &= H.slots == (case != "incapable")
+        # 6. ADVICE r05: the capability tests used to sit IN FRONT of the handshake (`_slot_records_on and self.slots`,
+        #    `_can_pack() and self.slot_records`): a rank with TRIRO_SLOT_RECORDS=0 never entered the all-gather and its
+        #    peer waited.  Now every rank enters, reports what it can do, and all land on the same rung.
+        if rank == 1:
+            os.environ["TRIRO_SLOT_RECORDS"] = "0"
+        R6 = ShardedRayMeshIntersector(Hashed(v, f, 77), ctrl_group=ctrl, dst_share=0.5)
+        ok &= R6.exchange_mode == "packed" and R6.slots and not R6.slot_records
+        pf = R6.preflight(o, d, dst=0)
+        ok &= pf["exchange_mode_used"] == "packed"
+        g = R6.intersects_closest(o, d, dst=0)
+        if rank == 0:
+            ok &= all(torch.equal(a, e) for a, e in zip(g, exp))
+        os.environ.pop("TRIRO_SLOT_RECORDS", None)
+        # ... and a handshake that THROWS on one rank (its hash kernel fails) is that rank saying "no slot form here",
+        # not an exception that leaves preflight() on one rank while the other waits in a collective
+        class BadHash(Hashed):
+            def replica_hash(self):
+                if dist.get_rank() == 1:
+                    raise RuntimeError("injected: hash kernel")
+                return super().replica_hash()
+        R7 = ShardedRayMeshIntersector(BadHash(v, f, 77), ctrl_group=ctrl)
+        pf = R7.preflight(o, d, dst=0)
+        ok &= pf["exchange_mode_used"] == "packed" and R7.exchange_mode == "packed"
+        g = R7.intersects_closest(o, d, dst=0)
+        if rank == 0:
+            ok &= all(torch.equal(a, e) for a, e in zip(g, exp))
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

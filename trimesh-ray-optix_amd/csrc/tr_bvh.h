@@ -14,8 +14,7 @@
 //   tris  :  F    x 48 B   tr_tri    Morton-ordered copy of the triangle (v0,v1,v2) + the
 //                                    original face index
 // Child ids: c >= 0 internal node index, c < 0 leaf, slot = ~c into `tris`.
-// One triangle per leaf, so the leaf box stored in the parent IS the triangle's exact box
-// and its slab interval is reused as the [tn, tf] of the hit predicate (tr_math.h).
+// One triangle per leaf; the leaf box stored in the parent is the triangle's padded box (tr_tri_box).
 //
 // Traversal is stackless: a 64-bit trail (bit k set = the node at depth k on the current
 // path still owes its far child) plus parent/sibling links (Hapala 2011 / Afra &
@@ -108,17 +107,17 @@ TR_HD void tr_qframe_make(const float* mn, const float* mx, tr_qframe* f) {
 //       contract:  p^ = fl(q s + b), d^ = fl(p^ - o), t^ = fl(d^ inv):   |t^ - T|        <= u |inv| (|p| + 2 |p - o|)
 //       fused:     bo = fl(b - o), b0 = fl(bo k), B = fl(b0 -+ e), t' = fl(q A + B):
 //                                                                        |t' - (T -+ e)| <= u |k| (|p - o| + 3 |b - o|) + 2 u e
-//       exit pad:  t^ * (1 + 2^-22), rounded:                            + 5 u |inv| |p - o|
-//     and |p - o| <= |b - o| + E:  e >= u |inv| (P + 11 |b - o| + 8 E) for the grid nodes; the 8-wide nodes decode in
+//       exit pad:  t^ * (1 + 2^-21), rounded (TR_SLAB_PAD, round 6):     + 9 u |inv| |p - o|
+//     and |p - o| <= |b - o| + E:  e >= u |inv| (P + 15 |b - o| + 12 E) for the grid nodes; the 8-wide nodes decode in
 //     their own frame (planes up to one extent outside the mesh's box, base_n - o rounded per node):
-//     e >= u |inv| (P + 10 |b - o| + 19 E).  e = 1.25 u |k| (P + 11 |b - o| + 19 E) covers both.  Entry planes get
+//     e >= u |inv| (P + 14 |b - o| + 27 E).  e = 1.25 u |k| (P + 15 |b - o| + 27 E) covers both.  Entry planes get
 //     -e, exit planes +e (sel_n / sel_f already separate them): t'_entry <= t_entry, t'_exit >= t_exit * TR_SLAB_PAD.
-//   * a clamped axis additionally gets -+ 1.0001e7 (> TR_TMAX): with |k| < |inv| the fused distance has the sign of
-//     the contract's and a smaller magnitude, so an exit plane behind the origin stays behind, one in front is pushed
-//     beyond TR_TMAX (it cannot cull), an entry plane in front stays smaller, one behind stays <= 0 -- all that
-//     tr_slab_hit(max(tn, 0) <= min(tf, limit <= TR_TMAX)) can see.
+//   * a clamped axis additionally gets -+ 1.1e7 (> TR_TLIM, the largest limit of a box test): with |k| < |inv| the fused
+//     distance has the sign of the contract's and a smaller magnitude, so an exit plane behind the origin stays behind,
+//     one in front is pushed beyond every limit (it cannot cull), an entry plane in front stays smaller, one behind
+//     stays <= 0 -- all that tr_slab_hit(max(tn, 0) <= min(tf, limit <= TR_TLIM)) can see.
 //   * M beyond 1e30 (or not finite): the axis is ignored (A = 0, B = -+inf).
-// So: tn' <= max(tn, 0) and tf' >= min(tf, TR_TMAX) for the contract's (tn, tf) of the same decoded box -- the fused
+// So: tn' <= max(tn, 0) and tf' >= min(tf, TR_TLIM) for the contract's (tn, tf) of the same decoded box -- the fused
 // test accepts whatever the contract's test accepts (tests/host_sim checks exactly this over the fuzz corpus), the
 // traversal visits a superset of nodes, the leaves decide: results are bit-identical.  In position units the margin
 // is ~1.3 float spacings of the coordinates plus 7e-7 of the camera distance: a few hundredths of a grid cell for a
@@ -133,8 +132,8 @@ TR_HD void tr_fuse_axis(float o, float inv, float base, float scale, float& k, f
     const float kmax = tr_u2f(ke << 23);
     const bool clamped = fabsf(inv) > kmax;
     const float kk = clamped ? copysignf(kmax, inv) : inv;
-    const float Me = fmaxf(fabsf(base), fabsf(top)) + 11.0f * fabsf(bo) + 1245184.0f * scale;             // P + 11 |b - o| + 19 E
-    const float ee = fabsf(kk) * Me * 7.450580596923828e-08f + (clamped ? 1.0001e7f : 0.0f) + 1.0e-37f;   // 1.25 * 2^-24
+    const float Me = fmaxf(fabsf(base), fabsf(top)) + 15.0f * fabsf(bo) + 1769472.0f * scale;             // P + 15 |b - o| + 27 E
+    const float ee = fabsf(kk) * Me * 7.450580596923828e-08f + (clamped ? 1.1e7f : 0.0f) + 1.0e-37f;      // 1.25 * 2^-24
     const float b0 = bo * kk;
     // (selects, no branch: an early return here left the compiler with a stack object for the B pairs)
     k = usable ? kk : 0.0f;
@@ -307,7 +306,6 @@ struct tr_result {
     float best_t;
     int32_t best_face;   // -1 = miss
     int32_t best_slot;
-    float U, V, det;
     // count
     int32_t count;
 };
@@ -335,7 +333,12 @@ TR_HD const tr_f4* tr_tri_ptr(const tr_bvh_view& b, int32_t slot) {
 
 TR_HD void tr_result_init(tr_result& res) {
     res.best_t = TR_TMAX; res.best_face = -1; res.best_slot = -1;
-    res.U = 0.f; res.V = 0.f; res.det = 1.f; res.count = 0;
+    res.count = 0;
+}
+// the limit a box's entry distance is culled against (tr_math.h, TR_CULL_SLACK)
+template <int Q>
+TR_HD float tr_cull_limit(const tr_result& res) {
+    return (Q == TR_Q_FIRST || Q == TR_Q_CLOSEST) ? res.best_t * TR_CULL_SLACK : TR_TLIM;
 }
 
 template <bool STATS, bool COMPACT = false>
@@ -357,31 +360,53 @@ TR_HD tr_tri tr_load_tri(const tr_bvh_view& b, int32_t slot, tr_counters* cnt) {
 // Fold one accepted/rejected leaf test into the per-query state.  `live` = the lane really
 // owns this leaf (the code runs unpredicated for the whole wave).  Returns true when the ray
 // is finished (ANY query, first accepted hit).
-// IV: the slab interval (tn, tf) of the leaf's box comes with the call (it was produced by the exact
-// parent node's test and carried through the leaf FIFO).  !IV: the full predicate -- the interval is
-// recomputed from the triangle's vertices, same bits; this is what a trip over the 32-byte grid nodes
-// needs (their boxes are only conservative), and it takes six registers out of the traversal state.
-template <int Q, int K, bool IV = true>
-TR_HD bool tr_fold_leaf(bool live, const tr_ray& r, const tr_tri& t, int32_t slot, float tn, float tf,
-                        tr_result& res, tr_topk<K>& top) {
-    tr_hit h;
-    bool hit;
-    if (IV) hit = tr_tri_mt(r, t.ax, t.ay, t.az, t.bx, t.by, t.bz, t.cx, t.cy, t.cz, tn, tf, h) && live;
-    else hit = tr_tri_hit(r, t.ax, t.ay, t.az, t.bx, t.by, t.bz, t.cx, t.cy, t.cz, h) && live;
+// Fold one decided leaf test into the per-query state.  Returns true when the ray is finished (ANY query, first hit).
+template <int Q, int K>
+TR_HD bool tr_fold_hit(bool hit, float t, int32_t face, int32_t slot, tr_result& res, tr_topk<K>& top) {
     if (Q == TR_Q_ANY) {
-        if (hit) res.best_face = t.face;
+        if (hit) res.best_face = face;
         return hit;
     } else if (Q == TR_Q_COUNT) {
         res.count += hit ? 1 : 0;
     } else if (Q == TR_Q_LOCATION) {
-        if (hit) { res.count++; top.insert(h.t, t.face, slot); }
+        if (hit) { res.count++; top.insert(t, face, slot); }
     } else {
-        if (hit && tr_closer(h.t, t.face, res.best_t, res.best_face < 0 ? 0x7fffffff : res.best_face)) {
-            res.best_t = h.t; res.best_face = t.face; res.best_slot = slot;
-            res.U = h.U; res.V = h.V; res.det = h.det;
+        if (hit && tr_closer(t, face, res.best_t, res.best_face < 0 ? 0x7fffffff : res.best_face)) {
+            res.best_t = t; res.best_face = face; res.best_slot = slot;
         }
     }
     return false;
+}
+// The leaf test of the traversal: the float32 part of the predicate (tr_tri_fast) here, inside the trip; a test it
+// leaves UNDECIDED (< 1 % of them: the ray passes within rounding of an edge, or grazes the plane) is parked in `pe`
+// (the triangle's slot) and decided by the float64 part at the END of the trip (tr_drain_exact) -- a real call that
+// owns thirty registers: there the trip's node record and triangle are dead and the call fits under the kernels'
+// register budget, inside the leaf block it cost every kernel a wave per SIMD.  Until then the candidate culls
+// nothing, which changes no result.  `live` = the lane really owns this leaf (the code runs unpredicated for the
+// whole wave).  At most one test per trip and lane, and `pe` is emptied before the next one.
+template <int Q, int K>
+TR_HD bool tr_fold_leaf(bool live, const tr_ray& r, const tr_tri& t, int32_t slot, tr_result& res, tr_topk<K>& top, int32_t& pe) {
+    tr_hit h;
+    h.t = 0.f;
+    const int c = tr_tri_fast(r, t.ax, t.ay, t.az, t.bx, t.by, t.bz, t.cx, t.cy, t.cz, h);
+    if (live && c == TR_UNDECIDED) pe = slot;
+    return tr_fold_hit<Q, K>(live && c == TR_HIT, h.t, t.face, slot, res, top);
+}
+// decide the parked test (see tr_fold_leaf); wave-uniform skip when no lane has one
+template <int Q, int K, bool COMPACT = false>
+TR_HD bool tr_drain_exact(const tr_bvh_view& b, const tr_ray& r, int32_t& pe, tr_result& res, tr_topk<K>& top) {
+    bool fin = false;
+    if (TR_WAVE_ANY(pe >= 0)) {
+        if (pe >= 0) {
+            tr_counters* nc = nullptr;
+            const tr_tri t = tr_load_tri<false, COMPACT>(b, pe, nc);
+            tr_hit h;
+            const bool hit = tr_tri_exact(r, t.ax, t.ay, t.az, t.bx, t.by, t.bz, t.cx, t.cy, t.cz, h);
+            fin = tr_fold_hit<Q, K>(hit, h.t, t.face, pe, res, top);
+            pe = -1;
+        }
+    }
+    return fin;
 }
 
 // Far-child ring: the far child pushed at depth k is remembered in slot k % TR_RING of a
@@ -419,25 +444,16 @@ TR_HD void tr_ring_put(const tr_ring& ring, uint32_t slot, int32_t v) {
 
 // Per-lane traversal state between two iterations.  W = uint64_t in general; uint32_t when
 // the hierarchy is at most 32 levels high (halves the 64-bit shift/clz work per trip).
-template <typename W, bool IV = true>
+template <typename W>
 struct tr_state_t {
     int32_t node;     // next internal node to visit, -1 = hierarchy exhausted
     uint32_t depth;
     W trail;          // bit k: the node at depth k on the current path still owes its far child
     W owned;          // bit k: that far child is still in ring slot k % TR_RING
-    // leaves found by the previous node visit, tested one iteration later so that their
-    // triangle loads overlap the next node's load (one memory round trip per iteration)
-    int32_t p0, p1;   // tri slots, -1 = none
-    float p0n, p0f, p1n, p1f;   // their slab intervals
-    int32_t p2; float p2n, p2f;  // third queue slot (one leaf is tested per trip, up to two arrive)
-};
-// without the intervals (IV = false, see tr_fold_leaf)
-template <typename W>
-struct tr_state_t<W, false> {
-    int32_t node;
-    uint32_t depth;
-    W trail, owned;
+    // leaves found by earlier node visits (tri slots, -1 = none), tested one per trip so that their triangle loads
+    // overlap the next node's load (one memory round trip per iteration); up to two arrive per visit
     int32_t p0, p1, p2;
+    int32_t pe;       // a leaf test the float32 part left undecided, waiting for tr_drain_exact (-1 = none)
 };
 typedef tr_state_t<uint64_t> tr_state;
 typedef tr_state_t<uint32_t> tr_state32;
@@ -447,17 +463,16 @@ TR_HD uint32_t tr_top_bit(uint32_t x) { return 31u - (uint32_t)__builtin_clz(x);
 TR_HD uint64_t tr_ring_mask(uint64_t) { return TR_RING_MASK; }
 TR_HD uint32_t tr_ring_mask(uint32_t) { return 0x00010001u; }
 
-template <typename W, bool IV>
-TR_HD void tr_state_init(tr_state_t<W, IV>& st) {
+template <typename W>
+TR_HD void tr_state_init(tr_state_t<W>& st) {
     st.node = 0; st.depth = 0; st.trail = 0; st.owned = 0;
-    st.p0 = -1; st.p1 = -1; st.p2 = -1;
-    if constexpr (IV) { st.p0n = st.p0f = st.p1n = st.p1f = st.p2n = st.p2f = 0.f; }
+    st.p0 = -1; st.p1 = -1; st.p2 = -1; st.pe = -1;
 }
 
-template <typename W, bool IV>
-TR_HD bool tr_pending(const tr_state_t<W, IV>& st) { return st.p0 >= 0 || st.p1 >= 0; }
-template <typename W, bool IV>
-TR_HD bool tr_done(const tr_state_t<W, IV>& st) { return st.node < 0 && st.p0 < 0 && st.p1 < 0; }
+template <typename W>
+TR_HD bool tr_pending(const tr_state_t<W>& st) { return st.p0 >= 0 || st.p1 >= 0; }
+template <typename W>
+TR_HD bool tr_done(const tr_state_t<W>& st) { return st.node < 0 && st.p0 < 0 && st.p1 < 0 && st.pe < 0; }
 
 #ifndef TR_PK_SLAB
 #define TR_PK_SLAB 1
@@ -495,7 +510,6 @@ TR_HD void tr_node_slabs(const tr_ray& r, const tr_f4& n0, const tr_f4& n1, cons
 template <int Q, bool STATS>
 TR_HD void tr_node_step(const tr_bvh_view& b, const tr_ray& r, tr_state& st, const tr_result& res,
                         tr_counters* cnt, const tr_ring ring) {
-    const bool ordered = (Q == TR_Q_FIRST || Q == TR_Q_CLOSEST);
     const tr_f4* np = reinterpret_cast<const tr_f4*>(b.nodes + st.node);
     const tr_f4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
     if (STATS) cnt->nodes++;
@@ -506,15 +520,15 @@ TR_HD void tr_node_step(const tr_bvh_view& b, const tr_ray& r, tr_state& st, con
     u0.f = n3.x; u1.f = n3.y; u2.f = n3.z; u3.f = n3.w;
     const int32_t c0 = u0.i, c1 = u1.i;
     int32_t parent = u2.i, sibling = u3.i;
-    const float lim = ordered ? res.best_t : TR_TMAX;
+    const float lim = tr_cull_limit<Q>(res);
     bool h0 = tr_slab_hit(tn0, tf0, lim);
     bool h1 = tr_slab_hit(tn1, tf1, lim);
 #ifdef TR_COUNT_BOTTOM
     if (STATS && c0 < 0 && c1 < 0) { cnt->bottom++; cnt->bottom_hits += (h0 ? 1u : 0u) + (h1 ? 1u : 0u); }
 #endif
     // leaf children are queued for the leaf phase
-    if (h0 && c0 < 0) { st.p0 = ~c0; st.p0n = tn0; st.p0f = tf0; h0 = false; }
-    if (h1 && c1 < 0) { st.p1 = ~c1; st.p1n = tn1; st.p1f = tf1; h1 = false; }
+    if (h0 && c0 < 0) { st.p0 = ~c0; h0 = false; }
+    if (h1 && c1 < 0) { st.p1 = ~c1; h1 = false; }
     if (h0 | h1) {
         const bool both = h0 & h1;
         const bool swap = both ? (tn1 < tn0) : h1;   // descend into c1?
@@ -558,7 +572,6 @@ TR_HD void tr_node_step(const tr_bvh_view& b, const tr_ray& r, tr_state& st, con
 template <int Q, int K, bool STATS>
 TR_HD void tr_leaf_step(const tr_bvh_view& b, const tr_ray& r, tr_state& st, tr_result& res,
                         tr_topk<K>& top, tr_counters* cnt) {
-    const bool ordered = (Q == TR_Q_FIRST || Q == TR_Q_CLOSEST);
     const int32_t q0 = st.p0, q1 = st.p1;
     tr_counters* nc = nullptr;
     const bool any1 = TR_WAVE_ANY(q1 >= 0);
@@ -566,11 +579,13 @@ TR_HD void tr_leaf_step(const tr_bvh_view& b, const tr_ray& r, tr_state& st, tr_
     tr_tri t1 = t0;
     if (any1) t1 = tr_load_tri<false>(b, q1 >= 0 ? q1 : 0, nc);
     if (STATS && q0 >= 0) cnt->tris++;
-    bool fin = tr_fold_leaf<Q, K>(q0 >= 0, r, t0, q0, st.p0n, st.p0f, res, top);
+    bool fin = tr_fold_leaf<Q, K>(q0 >= 0, r, t0, q0, res, top, st.pe);
+    fin = tr_drain_exact<Q, K>(b, r, st.pe, res, top) || fin;
     if (any1) {
-        const bool live = q1 >= 0 && !fin && (!ordered || st.p1n <= res.best_t);
+        const bool live = q1 >= 0 && !fin;
         if (STATS && live) cnt->tris++;
-        fin = tr_fold_leaf<Q, K>(live, r, t1, q1, st.p1n, st.p1f, res, top) || fin;
+        fin = tr_fold_leaf<Q, K>(live, r, t1, q1, res, top, st.pe) || fin;
+        fin = tr_drain_exact<Q, K>(b, r, st.pe, res, top) || fin;
     }
     st.p0 = -1; st.p1 = -1;
     if (Q == TR_Q_ANY && fin) st.node = -1;
@@ -750,27 +765,18 @@ TR_HD void tr_rec_links(const tr_rec_q&, int32_t& parent, int32_t& sibling) { pa
 // trips where the whole wave visits the same node -- in scalar registers)
 // TEST = false: a trip WITHOUT the leaf block (tr_fused_step)
 template <int Q, int K, bool STATS, bool COMPACT, typename W, bool TEST, typename REC>
-TR_HD void tr_fused_body(const tr_bvh_view& b, const tr_ray& r,
-                         tr_state_t<W, std::is_same<REC, tr_rec_f>::value>& st, tr_result& res,
+TR_HD void tr_fused_body(const tr_bvh_view& b, const tr_ray& r, tr_state_t<W>& st, tr_result& res,
                          tr_topk<K>& top, tr_counters* cnt, const tr_ring ring, const bool has_node,
                          const REC& rec) {
-    constexpr bool IV = std::is_same<REC, tr_rec_f>::value;   // exact nodes: intervals travel with the leaves
-    const bool ordered = (Q == TR_Q_FIRST || Q == TR_Q_CLOSEST);
     if (STATS && has_node) cnt->nodes++;
     bool fin = false;
     const int32_t q0 = st.p0;
     if (TEST && TR_WAVE_ANY(q0 >= 0)) {
         tr_counters* nc = nullptr;
         const tr_tri t0 = tr_load_tri<false, COMPACT>(b, q0 >= 0 ? q0 : 0, nc);
-        bool live = q0 >= 0;
-        float ln = 0.f, lf = 0.f;
-        if constexpr (IV) {
-            // a queued leaf whose box entry lies beyond the best hit found meanwhile cannot win
-            live = live && (!ordered || st.p0n <= res.best_t);
-            ln = st.p0n; lf = st.p0f;
-        }
+        const bool live = q0 >= 0;
         if (STATS && live) cnt->tris++;
-        fin = tr_fold_leaf<Q, K, IV>(live, r, t0, q0, ln, lf, res, top);
+        fin = tr_fold_leaf<Q, K>(live, r, t0, q0, res, top, st.pe);
     }
     if (Q == TR_Q_ANY && fin) { st.node = -1; st.p1 = -1; st.p2 = -1; }
     float tn0, tf0, tn1, tf1;
@@ -778,7 +784,7 @@ TR_HD void tr_fused_body(const tr_bvh_view& b, const tr_ray& r,
     int32_t c0, c1, parent, sibling;
     tr_rec_children(rec, c0, c1);
     tr_rec_links(rec, parent, sibling);
-    const float lim = ordered ? res.best_t : TR_TMAX;
+    const float lim = tr_cull_limit<Q>(res);
     const bool go = has_node && st.node >= 0;
     bool h0 = tr_slab_hit(tn0, tf0, lim) && go;
     bool h1 = tr_slab_hit(tn1, tf1, lim) && go;
@@ -800,12 +806,6 @@ TR_HD void tr_fused_body(const tr_bvh_view& b, const tr_ray& r,
             st.p2 = (hb && two) ? ~c1 : -1;
             st.p1 = hb ? xi : (two ? ~c1 : -1);
             st.p0 = hb ? st.p0 : xi;
-            if constexpr (IV) {
-                const float xe = l0 ? tn0 : tn1, xx = l0 ? tf0 : tf1;
-                st.p2n = tn1;   st.p2f = tf1;
-                st.p1n = hb ? xe : tn1;   st.p1f = hb ? xx : tf1;
-                st.p0n = hb ? st.p0n : xe;   st.p0f = hb ? st.p0f : xx;
-            }
         }
     } else {
         const bool l0 = h0 && c0 < 0;
@@ -816,13 +816,6 @@ TR_HD void tr_fused_body(const tr_bvh_view& b, const tr_ray& r,
         const int32_t i1 = wait ? st.p2 : ~c1;
         const bool hb = st.p1 >= 0, two = l0 && l1;
         const int32_t xi = l0 ? ~c0 : (l1 ? i1 : -1);      // first new entry
-        if constexpr (IV) {
-            const float e1 = wait ? st.p2n : tn1, x1 = wait ? st.p2f : tf1;
-            const float xe = l0 ? tn0 : e1, xx = l0 ? tf0 : x1;
-            st.p0n = hb ? st.p1n : xe;   st.p0f = hb ? st.p1f : xx;
-            st.p1n = hb ? xe : e1;   st.p1f = hb ? xx : x1;
-            st.p2n = e1;   st.p2f = x1;
-        }
         st.p0 = hb ? st.p1 : xi;
         st.p1 = hb ? xi : (two ? i1 : -1);
         st.p2 = (hb && two) ? i1 : -1;
@@ -868,6 +861,11 @@ TR_HD void tr_fused_body(const tr_bvh_view& b, const tr_ray& r,
             st.depth = j + 1;
         }
     }
+    // the test this trip's leaf block left undecided, now that the trip's record and triangle are dead (tr_fold_leaf)
+    if (TEST) {
+        if (tr_drain_exact<Q, K, COMPACT>(b, r, st.pe, res, top) && Q == TR_Q_ANY) { st.node = -1; st.p0 = -1; st.p1 = -1; st.p2 = -1; }
+        st.pe = -1;     // (it is: said once more so that the compiler does not carry it around the loop)
+    }
 }
 
 
@@ -885,7 +883,7 @@ TR_HD void tr_fused_body(const tr_bvh_view& b, const tr_ray& r,
 // QN: walk the 32-byte grid nodes instead of the exact 64-byte ones (see tr_rec_q).
 template <int Q, int K, bool STATS, bool COMPACT = false, typename W = uint64_t, bool UNI = false, bool TEST = true,
           bool QN = false>
-TR_HD void tr_fused_step(const tr_bvh_view& b, const tr_ray& r, tr_state_t<W, !QN>& st, tr_result& res,
+TR_HD void tr_fused_step(const tr_bvh_view& b, const tr_ray& r, tr_state_t<W>& st, tr_result& res,
                          tr_topk<K>& top, tr_counters* cnt, const tr_ring ring) {
     // one leaf test per trip: the head of the lane's FIFO (p0, p1, p2).  The node is visited
     // unless the FIFO is full (it then waits one trip: no fetch, no new leaves).
@@ -961,12 +959,13 @@ struct tr_ustate_t {
     uint32_t depth;
     W trail, owned;   // as in tr_state_t
     int32_t nq;       // queued leaves
+    int32_t pe;       // a leaf test waiting for tr_drain_exact (-1 = none; tr_fold_leaf)
 };
 
 template <typename W>
-TR_HD void tr_ustate_init(tr_ustate_t<W>& st) { st.node = 0; st.depth = 0; st.trail = 0; st.owned = 0; st.nq = 0; }
+TR_HD void tr_ustate_init(tr_ustate_t<W>& st) { st.node = 0; st.depth = 0; st.trail = 0; st.owned = 0; st.nq = 0; st.pe = -1; }
 template <typename W>
-TR_HD bool tr_udone(const tr_ustate_t<W>& st) { return st.node < 0 && st.nq == 0; }
+TR_HD bool tr_udone(const tr_ustate_t<W>& st) { return st.node < 0 && st.nq == 0 && st.pe < 0; }
 // a lane may visit its node only while the queue can take both children
 template <typename W>
 TR_HD bool tr_ucan_node(const tr_ustate_t<W>& st) { return st.node >= 0 && st.nq <= TR_LEAFQ - 2; }
@@ -995,23 +994,15 @@ TR_HD void tr_unord_step(const tr_bvh_view& b, const tr_ray& r, bool go_node, bo
         tr_counters* nc = nullptr;
         const tr_tri t = tr_load_tri<false, COMPACT>(b, slot, nc);
         if (STATS && gl) cnt->tris++;
-        tr_hit h;
-        const bool hit = tr_tri_hit(r, t.ax, t.ay, t.az, t.bx, t.by, t.bz, t.cx, t.cy, t.cz, h) && gl;
-        if (Q == TR_Q_ANY) {
-            if (hit) { res.best_face = t.face; fin = true; }   // first accepted hit ends the ray
-        } else if (Q == TR_Q_COUNT) {
-            res.count += hit ? 1 : 0;
-        } else {
-            if (hit) { res.count++; top.insert(h.t, t.face, slot); }
-        }
+        fin = tr_fold_leaf<Q, K>(gl, r, t, slot, res, top, st.pe);   // (ANY: the first accepted hit ends the ray)
     }
     if (Q == TR_Q_ANY && fin) { st.node = -1; st.nq = 0; }
     const bool go = go_node && !fin;
     float tn0, tf0, tn1, tf1;
     tr_qnode_slabs(r, b.frame, w0, w1, tn0, tf0, tn1, tf1);
     const int32_t c0 = w1.z, c1 = w1.w;
-    bool h0 = tr_slab_hit(tn0, tf0, TR_TMAX) && go;
-    bool h1 = tr_slab_hit(tn1, tf1, TR_TMAX) && go;
+    bool h0 = tr_slab_hit(tn0, tf0, TR_TLIM) && go;
+    bool h1 = tr_slab_hit(tn1, tf1, TR_TLIM) && go;
     if (h0 && c0 < 0) { lq.base[st.nq * lq.stride] = ~c0; st.nq++; h0 = false; }
     if (h1 && c1 < 0) { lq.base[st.nq * lq.stride] = ~c1; st.nq++; h1 = false; }
     if (go) {
@@ -1037,6 +1028,10 @@ TR_HD void tr_unord_step(const tr_bvh_view& b, const tr_ray& r, bool go_node, bo
             else st.node = tr_climb<STATS>(b, st.node, st.depth, j, cnt);
             st.depth = j + 1;
         }
+    }
+    if (leaf_phase) {      // (wave-uniform) the test the leaf phase left undecided
+        if (tr_drain_exact<Q, K, COMPACT>(b, r, st.pe, res, top) && Q == TR_Q_ANY) { st.node = -1; st.nq = 0; }
+        st.pe = -1;
     }
 }
 

@@ -1,14 +1,23 @@
 // tr_math.h -- the arithmetic contract of the ray/triangle path ("Arithmetic
-// contract").  Every float operation below is fixed, in this order, with explicit fma
-// where fused and -ffp-contract=off everywhere else, so that any IEEE-754 binary32
-// implementation (gfx950 VALU, or the CPU oracle's independent restatement in
-// oracle/triro_oracle.c) produces bit-identical hit masks, triangle indices and keys.
+// contract"; version 3, round 6).  Every operation below is fixed, in this order, with explicit fma
+// where fused and -ffp-contract=off everywhere else, so that any IEEE-754 implementation (gfx950
+// VALU, or the CPU oracle's independent restatement in oracle/triro_oracle.c) produces bit-identical
+// hit masks, triangle indices, distances and barycentrics.
 //
-// What the reference leaves to OptiX (optixTrace, shaders.cu:86,112,163,191,238; built-in
-// triangle test; optixGetTriangleBarycentrics :139; optixIsFrontFaceHit :151) is replaced
-// by: robust slab test -> Moller-Trumbore -> distance clamped into the triangle's own slab
-// interval.  The hit predicate is a pure function of (ray, triangle), therefore independent
-// of the BVH that finds the candidates.
+// What the reference leaves to OptiX (optixTrace, shaders.cu:86,112,163,191,238; built-in WATERTIGHT
+// triangle test; optixGetTriangleBarycentrics :139; optixIsFrontFaceHit :151) is replaced by:
+//   * inside test: Moller-Trumbore in float32 wherever its answer is PROVEN (a running bound on the
+//     rounding error of U, V, det - U - V; the three must clear it), and otherwise -- the ray passes
+//     within rounding of an edge, a vertex or the triangle's plane -- Woop / Benthin / Wald 2013 edge
+//     functions in float64 (tr_woop64): exact negations for the two triangles of a shared edge, zero
+//     counts as inside, so no ray slips between two triangles of a closed mesh;
+//   * distance: T / det in float32 where its relative error is proven below 2^-11, float64 otherwise;
+//   * outputs: the barycentrics of the WINNING triangle from the float64 edge functions.
+// The predicate is a pure function of (ray, triangle) -- no box, no clamp (contract 2 clamped the distance
+// into the triangle's own slab interval, 45 instructions per leaf test) -- and is independent of the BVH
+// that finds the candidates because (a) every box test accepts a box that the ray truly meets within
+// [0, limit] (robust slab test, TR_SLAB_PAD; conservative forms tr_bvh.h / tr_wide.h) and (b) boxes are
+// culled against the best distance times TR_CULL_SLACK, which exceeds what a float32 distance can be off by.
 #pragma once
 #include <math.h>
 #include <stdint.h>
@@ -16,6 +25,9 @@
 #if defined(__HIPCC__)
 #define TR_HD __host__ __device__ __forceinline__
 #define TR_HDM __host__ __device__ __forceinline__
+// a REAL call on the device: the float64 part of the inside test runs for ~1 % of the leaf tests and needs ~50 registers;
+// inlined it raised every traversal kernel's allocation (77 -> 117 VGPRs: four waves per SIMD instead of six)
+#define TR_HD_CALL static __host__ __device__ __attribute__((noinline))
 #if defined(__HIP_DEVICE_COMPILE__)
 // A convergent no-op: marks a point where all control-flow paths of a loop body must merge,
 // so that jump threading cannot give the loop several back edges (LLVM then nests the loop
@@ -32,17 +44,33 @@
 #define TR_WAVE_ANY(x) (x)
 #define TR_HD static inline
 #define TR_HDM inline
+#define TR_HD_CALL static inline
 #endif
 
 #define TR_TMIN 0.0f
 #define TR_TMAX 1.0e7f                          // shaders.cu:86 (tmax of every optixTrace)
 #define TR_HUGE 3.0e38f                         // finite stand-in for 1/0
-#define TR_SLAB_PAD 1.00000023841857910156f     // 1 + 2^-22 (Ize 2013 robust slab)
+// Robust slab (Ize 2013): a plane distance (lo - o) * inv is three roundings from the exact one (subtract, reciprocal,
+// multiply): within (1 +- 2^-24)^3.  An entry distance can come out 3 u too large and an exit distance 3 u too small, in
+// different axes; the exit is therefore padded by 1 + 8 u, which after its own rounding still leaves > (1 + 3 u)^2: a box
+// that the ray's line truly meets is accepted, whatever the roundings (contract 2 had 1 + 4 u: enough in practice, not
+// in proof).
+#define TR_SLAB_PAD 1.000000476837158203125f    // 1 + 2^-21
+// Culling of boxes against the best hit so far: a float32 distance accepted without float64 is within 2^-11 relative
+// of the exact one (tr_tri_test), a box's entry distance at most 3 u beyond the exact entry -- so a box is only culled
+// when its entry lies beyond best * (1 + 2^-10); TR_TLIM bounds the interval for the queries that do not cull.
+#define TR_CULL_SLACK 1.0009765625f             // 1 + 2^-10
+#define TR_TLIM 1.001e7f                        // > TR_TMAX * TR_CULL_SLACK
+// margins of the float32 inside test (u = 2^-24): see tr_tri_test
+#define TR_BAND_K 5.9604644775390625e-07f       // 10 u
+#define TR_BAND_ABS 7.888609052210118e-31f      // 2^-100
+#define TR_BAND_MAXLEN 1.099511627776e12f       // 2^40: lengths beyond it leave the float32 part undecided (overflow)
 
 struct tr_ray {
     float ox, oy, oz;
     float dx, dy, dz;
     float ix, iy, iz;   // clamped reciprocals
+    float kd;           // TR_BAND_K * (|dx| + |dy| + |dz|): the ray's factor of the inside test's error bound
     // byte selectors (v_perm_b32) that pick, from a grid node's 16-bit plane pairs, the planes this ray ENTERS a box
     // through (lo where its direction is positive, hi where negative) and the ones it leaves through (tr_qnode_slabs)
     uint32_t sel_n, sel_f, sel_z;
@@ -77,6 +105,7 @@ TR_HD bool tr_ray_setup(tr_ray& r, float ox, float oy, float oz, float dx, float
     r.ox = ox; r.oy = oy; r.oz = oz;
     r.dx = dx; r.dy = dy; r.dz = dz;
     r.ix = tr_inv(dx); r.iy = tr_inv(dy); r.iz = tr_inv(dz);
+    r.kd = ((fabsf(dx) + fabsf(dy)) + fabsf(dz)) * TR_BAND_K;
     {
         const bool nx = r.ix < 0.f, ny = r.iy < 0.f, nz = r.iz < 0.f;
         // v_perm_b32(hi_pair, lo_pair, sel): selector bytes 0-3 pick bytes of lo_pair, 4-7 of hi_pair
@@ -111,35 +140,107 @@ TR_HD float tr_dot(float ax, float ay, float az, float bx, float by, float bz) {
 }
 
 struct tr_hit {
-    float t;     // key distance (MT distance clamped into the triangle's slab interval)
-    float U, V;  // unnormalised barycentrics of vertices 1 and 2
-    float det;   // > 0 : front face (CCW from the ray origin)
+    float t;     // distance along the ray (parametric: P = o + t d)
 };
 
-// det, U, V of Moller-Trumbore for (ray, triangle) -- a pure function of its inputs: the
-// closest-hit kernels keep only (t_key, face, slot) per ray while traversing and call this
-// again on the winning triangle to get the same bits for the outputs.
-TR_HD void tr_tri_duv(const tr_ray& r, float ax, float ay, float az, float bx, float by, float bz,
-                      float cx, float cy, float cz, float& det, float& U, float& V) {
-    float e1x = bx - ax, e1y = by - ay, e1z = bz - az;
-    float e2x = cx - ax, e2y = cy - ay, e2z = cz - az;
-    float px = fmaf(r.dy, e2z, -(r.dz * e2y));
-    float py = fmaf(r.dz, e2x, -(r.dx * e2z));
-    float pz = fmaf(r.dx, e2y, -(r.dy * e2x));
-    det = tr_dot(e1x, e1y, e1z, px, py, pz);
-    float sx = r.ox - ax, sy = r.oy - ay, sz = r.oz - az;
-    U = tr_dot(sx, sy, sz, px, py, pz);
-    float qx = fmaf(sy, e1z, -(sz * e1y));
-    float qy = fmaf(sz, e1x, -(sx * e1z));
-    float qz = fmaf(sx, e1y, -(sy * e1x));
-    V = tr_dot(r.dx, r.dy, r.dz, qx, qy, qz);
+// ---- the EXACT part of the contract --------------------------------------------------------------------------------
+// Woop / Benthin / Wald 2013 edge functions in float64 from the float32 inputs, in projective form (multiplied through
+// by d[kz]: no division).  kz = the dominant axis of the direction (the first of equals), (kx, ky, kz) cyclic.  A
+// vertex P becomes P' = P - o and Ph = (P'x dz - dx P'z, P'y dz - dy P'z): a function of (vertex, ray) alone, so both
+// triangles of a shared edge see the same two points.  An edge function is the DIFFERENCE OF TWO ROUNDED PRODUCTS: its
+// sign is the exact sign of the 2D orientation of the rounded points, or zero (rounding is monotone), and swapping the
+// end points negates it exactly -- a ray cannot pass between two triangles that share an edge.
+struct tr_woop {
+    double U, V, W;      // weights of a, b, c (unnormalised): inside iff all >= 0 or all <= 0 (and not all zero)
+    double Az, Bz, Cz;   // P'z of the three vertices
+    double dz;           // d[kz]
+};
+// (x, y, z) here are already the permuted components (kx, ky, kz)
+TR_HD void tr_woop64_xyz(float ox, float oy, float oz, float dx, float dy, float dz, float ax, float ay, float az,
+                         float bx, float by, float bz, float cx, float cy, float cz, tr_woop& w) {
+    const double Dx = dx, Dy = dy, Dz = dz, Ox = ox, Oy = oy, Oz = oz;
+    const double Ax = (double)ax - Ox, Ay = (double)ay - Oy, Az = (double)az - Oz;
+    const double Bx = (double)bx - Ox, By = (double)by - Oy, Bz = (double)bz - Oz;
+    const double Cx = (double)cx - Ox, Cy = (double)cy - Oy, Cz = (double)cz - Oz;
+    const double ahx = fma(-Dx, Az, Ax * Dz), ahy = fma(-Dy, Az, Ay * Dz);
+    const double bhx = fma(-Dx, Bz, Bx * Dz), bhy = fma(-Dy, Bz, By * Dz);
+    const double chx = fma(-Dx, Cz, Cx * Dz), chy = fma(-Dy, Cz, Cy * Dz);
+    w.U = chx * bhy - chy * bhx;     // (two rounded products and a subtraction: NOT an fma)
+    w.V = ahx * chy - ahy * chx;
+    w.W = bhx * ahy - bhy * ahx;
+    w.Az = Az; w.Bz = Bz; w.Cz = Cz;
+    w.dz = Dz;
+}
+TR_HD void tr_woop64(float ox, float oy, float oz, float dx, float dy, float dz, float ax, float ay, float az,
+                     float bx, float by, float bz, float cx, float cy, float cz, tr_woop& w) {
+    int kz = 0;
+    float m = fabsf(dx);
+    if (fabsf(dy) > m) { kz = 1; m = fabsf(dy); }
+    if (fabsf(dz) > m) kz = 2;
+    // three copies of the arithmetic behind a branch instead of thirty selects in front of one: the lanes of a wave that
+    // get here are few
+    if (kz == 2) tr_woop64_xyz(ox, oy, oz, dx, dy, dz, ax, ay, az, bx, by, bz, cx, cy, cz, w);
+    else if (kz == 0) tr_woop64_xyz(oy, oz, ox, dy, dz, dx, ay, az, ax, by, bz, bx, cy, cz, cx, w);
+    else tr_woop64_xyz(oz, ox, oy, dz, dx, dy, az, ax, ay, bz, bx, by, cz, cx, cy, w);
+}
+// both windings; a zero edge function counts as inside (a ray through a shared edge hits both triangles)
+TR_HD bool tr_woop_inside(const tr_woop& w, double& det) {
+    const bool neg = (w.U < 0.0) | (w.V < 0.0) | (w.W < 0.0), pos = (w.U > 0.0) | (w.V > 0.0) | (w.W > 0.0);
+    det = (w.U + w.V) + w.W;
+    return !(neg & pos) & (det != 0.0);
+}
+TR_HD float tr_woop_t(const tr_woop& w, double det) {
+    return (float)(fma(w.W, w.Cz, fma(w.V, w.Bz, w.U * w.Az)) / (det * w.dz));
+}
+// The exact part as one function: true iff the ray hits the triangle within [0, 1e7]; t = the distance.
+// A REAL CALL on the device (TR_HD_CALL): it runs for < 1 % of the leaf tests and owns ~30 registers.
+TR_HD_CALL float tr_tri_exact_t(float ox, float oy, float oz, float dx, float dy, float dz, float ax, float ay, float az,
+                                float bx, float by, float bz, float cx, float cy, float cz) {
+    tr_woop w;
+    double d64;
+    tr_woop64(ox, oy, oz, dx, dy, dz, ax, ay, az, bx, by, bz, cx, cy, cz, w);
+    if (!tr_woop_inside(w, d64)) return -1.0f;        // (no accepted distance is negative)
+    return tr_woop_t(w, d64);
+}
+TR_HD bool tr_tri_exact(const tr_ray& r, float ax, float ay, float az, float bx, float by, float bz,
+                        float cx, float cy, float cz, tr_hit& h) {
+    const float t = tr_tri_exact_t(r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, ax, ay, az, bx, by, bz, cx, cy, cz);
+    h.t = t;
+    return t >= TR_TMIN && t <= TR_TMAX;
 }
 
-// Moller-Trumbore given the triangle's own slab interval [tn, tf].  Early exits are kept: in
-// a wave most candidate triangles fail on det / U / V, and the compiler skips the rest of the
-// test when no lane is left (s_cbranch_execz).
-TR_HD bool tr_tri_mt(const tr_ray& r, float ax, float ay, float az, float bx, float by, float bz,
-                     float cx, float cy, float cz, float tn, float tf, tr_hit& h) {
+// ---- the hit predicate: a pure function of (ray, triangle) ----------------------------------------------------------
+// The float32 part: Moller-Trumbore with fixed fma placement, both orientations through a sign flip:
+//   (Uf, Vf, Wf) = sign(det) * (U, V, det - U - V);  exact arithmetic: inside  <=>  all three >= 0 (det != 0).
+// Rounding: every product term of U = s . (d x e2) passes at most 7 roundings (s, e2, the inner product, the fma of the
+// cross product, the outer product, two accumulating fma) and the terms' magnitudes sum to at most |s|_inf |d|_1 |e2|_1;
+// the same for V with e1; det's terms to |d|_1 |e1|_inf |e2|_1 <= |d|_1 E^2 / 4 with E = |e1|_1 + |e2|_1.  Hence, with
+// D1 = |det| - Uf and Wf = D1 - Vf,
+//   |Uf - exact| + |Vf - exact| <= 7 u |s|_inf |d|_1 E,   |det - exact| <= 2 u |d|_1 E^2,
+//   |D1 - exact|, |Wf - exact| <= 8 u |s|_inf |d|_1 E + 2 u |d|_1 E^2   (the roundings of the two subtractions included),
+// and with mm = 10 u |d|_1 E (|s|_inf + E) + 2^-100  (> every bound above + det's, the quantities of mm itself rounded):
+//   Uf < -mm, Vf < -mm or Wf < -mm : that exact value is < 0, and since |det| cannot be wrong by more than mm another
+//                                    one is > 0                                              -> outside, proven;
+//   D1 < -2 mm                     : Vf + Wf < -mm exactly, so one of them is < 0, and Uf > 0  -> outside, proven
+//                                    (known before V is: half of the candidates leave after U);
+//   min3(Uf, Vf, Wf) > mm          : all three exact values are > 0 with the true sign of det -> inside, proven;
+//   otherwise                      : undecided -- the float64 edge functions decide (NaN / inf from overflowing
+//                                    coordinates land here, too).
+// The bounds assume that no product overflows and that what underflows (an absolute error of 2^-149 per product, times
+// one more factor) stays below the 2^-100 in mm: both hold while |s|_inf + E and |d|_1 are at most 2^40 (1.1e12) --
+// larger lengths are left UNDECIDED, tiny ones are undecided by themselves (|Uf| < 2^-100).  The distance of a proven hit: t = T / det in float32 when |T| and |det| exceed
+// 2^12 x their own error bounds (4 u |s|_inf E^2 and 4 u |d|_1 E^2: relative error of t < 2^-11, what TR_CULL_SLACK
+// absorbs), otherwise undecided, too.  Accepted iff 0 <= t <= 1e7 (shaders.cu:86: tmin 0, tmax 1e7; no culling).
+// Early exits are kept: in a wave most candidate triangles are proven outside, and the compiler skips the rest when no
+// lane is left (s_cbranch_execz).
+enum { TR_MISS = 0, TR_HIT = 1, TR_UNDECIDED = 2 };
+TR_HD float tr_tri_scale(float ax, float ay, float az, float bx, float by, float bz, float cx, float cy, float cz) {
+    const float e1x = bx - ax, e1y = by - ay, e1z = bz - az;
+    const float e2x = cx - ax, e2y = cy - ay, e2z = cz - az;
+    return ((fabsf(e1x) + fabsf(e1y)) + fabsf(e1z)) + ((fabsf(e2x) + fabsf(e2y)) + fabsf(e2z));
+}
+TR_HD int tr_tri_fast(const tr_ray& r, float ax, float ay, float az, float bx, float by, float bz,
+                      float cx, float cy, float cz, tr_hit& h) {
     float e1x = bx - ax, e1y = by - ay, e1z = bz - az;
     float e2x = cx - ax, e2y = cy - ay, e2z = cz - az;
     // p = d x e2
@@ -147,28 +248,71 @@ TR_HD bool tr_tri_mt(const tr_ray& r, float ax, float ay, float az, float bx, fl
     float py = fmaf(r.dz, e2x, -(r.dx * e2z));
     float pz = fmaf(r.dx, e2y, -(r.dy * e2x));
     float det = tr_dot(e1x, e1y, e1z, px, py, pz);
-    if (det == 0.0f) return false;
     float sx = r.ox - ax, sy = r.oy - ay, sz = r.oz - az;
     float U = tr_dot(sx, sy, sz, px, py, pz);
+    const uint32_t flip = tr_f2u(det) & 0x80000000u;
+    const float Uf = tr_u2f(tr_f2u(U) ^ flip);
+    const float E = ((fabsf(e1x) + fabsf(e1y)) + fabsf(e1z)) + ((fabsf(e2x) + fabsf(e2y)) + fabsf(e2z));
+    const float Ls = fmaxf(fmaxf(fabsf(sx), fabsf(sy)), fabsf(sz));
+#ifdef TR_KD_LOCAL      // (experiment: one register of ray constants less, three instructions per leaf test more)
+    const float kd = ((fabsf(r.dx) + fabsf(r.dy)) + fabsf(r.dz)) * TR_BAND_K;
+#else
+    const float kd = r.kd;
+#endif
+    const float kE = kd * E;
+    const float LsE = Ls + E;
+    const float mm = fmaf(kE, LsE, TR_BAND_ABS);
+    // the bounds hold while nothing overflows and what underflows stays below the 2^-100 of mm: lengths up to 2^40
+    if (!((LsE <= TR_BAND_MAXLEN) & (kd <= TR_BAND_K * TR_BAND_MAXLEN))) return TR_UNDECIDED;      // (NaN, too)
+    const float D1 = fabsf(det) - Uf;
+    if ((Uf < -mm) | (D1 < -(mm + mm))) return TR_MISS;
     // q = s x e1
     float qx = fmaf(sy, e1z, -(sz * e1y));
     float qy = fmaf(sz, e1x, -(sx * e1z));
     float qz = fmaf(sx, e1y, -(sy * e1x));
     float V = tr_dot(r.dx, r.dy, r.dz, qx, qy, qz);
-    // inside test, both orientations at once: flipping the sign of U, V and det when det < 0
-    // is exact (and -(U+V) == (-U)+(-V)), so  det>0 ? (U>=0 && V>=0 && U+V<=det)
-    //                                              : (U<=0 && V<=0 && U+V>=det)
-    // becomes three compares on the flipped values -- no branch on the orientation.
-    const uint32_t flip = tr_f2u(det) & 0x80000000u;
-    const float Uf = tr_u2f(tr_f2u(U) ^ flip), Vf = tr_u2f(tr_f2u(V) ^ flip);
-    const bool ok = (Uf >= 0.0f) & (Vf >= 0.0f) & ((Uf + Vf) <= fabsf(det));
-    if (!ok) return false;
-    float T = tr_dot(e2x, e2y, e2z, qx, qy, qz);
-    float t = T / det;
-    float tk = fminf(fmaxf(t, tn), tf);
-    if (!(tk >= TR_TMIN && tk <= TR_TMAX)) return false;
-    h.t = tk; h.U = U; h.V = V; h.det = det;
-    return true;
+    const float Vf = tr_u2f(tr_f2u(V) ^ flip);
+    const float Wf = D1 - Vf;
+    if ((Vf < -mm) | (Wf < -mm)) return TR_MISS;
+    if (!(fminf(fminf(Uf, Vf), Wf) > mm)) return TR_UNDECIDED;
+    const float T = tr_dot(e2x, e2y, e2z, qx, qy, qz);
+    if (!(fabsf(det) >= (kE * E) * 1024.0f) | !(fabsf(T) >= (Ls * 9.765625e-4f) * (E * E))) return TR_UNDECIDED;
+    const float t = T / det;
+    h.t = t;
+    return (t >= TR_TMIN && t <= TR_TMAX) ? TR_HIT : TR_MISS;
+}
+// the whole predicate in one call (brute force, single-triangle meshes, host code); the traversal kernels run the two
+// parts apart (tr_fold_leaf / tr_drain_exact, tr_bvh.h)
+TR_HD bool tr_tri_test(const tr_ray& r, float ax, float ay, float az, float bx, float by, float bz,
+                       float cx, float cy, float cz, tr_hit& h) {
+    const int c = tr_tri_fast(r, ax, ay, az, bx, by, bz, cx, cy, cz, h);
+    if (c != TR_UNDECIDED) return c == TR_HIT;
+    return tr_tri_exact(r, ax, ay, az, bx, by, bz, cx, cy, cz, h);
+}
+
+// outputs of a hit (shaders.cu:137-153).  The reference returns uv = (1-u-v, u) with (u, v) OptiX' barycentrics = the
+// weights of face vertices 1 and 2 (:139,149), i.e. uv = (w0, w1), the weights of vertices 0 and 1 -- here each the
+// float32 rounding of a float64 quotient of the edge functions of (ray, WINNING triangle), so both are correctly
+// rounded whatever their magnitude; front (optixIsFrontFaceHit, :151) = counter-clockwise seen from the origin =
+// d . ((b - a) x (c - a)) < 0  <=>  the edge functions' sum and d[kz] have the same sign.
+// (a real call on the device, like the exact part of the predicate: the float64 arithmetic keeps its ~30 registers to
+// itself -- inlined into the streaming kernels' refill path it sent 20-28 values of the persistent loop to scratch)
+struct tr_bary { float w0, w1; int front; };
+TR_HD_CALL tr_bary tr_tri_bary_call(float ox, float oy, float oz, float dx, float dy, float dz, float ax, float ay, float az,
+                                    float bx, float by, float bz, float cx, float cy, float cz) {
+    tr_woop w;
+    tr_woop64(ox, oy, oz, dx, dy, dz, ax, ay, az, bx, by, bz, cx, cy, cz, w);
+    const double det = (w.U + w.V) + w.W;
+    tr_bary o;
+    o.w0 = (float)(w.U / det);
+    o.w1 = (float)(w.V / det);
+    o.front = ((det < 0.0) == (w.dz < 0.0)) ? 1 : 0;
+    return o;
+}
+TR_HD void tr_tri_bary(const tr_ray& r, float ax, float ay, float az, float bx, float by, float bz,
+                       float cx, float cy, float cz, float& w0, float& w1, bool& front) {
+    const tr_bary o = tr_tri_bary_call(r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, ax, ay, az, bx, by, bz, cx, cy, cz);
+    w0 = o.w0; w1 = o.w1; front = o.front != 0;
 }
 
 // Box of a triangle, padded outward by |x|*2^-21 + 2^-100 per bound.  The padding makes a
@@ -186,41 +330,29 @@ TR_HD void tr_tri_box(float ax, float ay, float az, float bx, float by, float bz
     l = fminf(fminf(az, bz), cz); h = fmaxf(fmaxf(az, bz), cz); lo[2] = l - tr_pad(l); hi[2] = h + tr_pad(h);
 }
 
-// full predicate: slab of the triangle's box, then MT (used where the box is not already
-// known from the parent node, e.g. the brute-force kernel for single-triangle meshes)
-TR_HD bool tr_tri_hit(const tr_ray& r, float ax, float ay, float az, float bx, float by, float bz,
-                      float cx, float cy, float cz, tr_hit& h) {
-    float lo[3], hi[3], tn, tf;
-    tr_tri_box(ax, ay, az, bx, by, bz, cx, cy, cz, lo, hi);
-    tr_slab(r, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], tn, tf);
-    if (!tr_slab_hit(tn, tf, TR_TMAX)) return false;
-    return tr_tri_mt(r, ax, ay, az, bx, by, bz, cx, cy, cz, tn, tf, h);
-}
-
 // (t, tri) lexicographic order used for closest hit and multi-hit ordering
 TR_HD bool tr_closer(float t, int32_t tri, float bt, int32_t btri) {
     return (t < bt) || (t == bt && tri < btri);
 }
 
-// outputs of a hit: shaders.cu:137-153.  loc = u*V1 + v*V2 + (1-u-v)*V0 (:143-146),
-// uv = (1-u-v, u) (:149).  In two steps so that a result can travel as (triangle, u, v) -- 12 bytes
+// loc = u*V1 + v*V2 + (1-u-v)*V0 (shaders.cu:143-146) in float32 from the float32 (w0, w1): w2 = (1 - w0) - w1,
+// loc = fma(w0, V0, fma(w2, V2, w1 * V1)); uv = (w0, w1) (:149).  A result can travel as (triangle, w0, w1) -- 12 bytes
 // instead of 26 -- and be expanded elsewhere with the very same operations (tr_closest_expand).
-TR_HD void tr_hit_bary(const tr_hit& h, float& u, float& v) {
-    u = h.U / h.det;
-    v = h.V / h.det;
-}
-TR_HD void tr_bary_outputs(float u, float v, float ax, float ay, float az, float bx, float by,
+TR_HD void tr_bary_outputs(float w0, float w1, float ax, float ay, float az, float bx, float by,
                            float bz, float cx, float cy, float cz, float* loc, float* uv) {
-    float w = (1.0f - u) - v;
-    loc[0] = fmaf(w, ax, fmaf(v, cx, u * bx));
-    loc[1] = fmaf(w, ay, fmaf(v, cy, u * by));
-    loc[2] = fmaf(w, az, fmaf(v, cz, u * bz));
-    uv[0] = w;
-    uv[1] = u;
+    const float w2 = (1.0f - w0) - w1;
+    loc[0] = fmaf(w0, ax, fmaf(w2, cx, w1 * bx));
+    loc[1] = fmaf(w0, ay, fmaf(w2, cy, w1 * by));
+    loc[2] = fmaf(w0, az, fmaf(w2, cz, w1 * bz));
+    uv[0] = w0;
+    uv[1] = w1;
 }
-TR_HD void tr_hit_outputs(const tr_hit& h, float ax, float ay, float az, float bx, float by,
+// all outputs of the hit of ray r on the triangle; returns front
+TR_HD bool tr_hit_outputs(const tr_ray& r, float ax, float ay, float az, float bx, float by,
                           float bz, float cx, float cy, float cz, float* loc, float* uv) {
-    float u, v;
-    tr_hit_bary(h, u, v);
-    tr_bary_outputs(u, v, ax, ay, az, bx, by, bz, cx, cy, cz, loc, uv);
+    float w0, w1;
+    bool front;
+    tr_tri_bary(r, ax, ay, az, bx, by, bz, cx, cy, cz, w0, w1, front);
+    tr_bary_outputs(w0, w1, ax, ay, az, bx, by, bz, cx, cy, cz, loc, uv);
+    return front;
 }

@@ -30,7 +30,7 @@ MAX_ANYHIT_SIZE = 8   # LaunchParams.h:8
 MAX_SIZE_LENGTH = 4   # LaunchParams.h:9
 
 _LIB_NAME = "libtriro_hip.so"
-ABI_VERSION = 9     # TR_ABI_VERSION of include/triro_hip.h this binding was written against
+ABI_VERSION = 10    # TR_ABI_VERSION of include/triro_hip.h this binding was written against
 _lib = None
 _lib_error = None
 
@@ -125,7 +125,7 @@ def get_module():
         fn = getattr(lib, name)   # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.tr_abi_version() != ABI_VERSION:
+    if lib.tr_abi_version() != ABI_VERSION and os.environ.get("TRIRO_ABI_ANY") != "1":      # (TRIRO_ABI_ANY=1: A/B runs against an older build)
         raise RuntimeError(f"libtriro_hip.so ABI version {lib.tr_abi_version()} != {ABI_VERSION} expected by this binding")
     _lib = lib
     return _lib
@@ -421,6 +421,7 @@ def intersects_location(accel_structure, origins, dirs, ray_base: int = 0, fused
     dev = origins.device
     lib = get_module()
     n = origins.numel() // 3
+    _check_ray_idx_range(n, ray_base, "intersects_location / intersects_id")
     if fused:
         with torch.cuda.device(dev):
             stream = _stream_ptr(dev)
@@ -462,6 +463,16 @@ def intersects_location(accel_structure, origins, dirs, ray_base: int = 0, fused
     return loc, ray, tri
 
 
+def _check_ray_idx_range(n: int, ray_base: int, what: str):
+    """ray_idx outputs are int32 by API (ray_optix.py:143-144 `arange(..., dtype=int32)`, ray.cpp:352): a flat ray index of
+    2^31 or more does not fit.  The reference's device code overflows silently far earlier (`int` arithmetic on idx * 3
+    in getRay, shaders.cu:37: from 715 827 883 rays on); here the traversal is 64-bit throughout (intersects_any / first /
+    closest / count take batches of 2^31 rays and more, tests/test_gpu_round6.py) and the queries that RETURN ray indices
+    refuse what their output type cannot hold."""
+    if n + int(ray_base) >= (1 << 31):
+        raise ValueError(f"{what}: {n} rays (+ ray_base {ray_base}) reach 2^31: beyond the int32 ray_idx of the API; split the batch")
+
+
 def compact_closest(hit, front, tri, loc, uv, ray_base: int = 0):
     """Fused stream compaction (ray_optix.py:142-144: five boolean-mask gathers, one host
     sync each) -> one scan + one gather kernel, one host sync for the size.
@@ -469,6 +480,7 @@ def compact_closest(hit, front, tri, loc, uv, ray_base: int = 0):
     dev = hit.device
     lib = get_module()
     n = hit.numel()
+    _check_ray_idx_range(n, ray_base, "stream compaction")
     with torch.cuda.device(dev):
         stream = _stream_ptr(dev)
         offsets = torch.empty(n, dtype=torch.int64, device=dev)

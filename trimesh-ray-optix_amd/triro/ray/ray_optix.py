@@ -105,6 +105,8 @@ class RayMeshIntersector:
         """ray_optix.py:117-146.
         stream_compaction=False -> (hit[*b], front[*b], tri_idx[*b], loc[*b,3], uv[*b,2])
         stream_compaction=True  -> (hit[*b], front[h], ray_idx[h], tri_idx[h], loc[h,3], uv[h,2])"""
+        if stream_compaction:      # ray_idx is int32 by API: refuse before tracing what it cannot index
+            hops._check_ray_idx_range(origins.numel() // 3, 0, "intersects_closest(stream_compaction=True)")
         hit, front, tri_idx, loc, uv = hops.intersects_closest(self.as_wrapper, origins, directions)
         if stream_compaction:
             front_c, ray_idx, tri_c, loc_c, uv_c = hops.compact_closest(hit, front, tri_idx, loc, uv)
@@ -185,6 +187,7 @@ class RayMeshIntersector:
             if return_locations:
                 return tri_idx, ray_idx, loc
             return tri_idx, ray_idx
+        hops._check_ray_idx_range(origins.numel() // 3, 0, "intersects_id")
         hit, _, tri_idx, loc, _ = hops.intersects_closest(self.as_wrapper, origins, directions)
         _, ray_idx, tri_c, loc_c, _ = hops.compact_closest(hit, None, tri_idx, loc if return_locations else None, None)
         if return_locations:

@@ -251,7 +251,7 @@ class ShardedRayMeshIntersector:
         self._slots_on = os.environ.get("TRIRO_PACKED_SLOTS", "1") != "0"
         # 4-byte records (the slot alone) where the destination holds the rays: TRIRO_SLOT_RECORDS=0 keeps the 12-byte ones
         self._slot_records_on = os.environ.get("TRIRO_SLOT_RECORDS", "1") != "0"
-        self._fp_key, self._fp_ok = None, None       # replica handshake (_replicas_agree)
+        self._fp_key, self._fp_ok, self._rec_ok = None, None, False       # replica handshake (_replicas_agree)
         self._scratch_bufs = {}
         self._side = None      # side stream of the destination rank (wait for chunk, expand)
         # ctrl_group: a gloo group over the SAME ranks as `group` (bench.py creates one next to the RCCL communicator):
@@ -268,7 +268,10 @@ class ShardedRayMeshIntersector:
         """the rung of LADDER a gathered closest-hit query takes: "slot" degrades by itself to "packed" where the
         tracer has no 4-byte records or the replicas differ, "packed" to "dense" where it has no packed records"""
         m = self._mode
-        if m == "slot" and not (self._can_pack() and self.slot_records):
+        # (the handshake first, whatever this rank can do itself: it is a collective -- ADVICE r05: a rank without packed
+        # records or with TRIRO_SLOT_RECORDS=0 short-circuited past it and left its peers waiting in the all-gather)
+        slot_records = self.slot_records
+        if m == "slot" and not (self._can_pack() and slot_records):
             m = "packed"
         if m == "packed" and not self._can_pack():
             m = "dense"
@@ -327,16 +330,31 @@ class ShardedRayMeshIntersector:
         rungs = list(ladder) if ladder is not None else list(LADDER[LADDER.index(self._mode):])
         if "staged" in rungs and self.ctrl_group is None and not self._base_stage[0]:
             rungs.remove("staged")
-        requested = self.exchange_mode
+        # reading `exchange_mode` can itself be first contact with the data communicator (the replica
+        # handshake: a hash kernel + an all-gather).  An exception there is a failed rung like any other: it is caught,
+        # the verdict is all-reduced on the control group and every rank steps down together.
+        try:
+            requested = self.exchange_mode
+        except Exception as exc:      # noqa: BLE001
+            requested = f"unknown ({type(exc).__name__}: {exc})"
         attempts = []
         want_out = None
         for mode in rungs:
             self.set_exchange_mode(mode)
-            eff = self.exchange_mode          # (what this rung really does here: every rank sees the same)
+            ok, reason, eff = True, "", None
+            try:
+                eff = self.exchange_mode          # (what this rung really does here: every rank sees the same)
+            except Exception as exc:      # noqa: BLE001
+                ok, reason = False, f"handshake: {type(exc).__name__}: {exc}"
+                self._fp_ok, self._rec_ok, self._fp_key = False, False, self._handshake_key()      # do not enter that collective again for this hierarchy
+            if not self._agree(ok):
+                attempts.append({"mode": mode, "ok": False, "reason": reason or "the handshake failed on another rank"})
+                if ok:
+                    self._fp_ok, self._rec_ok, self._fp_key = False, False, self._handshake_key()
+                continue
             if eff != mode:
                 attempts.append({"mode": mode, "ok": False, "reason": f"not available here (would run as '{eff}')"})
                 continue
-            ok, reason = True, ""
             try:
                 if mode in os.environ.get("TRIRO_PREFLIGHT_FAIL", "").split(","):
                     # test hook: make a rung fail on purpose (every rank alike), e.g. to rehearse the fallbacks on real hardware
@@ -376,30 +394,57 @@ class ShardedRayMeshIntersector:
         enters whatever its own answer is (a rank that skipped it left the others waiting); any 0 or any
         difference switches EVERY rank to the face form (they all see the same gathered values) instead of returning
         wrong triangles.  Repeated when the local hierarchy changes (`generation`: update_raw, refit, load)."""
-        if not hasattr(self.local, "replica_hash") and not hasattr(self.local, "replica_fingerprint"):
-            return True              # (stand-in tracers of the CPU tests: no arena, nothing to compare)
         if self.world < 2 or not dist.is_initialized():
             return True
-        info = self.local.bvh_info() if hasattr(self.local, "bvh_info") else {}
-        key = (getattr(self.local, "generation", None), info.get("num_tris"), info.get("num_nodes"), info.get("arena_bytes"))
+        key = self._handshake_key()
         if self._fp_key != key or self._fp_ok is None:
+            # Two words per rank.  [0] the hash of the arena, 0 = "no slot form here" (switched off, an older library, a mesh
+            # beyond its range, a stand-in tracer with no arena and no slot form); a stand-in tracer that HAS slot records
+            # but no arena to hash (CPU tests) reports 1.  [1] can this rank send / finish 4-byte records at all
+            # (TRIRO_SLOT_RECORDS, the tracer's slot_records, packed records) -- ADVICE r05: that capability used to be
+            # tested in front of the collective, so a rank without it never entered.
+            has_hash = hasattr(self.local, "replica_hash") or hasattr(self.local, "replica_fingerprint")
             capable = self._slots_on and bool(getattr(self.local, "packed_slots", False))
             fp = 0
-            if capable:
-                fn = getattr(self.local, "replica_hash", None) or self.local.replica_fingerprint
-                fp = (int(fn()) & 0x7fffffffffffffff) or 1
-            cdev = torch.device("cpu") if self._stage or not torch.cuda.is_available() else torch.device("cuda", torch.cuda.current_device())
-            mine = torch.tensor([fp], dtype=torch.int64, device=cdev)
-            every = torch.empty((self.world,), dtype=torch.int64, device=cdev)
-            dist.all_gather_into_tensor(every, mine, group=self._xg)
-            vals = [int(x) for x in every.tolist()]
+            if capable and has_hash:
+                try:      # a rank whose hash kernel fails still enters the all-gather, as "no slot form here"
+                    fn = getattr(self.local, "replica_hash", None) or self.local.replica_fingerprint
+                    fp = (int(fn()) & 0x7fffffffffffffff) or 1
+                except Exception:      # noqa: BLE001
+                    fp = 0
+            elif capable:
+                fp = 1
+            rec = 1 if (capable and hasattr(self.local, "intersects_closest_packed") and hasattr(self.local, "closest_expand")
+                        and bool(getattr(self.local, "slot_records", False))
+                        and os.environ.get("TRIRO_SLOT_RECORDS", "1") != "0") else 0
+            # 16 bytes per rank: over the control group (gloo, host tensors) where there is one, so that the handshake is
+            # not the first thing the data communicator ever does (ADVICE r05)
+            if self.ctrl_group is not None:
+                mine = torch.tensor([fp, rec], dtype=torch.int64)
+                parts = [torch.zeros(2, dtype=torch.int64) for _ in range(self.world)]
+                dist.all_gather(parts, mine, group=self.ctrl_group)
+                got = [int(x) for part in parts for x in part.tolist()]
+            else:
+                cdev = torch.device("cpu") if self._stage or not torch.cuda.is_available() else torch.device("cuda", torch.cuda.current_device())
+                mine = torch.tensor([fp, rec], dtype=torch.int64, device=cdev)
+                every = torch.empty((2 * self.world,), dtype=torch.int64, device=cdev)
+                dist.all_gather_into_tensor(every, mine, group=self._xg)
+                got = [int(x) for x in every.tolist()]
+            vals, recs = got[0::2], got[1::2]
             self._fp_ok = all(x == vals[0] for x in vals) and vals[0] != 0
+            self._rec_ok = self._fp_ok and all(x == 1 for x in recs)
             self._fp_key = key
             if not self._fp_ok and self.rank == 0 and any(vals):
                 import warnings
                 warnings.warn("triro.ray.sharded: the ranks' BVH replicas differ (or some rank has no slot form); closest-hit "
                               "records fall back to the face form (12 bytes per ray)")
         return self._fp_ok
+
+    def _handshake_key(self):
+        """what the cached verdict of the replica handshake belongs to: this hierarchy, these switches"""
+        info = self.local.bvh_info() if hasattr(self.local, "bvh_info") else {}
+        return (getattr(self.local, "generation", None), info.get("num_tris"), info.get("num_nodes"), info.get("arena_bytes"),
+                self._slots_on, os.environ.get("TRIRO_SLOT_RECORDS", "1") != "0")
 
     @property
     def slots(self) -> bool:
@@ -413,7 +458,11 @@ class ShardedRayMeshIntersector:
 
     @property
     def slot_records(self) -> bool:
-        return self._slot_records_on and self.slots and bool(getattr(self.local, "slot_records", False))
+        # (the handshake first, unconditionally: see `slots`; EVERY rank must be able to use 4-byte records)
+        agree = self._replicas_agree()
+        rec_ok = self._rec_ok if (self.world >= 2 and dist.is_initialized()) else True
+        return (agree and rec_ok and self._slot_records_on and self._slots_on and bool(getattr(self.local, "packed_slots", False))
+                and bool(getattr(self.local, "slot_records", False)))
 
     @slot_records.setter
     def slot_records(self, on: bool):
@@ -749,7 +798,7 @@ class ShardedRayMeshIntersector:
                     if deferred is None:
                         deferred = exc
                     if not dense_mine and mine is not None:
-                        mine[a:z].fill_(-1)
+                        mine[a:z].fill_(-1)      # (bit 31 of the first word set = a miss, the other words are ignored: include/triro_hip.h, tr_packed_hit)
             if world > 1 or self.force_collectives:
                 if dense_mine:
                     # nothing of this rank travels: it only receives (its own rows of packed_all stay unused).
