@@ -1186,11 +1186,22 @@ def run_emulation(args):
             out_ = pending.pop(0).wait()
         return out_
     out = None
+
+    def device_mallocs():
+        st = torch.cuda.memory_stats(dev)
+        return int(st.get("num_device_alloc", 0)), int(st.get("num_device_free", 0))
     with trace_ctx():
+        # The warm-up keeps the previous step's outputs alive exactly as the timed loop does (round 6).  Until then it
+        # dropped them at once, the timed loop -- two steps in flight + the result the caller still holds -- needed a THIRD
+        # 26-B-per-ray output pool (2.6 GB at 100 M rays), and that one hipMalloc sat inside the clock: 1 ms on pristine
+        # device memory, 50-60 ms when the driver first has to scrub pages earlier processes used -- round 5's "bistable"
+        # rank-0 step (1.74 / 7.5 ms for 10 timed steps: profiles/r06_emulate_bistable.txt has the kernel trace with the gap).
         for _ in range(warm):
-            step()
-        drain()
+            o_k = step()
+            out = o_k if o_k is not None else out
+        out = drain() or out
         sync()
+        m0 = device_mallocs()
         t0 = time.perf_counter()
         for _ in range(steps):
             o_k = step()
@@ -1198,6 +1209,7 @@ def run_emulation(args):
         out = drain() or out
         sync()
         rank0_ms = (time.perf_counter() - t0) / steps * 1e3
+        m1 = device_mallocs()
     # the same without the peers (own shard only, dense): what the arrivals + expansions add
     for _ in range(warm):
         r.intersects_closest(o0, d0)
@@ -1265,6 +1277,7 @@ def run_emulation(args):
                       "expansion_rays": pz - pa,
                       "expansion_GBps": round((pz - pa) * (54 if slot_rec else 38) / (expand_ms * 1e-3) / 1e9, 1) if expand_ms > 0 else None,
                       "implied_scaling_vs_1gpu": round(implied, 3),
+                      "device_mallocs_in_timed_region": m1[0] - m0[0], "device_frees_in_timed_region": m1[1] - m0[1],
                       "note": "implied = N x plain / max(rank0, peer) for weak scaling, plain / max(rank0, peer) for strong; "
                               "arrival = device-to-device copies (read + write; an xGMI receive only writes); link time is not "
                               "modelled (12-byte records: 12.6 MB per peer and 1 M rays = 0.2 ms on one 76.8 GB/s link direction at 80 %; "

@@ -206,7 +206,9 @@ int tr_closest_from_slots(const tr_bvh *bvh, const tr_rays *rays, const int32_t 
  *    handles with the same hash name the same triangles by the same slots and hold the same vertices for them (up to a
  *    2^-64 collision), so slot-form records of one can be finished on the other; a sharded front end compares the ranks'
  *    hashes before it lets such records travel (triro/ray/sharded.py).  One pass over the arena (63 MB at 1.31 M
- *    triangles), synchronises `stream`.  The reference has no counterpart (single GPU: base.cpp:15-17).        */
+ *    triangles), synchronises `stream` (refused with TR_ERR_INVALID_ARG on a stream that is being captured).  The hash
+ *    covers the slot -> triangle identity ONLY -- what slot-form records need --, not the node arrays, the key mode or the
+ *    node layout.  The reference has no counterpart (single GPU: base.cpp:15-17).        */
 int tr_bvh_replica_hash(const tr_bvh *bvh, uint64_t *h_hash, void *stream);
 
 /* -- multi-hit (intersectsLocation, ray.cpp:324-378):
@@ -265,7 +267,7 @@ int tr_trace_stats_query(const tr_bvh *bvh, const tr_rays *rays, int query, tr_t
  *        previous launch of the same batch shape on the same (handle, stream)), "order_transfer" (0/1: the first launch of a
  *        new image resolution starts from the previous resolution's costs, resampled), "sort_inline" (0/1: in the steady
  *        state the sort of the measured costs rides in the next launch of the shape as one workgroup instead of running as
- *        a kernel behind the measuring launch), "xcd_chunk" (blocks of 256 rays per
+ *        a kernel behind the measuring launch), "xcd_chunk" (blocks of 128 rays per
  *        XCD-local chunk of the block -> ray map, 0 = identity), "compact" (0/1: 32-bit offsets / trail words where the
  *        hierarchy permits),
  *      "steal" (intra-wave work stealing: 0 off / 1 closest, first and any up to 4 M rays -- a ray gives subtrees away from its
@@ -282,7 +284,7 @@ int tr_trace_stats_query(const tr_bvh *bvh, const tr_rays *rays, int query, tr_t
  *      "stream" (0 never / 1 auto: batches above 4 M rays (count: from 16 M on) that a probe on the device finds incoherent / 2 always: the
  *        streaming launch with wave-level ray refill), "stream_rays", "stream_refill", "stream_dynamic" (rays per range,
  *        idle lanes that trigger a refill -- 0 = by query: 28 closest / first, 20 any / count --, ranges handed out by a work counter),
- *      "wide" (0 never / 1 always / 2 from 1 M triangles on: the streaming launch walks 8-wide nodes with 8-bit child boxes,
+ *      "wide" (0 never / 1 always / 2 (default) on meshes from 1 M triangles on AND batches from 8 M rays on: the streaming launch walks 8-wide nodes with 8-bit child boxes,
  *        built on the first query that wants them), "wide_direct" (0 never / 1 multi-hit list launches on meshes from 500 k
  *        triangles on / 2 count and location / 3 every query: the direct launch on the 8-wide nodes), "wide_stack" (1..12:
  *        entries of a lane's node stack kept in LDS; the rest spills to global memory),

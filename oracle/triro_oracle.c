@@ -43,7 +43,7 @@
  *          (Uf,Vf) = (U,V) with the sign bit of det flipped in; D1 = |det| - Uf; Wf = D1 - Vf; m3 = min(min(Uf,Vf),Wf)
  *   bound: E = (|e1x|+|e1y|+|e1z|) + (|e2x|+|e2y|+|e2z|), Ls = max|s_i|, kd = (|dx|+|dy|+|dz|) * 10*2^-24,
  *          mm = fma(kd*E, Ls+E, 2^-100)  -- exceeds the rounding error of Uf, Vf, Wf and det (proof: tr_math.h);
- *          Ls+E > 2^40 or kd > 10*2^-24*2^40 (or NaN) -> the float32 part does not answer (overflow)
+ *          Ls+E > 2^40 or |d|_1 > 2^40 (kd = inf) or NaN -> the float32 part does not answer (overflow)
  *   inside: Uf < -mm or D1 < -2mm or Vf < -mm or Wf < -mm -> outside (proven);  m3 > mm -> inside (proven), t = T/det in float32 provided
  *          |det| >= (kd*E*E)*1024 and |T| >= (Ls*2^-10)*(E*E) (relative error of t < 2^-11);
  *          anything else (also NaN) -> the EXACT part: Woop / Benthin / Wald 2013 edge functions in float64 from the
@@ -132,7 +132,10 @@ static void ray_setup(ray_t *r, const float *o, const float *d) {
         if (fabsf(inv) > TR_HUGE) inv = copysignf(TR_HUGE, d[i]);
         r->inv[i] = inv;
     }
-    r->kd = ((fabsf(d[0]) + fabsf(d[1])) + fabsf(d[2])) * TR_BAND_K;
+    {
+        const float l1 = (fabsf(d[0]) + fabsf(d[1])) + fabsf(d[2]);
+        r->kd = l1 <= TR_BAND_MAXLEN ? l1 * TR_BAND_K : INFINITY; /* too long: the float32 part does not answer */
+    }
     r->valid = ok;
 }
 
@@ -242,7 +245,7 @@ static inline int tri_hit(const ray_t *r, const float *a, const float *b, const 
     __atomic_fetch_add(&g_leaf_tests, 1, __ATOMIC_RELAXED);
 #endif
     /* lengths beyond 2^40 (overflow) and NaN: the float32 part does not answer */
-    int exact = !(LsE <= TR_BAND_MAXLEN && r->kd <= TR_BAND_K * TR_BAND_MAXLEN);
+    int exact = !(LsE <= TR_BAND_MAXLEN);
     float V = 0.0f, Vf = 0.0f, Wf = 0.0f;
     if (!exact) {
         if (Uf < -mm || D1 < -(mm + mm)) return 0; /* proven outside, known before V is */

@@ -224,7 +224,8 @@ void* sim_build(const float* verts, int64_t nv, const int32_t* faces, int64_t nf
         t.ax = a[0]; t.ay = a[1]; t.az = a[2];
         t.bx = bb[0]; t.by = bb[1]; t.bz = bb[2];
         t.cx = c[0]; t.cy = c[1]; t.cz = c[2];
-        t.face = (int32_t)f; t.pad0 = t.pad1 = 0;
+        t.face = (int32_t)f; t.pad1 = 0;
+        t.esum = tr_tri_scale(t.ax, t.ay, t.az, t.bx, t.by, t.bz, t.cx, t.cy, t.cz);
         b->tris[k] = t;
         memcpy(&sbox[6 * k], &tribox[6 * f], 24);
     }
@@ -581,7 +582,8 @@ extern "C" void sim_tri_fast_vs_exact(const float* o, const float* d, const floa
         tr_ray_setup(r, o[3 * i], o[3 * i + 1], o[3 * i + 2], d[3 * i], d[3 * i + 1], d[3 * i + 2]);
         const float* t = tri + 9 * i;
         tr_hit h; h.t = 0.f;
-        code_fast[i] = tr_tri_fast(r, t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], h);
+        code_fast[i] = tr_tri_fast(r, t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8],
+                                   tr_tri_scale(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8]), h);
         t_fast[i] = h.t;
         tr_hit he; he.t = 0.f;
         hit_exact[i] = tr_tri_exact(r, t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], he) ? 1 : 0;

@@ -11,8 +11,9 @@ sys.path.insert(0, os.path.join(ROOT, "scripts"))
 
 def test_no_query_kernel_of_the_shipped_library_spills_inside_its_trips():
     """VERDICT r03 #7a, restated in round 6.  The traversal kernels ask for a wave per SIMD more than the compiler's own
-    budget gives them -- the streaming launches since round 5 (binary nodes: six waves, 80 registers; 8-wide nodes: five,
-    96), the direct launches since round 6, where the float64 part of the hit predicate is a real call at the end of a
+    budget gives them -- the streaming launch on the 8-wide nodes since round 5 (five waves, 96 registers; the one on the
+    binary nodes ran at six until the float64 call of round 6 made five faster: profiles/r06_ab_stream_waves.txt), the
+    direct launches since round 6, where the float64 part of the hit predicate is a real call at the end of a
     trip (tr_drain_exact: the callee owns 30 registers) and the stealing closest kernel would otherwise land at 83 --
     and pay with kernel-lifetime values in scratch: stored in the prologue, read once per refill / after the traversal
     loop.  What is pinned here, read off the shipped ISA: the budgets, a bound on the spilled registers, and NO scratch
@@ -28,8 +29,8 @@ def test_no_query_kernel_of_the_shipped_library_spills_inside_its_trips():
     stream = [k for k in ks if k["name"].startswith("void k_query_stream<")]
     wide = [k for k in ks if k["name"].startswith("void k_query_wide<")]
     direct = [k for k in ks if k not in stream and k not in wide and "_stats" not in k["name"] and "_wide" not in k["name"]]
-    # (<Q, COMPACT, BS, DEEP>: the instantiations with 64-bit addressing keep five waves)
-    assert stream and all(k["vgpr"] <= (80 if ", true, 128," in k["name"] else 96) and k["vgpr_spill"] <= 24 for k in stream), [(k["name"], k["vgpr"], k["vgpr_spill"]) for k in stream]
+    # (<Q, COMPACT, BS, DEEP>: five waves per SIMD since round 6 -- 96 registers; four for the instantiations with 64-bit addressing)
+    assert stream and all(k["vgpr"] <= (96 if ", true, 128," in k["name"] else 128) and k["vgpr_spill"] <= 4 for k in stream), [(k["name"], k["vgpr"], k["vgpr_spill"]) for k in stream]
     assert wide and all(k["vgpr"] <= 96 and k["vgpr_spill"] <= 16 for k in wide), [(k["name"], k["vgpr"], k["vgpr_spill"]) for k in wide]
     bad = [(k["name"], k["vgpr"], k["vgpr_spill"]) for k in direct if k["vgpr_spill"] > 8]
     assert not bad, bad

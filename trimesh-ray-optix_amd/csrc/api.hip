@@ -228,7 +228,7 @@ struct tr_blob_header {
     float aabb_min[3], aabb_max[3];
     uint32_t sizeof_node, sizeof_tri, sizeof_link, pad;
 };
-const char TR_MAGIC[8] = {'T', 'R', 'B', 'V', 'H', 0, 0, 3};   // 3: arena = nodes | links | tris | 32-byte grid nodes
+const char TR_MAGIC[8] = {'T', 'R', 'B', 'V', 'H', 0, 0, 4};   // 4: arena = nodes | links | tris (with the scale of contract 3's inside test) | 32-byte grid nodes
 }  // namespace
 
 int64_t tr_bvh_serialized_size(const tr_bvh* bvh) {
@@ -335,6 +335,13 @@ int tr_bvh_replica_hash(const tr_bvh* bvh, uint64_t* h_hash, void* stream) {
     tr_device_state* st;
     TR_TRY(tr_get_device_state(bvh->device, &st));
     hipStream_t s = (hipStream_t)stream;
+    {   // the hash is read back on the host: not something a stream that is being captured into a graph can do
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+            (void)hipGetLastError();
+            return tr_fail(TR_ERR_INVALID_ARG, "tr_bvh_replica_hash synchronises: not on a stream that is being captured");
+        }
+    }
     unsigned long long sum = 0;
     if (bvh->num_tris > 0) {
         unsigned long long* d_sum = nullptr;

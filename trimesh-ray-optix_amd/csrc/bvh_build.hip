@@ -260,7 +260,8 @@ __global__ __launch_bounds__(256) void k_gather(const float* __restrict__ verts,
     t.ax = a[0]; t.ay = a[1]; t.az = a[2];
     t.bx = b[0]; t.by = b[1]; t.bz = b[2];
     t.cx = c[0]; t.cy = c[1]; t.cz = c[2];
-    t.face = (int32_t)f; t.pad0 = 0; t.pad1 = 0;
+    t.face = (int32_t)f; t.pad1 = 0;
+    t.esum = tr_tri_scale(t.ax, t.ay, t.az, t.bx, t.by, t.bz, t.cx, t.cy, t.cz);
     tris[k] = t;
     float lo[3], hi[3];
     tr_tri_box(t.ax, t.ay, t.az, t.bx, t.by, t.bz, t.cx, t.cy, t.cz, lo, hi);
@@ -403,7 +404,8 @@ __global__ __launch_bounds__(256) void k_regather(const float* __restrict__ vert
     t.ax = a[0]; t.ay = a[1]; t.az = a[2];
     t.bx = b[0]; t.by = b[1]; t.bz = b[2];
     t.cx = c[0]; t.cy = c[1]; t.cz = c[2];
-    t.face = (int32_t)f; t.pad0 = 0; t.pad1 = 0;
+    t.face = (int32_t)f; t.pad1 = 0;
+    t.esum = tr_tri_scale(t.ax, t.ay, t.az, t.bx, t.by, t.bz, t.cx, t.cy, t.cz);
     tris[k] = t;
     float lo[3], hi[3];
     tr_tri_box(t.ax, t.ay, t.az, t.bx, t.by, t.bz, t.cx, t.cy, t.cz, lo, hi);

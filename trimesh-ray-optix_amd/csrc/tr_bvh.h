@@ -222,7 +222,8 @@ TR_HD void tr_qnode_set_box(uint32_t* q, const float* lo, const float* hi, const
 struct alignas(16) tr_tri {
     float ax, ay, az, bx, by, bz, cx, cy, cz;
     int32_t face;  // original triangle index
-    int32_t pad0, pad1;
+    float esum;    // tr_tri_scale: |b - a|_1 + |c - a|_1, the triangle's factor of the inside test's error bound (tr_tri_fast)
+    int32_t pad1;
 #if TR_TRI_BYTES == 64
     int32_t pad2[4];
 #endif
@@ -352,7 +353,8 @@ TR_HD tr_tri tr_load_tri(const tr_bvh_view& b, int32_t slot, tr_counters* cnt) {
     union { float f; int32_t i; } u;
     u.f = q2.y;
     t.face = u.i;
-    t.pad0 = t.pad1 = 0;
+    t.esum = q2.z;
+    t.pad1 = 0;
     if (STATS) cnt->tris++;
     return t;
 }
@@ -388,7 +390,7 @@ template <int Q, int K>
 TR_HD bool tr_fold_leaf(bool live, const tr_ray& r, const tr_tri& t, int32_t slot, tr_result& res, tr_topk<K>& top, int32_t& pe) {
     tr_hit h;
     h.t = 0.f;
-    const int c = tr_tri_fast(r, t.ax, t.ay, t.az, t.bx, t.by, t.bz, t.cx, t.cy, t.cz, h);
+    const int c = tr_tri_fast(r, t.ax, t.ay, t.az, t.bx, t.by, t.bz, t.cx, t.cy, t.cz, t.esum, h);
     if (live && c == TR_UNDECIDED) pe = slot;
     return tr_fold_hit<Q, K>(live && c == TR_HIT, h.t, t.face, slot, res, top);
 }

@@ -105,7 +105,11 @@ TR_HD bool tr_ray_setup(tr_ray& r, float ox, float oy, float oz, float dx, float
     r.ox = ox; r.oy = oy; r.oz = oz;
     r.dx = dx; r.dy = dy; r.dz = dz;
     r.ix = tr_inv(dx); r.iy = tr_inv(dy); r.iz = tr_inv(dz);
-    r.kd = ((fabsf(dx) + fabsf(dy)) + fabsf(dz)) * TR_BAND_K;
+    {
+        // (a direction longer than 2^40 leaves the float32 part of the inside test undecided: kd = inf, tr_tri_fast)
+        const float l1 = (fabsf(dx) + fabsf(dy)) + fabsf(dz);
+        r.kd = l1 <= TR_BAND_MAXLEN ? l1 * TR_BAND_K : INFINITY;
+    }
     {
         const bool nx = r.ix < 0.f, ny = r.iy < 0.f, nz = r.iz < 0.f;
         // v_perm_b32(hi_pair, lo_pair, sel): selector bytes 0-3 pick bytes of lo_pair, 4-7 of hi_pair
@@ -239,8 +243,9 @@ TR_HD float tr_tri_scale(float ax, float ay, float az, float bx, float by, float
     const float e2x = cx - ax, e2y = cy - ay, e2z = cz - az;
     return ((fabsf(e1x) + fabsf(e1y)) + fabsf(e1z)) + ((fabsf(e2x) + fabsf(e2y)) + fabsf(e2z));
 }
+// E = tr_tri_scale of the triangle (the kernels read it from the triangle's record, where the builder put it)
 TR_HD int tr_tri_fast(const tr_ray& r, float ax, float ay, float az, float bx, float by, float bz,
-                      float cx, float cy, float cz, tr_hit& h) {
+                      float cx, float cy, float cz, float E, tr_hit& h) {
     float e1x = bx - ax, e1y = by - ay, e1z = bz - az;
     float e2x = cx - ax, e2y = cy - ay, e2z = cz - az;
     // p = d x e2
@@ -252,18 +257,13 @@ TR_HD int tr_tri_fast(const tr_ray& r, float ax, float ay, float az, float bx, f
     float U = tr_dot(sx, sy, sz, px, py, pz);
     const uint32_t flip = tr_f2u(det) & 0x80000000u;
     const float Uf = tr_u2f(tr_f2u(U) ^ flip);
-    const float E = ((fabsf(e1x) + fabsf(e1y)) + fabsf(e1z)) + ((fabsf(e2x) + fabsf(e2y)) + fabsf(e2z));
     const float Ls = fmaxf(fmaxf(fabsf(sx), fabsf(sy)), fabsf(sz));
-#ifdef TR_KD_LOCAL      // (experiment: one register of ray constants less, three instructions per leaf test more)
-    const float kd = ((fabsf(r.dx) + fabsf(r.dy)) + fabsf(r.dz)) * TR_BAND_K;
-#else
-    const float kd = r.kd;
-#endif
-    const float kE = kd * E;
+    const float kE = r.kd * E;
     const float LsE = Ls + E;
     const float mm = fmaf(kE, LsE, TR_BAND_ABS);
     // the bounds hold while nothing overflows and what underflows stays below the 2^-100 of mm: lengths up to 2^40
-    if (!((LsE <= TR_BAND_MAXLEN) & (kd <= TR_BAND_K * TR_BAND_MAXLEN))) return TR_UNDECIDED;      // (NaN, too)
+    // (the direction's: kd = inf makes mm inf or NaN, and nothing below is decided)
+    if (!(LsE <= TR_BAND_MAXLEN)) return TR_UNDECIDED;      // (NaN, too)
     const float D1 = fabsf(det) - Uf;
     if ((Uf < -mm) | (D1 < -(mm + mm))) return TR_MISS;
     // q = s x e1
@@ -285,7 +285,7 @@ TR_HD int tr_tri_fast(const tr_ray& r, float ax, float ay, float az, float bx, f
 // parts apart (tr_fold_leaf / tr_drain_exact, tr_bvh.h)
 TR_HD bool tr_tri_test(const tr_ray& r, float ax, float ay, float az, float bx, float by, float bz,
                        float cx, float cy, float cz, tr_hit& h) {
-    const int c = tr_tri_fast(r, ax, ay, az, bx, by, bz, cx, cy, cz, h);
+    const int c = tr_tri_fast(r, ax, ay, az, bx, by, bz, cx, cy, cz, tr_tri_scale(ax, ay, az, bx, by, bz, cx, cy, cz), h);
     if (c != TR_UNDECIDED) return c == TR_HIT;
     return tr_tri_exact(r, ax, ay, az, bx, by, bz, cx, cy, cz, h);
 }
