@@ -40,11 +40,11 @@
  *   ray:   valid iff all six of o,d are finite (else the ray misses everything)
  *   MT:    e1=b-a, e2=c-a, p=cross(d,e2), det=dot(e1,p), s=o-a, U=dot(s,p), q=cross(s,e1), V=dot(d,q), T=dot(e2,q)
  *          cross(x,y).x = fma(x.y, y.z, -(x.z*y.y)) (cyclic);  dot(x,y) = fma(x.z, y.z, fma(x.y, y.y, x.x*y.x))
- *          (Uf,Vf) = (U,V) with the sign bit of det flipped in; D1 = |det| - Uf; Wf = D1 - Vf; m3 = min(min(Uf,Vf),Wf)
+ *          (Uf,Vf) = (U,V) with the sign bit of det flipped in; Wf = (|det| - Uf) - Vf; m3 = min(min(Uf,Vf),Wf)
  *   bound: E = (|e1x|+|e1y|+|e1z|) + (|e2x|+|e2y|+|e2z|), Ls = max|s_i|, kd = (|dx|+|dy|+|dz|) * 10*2^-24,
  *          mm = fma(kd*E, Ls+E, 2^-100)  -- exceeds the rounding error of Uf, Vf, Wf and det (proof: tr_math.h);
  *          Ls+E > 2^40 or |d|_1 > 2^40 (kd = inf) or NaN -> the float32 part does not answer (overflow)
- *   inside: Uf < -mm or D1 < -2mm or Vf < -mm or Wf < -mm -> outside (proven);  m3 > mm -> inside (proven), t = T/det in float32 provided
+ *   inside: m3 < -mm -> outside (proven);  m3 > mm -> inside (proven), t = T/det in float32 provided
  *          |det| >= (kd*E*E)*1024 and |T| >= (Ls*2^-10)*(E*E) (relative error of t < 2^-11);
  *          anything else (also NaN) -> the EXACT part: Woop / Benthin / Wald 2013 edge functions in float64 from the
  *          float32 inputs, projective form (woop64 below): inside iff U,V,W all >= 0 or all <= 0 and U+V+W != 0;
@@ -240,21 +240,19 @@ static inline int tri_hit(const ray_t *r, const float *a, const float *b, const 
     const float kE = r->kd * E;
     const float LsE = Ls + E;
     const float mm = fmaf(kE, LsE, TR_BAND_ABS);
-    const float D1 = fabsf(det) - Uf; /* = Vf + Wf */
 #ifdef ORACLE_STATS
     __atomic_fetch_add(&g_leaf_tests, 1, __ATOMIC_RELAXED);
 #endif
     /* lengths beyond 2^40 (overflow) and NaN: the float32 part does not answer */
     int exact = !(LsE <= TR_BAND_MAXLEN);
-    float V = 0.0f, Vf = 0.0f, Wf = 0.0f;
     if (!exact) {
-        if (Uf < -mm || D1 < -(mm + mm)) return 0; /* proven outside, known before V is */
         cross3(s, e1, q);
-        V = dot3(r->d, q);
-        Vf = neg ? -V : V;
-        Wf = D1 - Vf;
-        if (Vf < -mm || Wf < -mm) return 0;        /* proven outside */
-        exact = !(minf_(minf_(Uf, Vf), Wf) > mm); /* not proven inside */
+        const float V = dot3(r->d, q);
+        const float Vf = neg ? -V : V;
+        const float Wf = (fabsf(det) - Uf) - Vf;
+        const float m3 = minf_(minf_(Uf, Vf), Wf);
+        if (m3 < -mm) return 0;  /* proven outside */
+        exact = !(m3 > mm);      /* not proven inside */
     }
     float t = 0.0f;
     if (!exact) {

@@ -38,6 +38,8 @@ ap.add_argument("--flat", action="store_true", help="pass image-shaped rays as a
 ap.add_argument("--stats", action="store_true", help="also run the instrumented kernel (traversal counters)")
 ap.add_argument("--each", action="store_true", help="also print the time of every step")
 ap.add_argument("--rays", type=int, default=0, help="c3 / c5s: number of hash rays instead of the config's 10 M / 12.5 M")
+ap.add_argument("--far", type=float, default=1.0, help="pinhole configs: the camera this many times farther away with the field of view narrowed "
+                "by the same factor (the same image of the mesh from a far origin: ADVICE r05, the margins of the fused box test and of the inside test)")
 ap.add_argument("--presort", type=int, default=0, help="c3 / c5s: sort the rays by (origin cell with this many bits per axis, direction octant) BEFORE the timed region")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -80,7 +82,9 @@ elif a.config in ("room", "terrain", "soup"):
     n = w * h
 else:
     dist = 2.5 if a.config == "c4" else 2.5 * rad
-    on, dn = W.pinhole_grid(a.res, a.res, distance=dist)
+    import math
+    vf = 40.0 if a.far == 1.0 else 2.0 * math.degrees(math.atan(math.tan(math.radians(20.0)) / a.far))
+    on, dn = W.pinhole_grid(a.res, a.res, vfov_deg=vf, distance=dist * a.far)
     o, d = T(on), T(dn)
     if a.flat:
         o, d = o.reshape(-1, 3).contiguous(), d.reshape(-1, 3).contiguous()

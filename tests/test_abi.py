@@ -130,3 +130,21 @@ def test_every_option_is_documented():
     integ = open(os.path.join(root, "INTEGRATION.md")).read()
     assert [n for n in names if f'"{n}"' not in hdr] == []
     assert [n for n in names if f"`{n}`" not in integ] == []
+
+
+def test_native_step_library_exports_every_declared_symbol():
+    """include/triro_rccl.h <-> libtriro_rccl.so (no compute, no RCCL call: the symbols and the struct layout only)"""
+    import ctypes
+    import re
+    import triro.backend.ops as hops
+    path = hops.rccl_library_path()
+    assert os.path.exists(path), "build with __graft_entry__.build()"
+    lib = ctypes.CDLL(hops.library_path(), mode=ctypes.RTLD_GLOBAL) and ctypes.CDLL(path)
+    hdr = open(os.path.join(ROOT, "include", "triro_rccl.h")).read()
+    names = set(re.findall(r"\b(tr_[a-z_0-9]+)\s*\(", hdr))
+    assert {"tr_rccl_available", "tr_comm_unique_id", "tr_comm_create", "tr_comm_destroy", "tr_sharded_closest_step", "tr_rccl_last_error"} <= names
+    for n in names:
+        assert hasattr(lib, n), n
+    # tr_shard_step: 8 + 4*4 + 8 + 3*8 (pointers) + ... = the layout the binding assumes
+    assert ctypes.sizeof(hops.TrShardStep) == 8 + 16 + 8 + 8 * 13 + 8      # (the trailing int32 flags is padded to 8)
+    assert hops.TrShardStep.per_row.offset == 24 and hops.TrShardStep.bounds.offset == 32 and hops.TrShardStep.flags.offset == 136

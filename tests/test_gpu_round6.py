@@ -126,3 +126,17 @@ def test_rays_aimed_at_shared_edges_and_vertices_never_slip_through(device):
             assert np.all(ec[:300_000] % 2 == 0)
         wtri, wt, wcnt = R.watertight(eye, d)
         assert int(((wtri >= 0) != eh).sum()) <= 8 and int(((wtri >= 0) != eh)[:300_000].sum()) == 0
+
+
+@pytest.mark.timeout(600)
+def test_native_step_matches_the_python_pipeline_and_runs_on_rccl(device):
+    """VERDICT r05 "next" #3: tr_sharded_closest_step (include/triro_rccl.h) -- one C call per pipelined step -- gives
+    the bits of the plain call and of the Python pipeline on the destination's side of a pretended 4-rank world, and its
+    transfers run on real RCCL (one rank playing all four through ncclSend / ncclRecv): tests/native_step_world1.py."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "native_step_world1.py")], capture_output=True, text=True, env=env, timeout=540)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]

@@ -309,7 +309,16 @@ struct tr_result {
     int32_t best_slot;
     // count
     int32_t count;
+#ifdef TR_LIM_REG
+    float lim;           // best_t * TR_CULL_SLACK, kept beside best_t (a register for one multiply per trip: A/B builds)
+#endif
 };
+TR_HD void tr_set_best_t(tr_result& res, float t) {
+    res.best_t = t;
+#ifdef TR_LIM_REG
+    res.lim = t * TR_CULL_SLACK;
+#endif
+}
 
 // COMPACT addressing: byte offsets fit 32 bits (nodes*64 and tris*48 below 4 GiB), so the
 // loads use an SGPR base + 32-bit VGPR offset instead of 64-bit per-lane address arithmetic
@@ -333,13 +342,17 @@ TR_HD const tr_f4* tr_tri_ptr(const tr_bvh_view& b, int32_t slot) {
 }
 
 TR_HD void tr_result_init(tr_result& res) {
-    res.best_t = TR_TMAX; res.best_face = -1; res.best_slot = -1;
+    tr_set_best_t(res, TR_TMAX); res.best_face = -1; res.best_slot = -1;
     res.count = 0;
 }
 // the limit a box's entry distance is culled against (tr_math.h, TR_CULL_SLACK)
 template <int Q>
 TR_HD float tr_cull_limit(const tr_result& res) {
+#ifdef TR_LIM_REG
+    return (Q == TR_Q_FIRST || Q == TR_Q_CLOSEST) ? res.lim : TR_TLIM;
+#else
     return (Q == TR_Q_FIRST || Q == TR_Q_CLOSEST) ? res.best_t * TR_CULL_SLACK : TR_TLIM;
+#endif
 }
 
 template <bool STATS, bool COMPACT = false>
@@ -374,7 +387,7 @@ TR_HD bool tr_fold_hit(bool hit, float t, int32_t face, int32_t slot, tr_result&
         if (hit) { res.count++; top.insert(t, face, slot); }
     } else {
         if (hit && tr_closer(t, face, res.best_t, res.best_face < 0 ? 0x7fffffff : res.best_face)) {
-            res.best_t = t; res.best_face = face; res.best_slot = slot;
+            tr_set_best_t(res, t); res.best_face = face; res.best_slot = slot;
         }
     }
     return false;
@@ -391,7 +404,9 @@ TR_HD bool tr_fold_leaf(bool live, const tr_ray& r, const tr_tri& t, int32_t slo
     tr_hit h;
     h.t = 0.f;
     const int c = tr_tri_fast(r, t.ax, t.ay, t.az, t.bx, t.by, t.bz, t.cx, t.cy, t.cz, t.esum, h);
+#ifndef TR_NO_EXACT      // (-DTR_NO_EXACT: what the float64 part costs -- undecided tests count as misses: WRONG results, timing only)
     if (live && c == TR_UNDECIDED) pe = slot;
+#endif
     return tr_fold_hit<Q, K>(live && c == TR_HIT, h.t, t.face, slot, res, top);
 }
 // decide the parked test (see tr_fold_leaf); wave-uniform skip when no lane has one

@@ -219,17 +219,15 @@ TR_HD bool tr_tri_exact(const tr_ray& r, float ax, float ay, float az, float bx,
 // Rounding: every product term of U = s . (d x e2) passes at most 7 roundings (s, e2, the inner product, the fma of the
 // cross product, the outer product, two accumulating fma) and the terms' magnitudes sum to at most |s|_inf |d|_1 |e2|_1;
 // the same for V with e1; det's terms to |d|_1 |e1|_inf |e2|_1 <= |d|_1 E^2 / 4 with E = |e1|_1 + |e2|_1.  Hence, with
-// D1 = |det| - Uf and Wf = D1 - Vf,
+// Wf = (|det| - Uf) - Vf,
 //   |Uf - exact| + |Vf - exact| <= 7 u |s|_inf |d|_1 E,   |det - exact| <= 2 u |d|_1 E^2,
-//   |D1 - exact|, |Wf - exact| <= 8 u |s|_inf |d|_1 E + 2 u |d|_1 E^2   (the roundings of the two subtractions included),
-// and with mm = 10 u |d|_1 E (|s|_inf + E) + 2^-100  (> every bound above + det's, the quantities of mm itself rounded):
-//   Uf < -mm, Vf < -mm or Wf < -mm : that exact value is < 0, and since |det| cannot be wrong by more than mm another
-//                                    one is > 0                                              -> outside, proven;
-//   D1 < -2 mm                     : Vf + Wf < -mm exactly, so one of them is < 0, and Uf > 0  -> outside, proven
-//                                    (known before V is: half of the candidates leave after U);
-//   min3(Uf, Vf, Wf) > mm          : all three exact values are > 0 with the true sign of det -> inside, proven;
-//   otherwise                      : undecided -- the float64 edge functions decide (NaN / inf from overflowing
-//                                    coordinates land here, too).
+//   |Wf - exact| <= 8 u |s|_inf |d|_1 E + 2 u |d|_1 E^2   (the roundings of the two subtractions included),
+// and with mm = 10 u |d|_1 E (|s|_inf + E) + 2^-100  (> every bound above + det's, the quantities of mm itself rounded)
+// and m3 = min(Uf, Vf, Wf):
+//   m3 < -mm  : one exact value is < 0, and since |det| cannot be wrong by more than mm another one is > 0
+//                                                                                            -> outside, proven;
+//   m3 >  mm  : all three exact values are > 0 with the true sign of det                    -> inside, proven;
+//   otherwise : undecided -- the float64 edge functions decide (NaN from overflowing coordinates lands here, too).
 // The bounds assume that no product overflows and that what underflows (an absolute error of 2^-149 per product, times
 // one more factor) stays below the 2^-100 in mm: both hold while |s|_inf + E and |d|_1 are at most 2^40 (1.1e12) --
 // larger lengths are left UNDECIDED, tiny ones are undecided by themselves (|Uf| < 2^-100).  The distance of a proven hit: t = T / det in float32 when |T| and |det| exceed
@@ -264,17 +262,18 @@ TR_HD int tr_tri_fast(const tr_ray& r, float ax, float ay, float az, float bx, f
     // the bounds hold while nothing overflows and what underflows stays below the 2^-100 of mm: lengths up to 2^40
     // (the direction's: kd = inf makes mm inf or NaN, and nothing below is decided)
     if (!(LsE <= TR_BAND_MAXLEN)) return TR_UNDECIDED;      // (NaN, too)
-    const float D1 = fabsf(det) - Uf;
-    if ((Uf < -mm) | (D1 < -(mm + mm))) return TR_MISS;
     // q = s x e1
     float qx = fmaf(sy, e1z, -(sz * e1y));
     float qy = fmaf(sz, e1x, -(sx * e1z));
     float qz = fmaf(sx, e1y, -(sy * e1x));
     float V = tr_dot(r.dx, r.dy, r.dz, qx, qy, qz);
     const float Vf = tr_u2f(tr_f2u(V) ^ flip);
-    const float Wf = D1 - Vf;
-    if ((Vf < -mm) | (Wf < -mm)) return TR_MISS;
-    if (!(fminf(fminf(Uf, Vf), Wf) > mm)) return TR_UNDECIDED;
+    const float Wf = (fabsf(det) - Uf) - Vf;
+    // ONE decision from the smallest of the three (round 6 tried exits after U and after V: with five lanes of a wave in
+    // a leaf block some lane nearly always survives them, the branches cost more than they skipped)
+    const float m3 = fminf(fminf(Uf, Vf), Wf);
+    if (m3 < -mm) return TR_MISS;
+    if (!(m3 > mm)) return TR_UNDECIDED;
     const float T = tr_dot(e2x, e2y, e2z, qx, qy, qz);
     if (!(fabsf(det) >= (kE * E) * 1024.0f) | !(fabsf(T) >= (Ls * 9.765625e-4f) * (E * E))) return TR_UNDECIDED;
     const float t = T / det;

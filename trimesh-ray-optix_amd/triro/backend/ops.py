@@ -524,3 +524,59 @@ def trace_stats(accel_structure, origins, dirs, query: str = "closest") -> dict:
 
 def set_option(name: str, value: int):
     _check(get_module().tr_set_option(name.encode(), int(value)))
+
+
+# --- the native N-rank step (include/triro_rccl.h, csrc/gather_rccl.cpp) --------------------------------------------
+_RCCL_LIB_NAME = "libtriro_rccl.so"
+_rccl_module = None
+
+
+class TrShardStep(C.Structure):
+    """tr_shard_step of include/triro_rccl.h"""
+    _fields_ = [("n_total", C.c_int64), ("world", C.c_int32), ("rank", C.c_int32), ("dst", C.c_int32), ("chunks", C.c_int32),
+                ("per_row", C.c_int64), ("bounds", C.POINTER(C.c_int64)), ("my_rays", C.POINTER(TrRays)),
+                ("all_rays", C.POINTER(TrRays)), ("d_records", C.c_void_p), ("d_staging", C.c_void_p), ("d_hit", C.c_void_p),
+                ("d_front", C.c_void_p), ("d_tri", C.c_void_p), ("d_loc3", C.c_void_p), ("d_uv2", C.c_void_p),
+                ("stream", C.c_void_p), ("side_stream", C.c_void_p), ("done_event", C.c_void_p), ("flags", C.c_int32)]
+
+
+STEP_NO_EXCHANGE, STEP_LOOPBACK = 1, 2
+COMM_ID_BYTES = 128
+
+
+def rccl_library_path() -> str:
+    return os.environ.get("TRIRO_RCCL_LIBRARY") or os.path.join(os.path.dirname(library_path()), _RCCL_LIB_NAME)
+
+
+def get_rccl_module():
+    """libtriro_rccl.so (one C call per pipelined step of a ray-sharded closest-hit query).  Raises when it is not built;
+    whether RCCL itself can be found is a question for rccl_available()."""
+    global _rccl_module
+    if _rccl_module is None:
+        get_module()                       # libtriro_hip.so first: the step library links against it
+        path = rccl_library_path()
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} not found: build it (make -C trimesh-ray-optix_amd/csrc all, __graft_entry__.build())")
+        lib = C.CDLL(path)
+        lib.tr_rccl_last_error.restype = C.c_char_p
+        lib.tr_rccl_available.restype = _int
+        lib.tr_comm_unique_id.argtypes = [C.c_void_p]
+        lib.tr_comm_create.argtypes = [C.c_void_p, _int, _int, _int, C.POINTER(_vp)]
+        lib.tr_comm_destroy.argtypes = [_vp]
+        lib.tr_sharded_closest_step.argtypes = [_vp, _vp, C.POINTER(TrShardStep)]
+        for f in ("tr_comm_unique_id", "tr_comm_create", "tr_comm_destroy", "tr_sharded_closest_step"):
+            getattr(lib, f).restype = _int
+        _rccl_module = lib
+    return _rccl_module
+
+
+def rccl_available() -> bool:
+    try:
+        return get_rccl_module().tr_rccl_available() == 0
+    except Exception:
+        return False
+
+
+def _check_rccl(rc: int):
+    if rc != 0:
+        raise RuntimeError("libtriro_rccl: " + (get_rccl_module().tr_rccl_last_error() or b"?").decode())
