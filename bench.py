@@ -51,7 +51,11 @@ BYTES_PER_RAY_CLOSEST = 50      # 24 B in + 26 B out
 # the streaming boundary of large meshes moved to 2.75 M rays: rank 0's 2.4 M incoherent rays then take the direct launch, which does not
 # overlap with the expansion on the side stream -- a smaller shard (1.9 M rays) balances the step again: r05_emulate_final_tree.jsonl;
 # with the early stealing of unrelated rays that shard's trace takes 0.33 ms: rank 0 1.68 ms, a peer 1.78 -- 6.6x / 6.2x)
-AUTO_RHO = {("c5i", "slot"): 0.092, ("c5i", "packed"): 0.064, ("c5ii", "slot"): 0.125, ("c5ii", "packed"): 0.101}
+# (round 6: finishing a ray from its slot now computes its barycentrics in float64 -- the expansion of 7.9 M records 0.093 -> 0.100 ms --
+# and the trace changed with the contract: c5i / slot re-derived from profiles/r06_emulate_shares.txt -- share 0.39 / 0.30 / 0.22 / 0.15 ->
+# rank 0 0.231 / 0.222 / 0.213 / 0.230 ms against a peer's 0.202-0.205: 0.22, i.e. rho = 0.115; c5ii / slot unchanged: rank 0 1.79-1.82 ms
+# against a peer's 1.82-1.86 in six processes)
+AUTO_RHO = {("c5i", "slot"): 0.115, ("c5i", "packed"): 0.064, ("c5ii", "slot"): 0.125, ("c5ii", "packed"): 0.101}
 
 
 def resolve_share(args, world):
@@ -119,7 +123,7 @@ def parse(argv=None):
     ap.add_argument("--arrival", choices=["copy", "none"], default="copy",
                     help="--emulate-world: how the peers' records arrive: device copies on a copy stream (pessimistic: blit "
                          "kernels) or not at all (they are simply there: expansion cost only)")
-    ap.add_argument("--exchange", choices=["slot", "packed", "dense", "padded", "staged"], default=None,
+    ap.add_argument("--exchange", choices=["native", "slot", "packed", "dense", "padded", "staged"], default=None,
                     help="N > 1: the rung of the exchange ladder to start from (default: slot, or packed with --records packed); the "
                          "preflight steps down from there (triro.ray.sharded.LADDER)")
     ap.add_argument("--no-preflight", action="store_true", help="N > 1: skip the checked small batch in front of the run")
@@ -227,16 +231,18 @@ def cpu_baseline(v, f, o, d, budget_s=20.0):
 
 # ---- the parity error bar (static: measured by scripts/watertight_bound.py, kept under profiles/) ---------------
 def parity_error_bars():
-    """How far the contract's answers can be from a watertight reference (OptiX's built-in triangle test is closed and
-    nothing of the reference runs here: parity is UNPINNED at the bit level).  Per BASELINE config: the
-    fraction of rays whose hit mask / triangle index / hit count differ from a float64 Woop-Benthin-Wald test on the same
-    float32 inputs, and the largest relative distance difference on the same triangle (profiles/r0x_watertight_bound.jsonl;
-    the GPU outputs are the contract's bit for bit: tests/test_watertight.py)."""
+    """The contract against an independent watertight reference (OptiX's built-in triangle test is closed and nothing of the
+    reference runs here: parity is UNPINNED at the bit level).  Per BASELINE config at full size: the rays
+    whose hit mask / triangle index / hit count differ from the published form of the Woop-Benthin-Wald test evaluated in
+    float64 on the same (anchored) float32 rays, and the largest differences of what the API returns -- uv, loc -- and of
+    the distance on the same triangle (profiles/r06_watertight_bound.jsonl, scripts/watertight_bound.py --full; the GPU
+    outputs are the contract's bit for bit: tests/test_watertight.py, tests/test_gpu_configs.py)."""
     out = {"pinned_bit_exact_against_reference": False,
-           "note": "bit-exact against the CPU oracle (every BASELINE config, full size, incl. loc / uv); against a float64 "
-                   "watertight ray / triangle test the rates below; the reference's own arithmetic (OptiX) is closed and "
-                   "unbuildable here", "configs": {}}
-    for name in ("r05_watertight_bound.jsonl", "r04_watertight_bound.jsonl"):
+           "note": "bit-exact against the CPU oracle (every BASELINE config, full size, incl. loc / uv); the contract is watertight "
+                   "since round 6 (float32 Moller-Trumbore where a proven error bound lets it decide, float64 edge functions "
+                   "elsewhere, barycentrics from float64): against an independent float64 watertight test the differences below; "
+                   "the reference's own arithmetic (OptiX) is closed and unbuildable here", "configs": {}}
+    for name in ("r06_watertight_bound.jsonl", "r05_watertight_bound.jsonl"):
         p = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(p):
             continue
@@ -252,10 +258,12 @@ def parity_error_bars():
                     continue
                 out["configs"][key] = {
                     "rays": int(j.get("rays", 0)),
-                    "hit_mask_rate": round((j.get("only_contract", 0) + j.get("only_watertight", 0)) / n, 9),
-                    "tri_idx_rate": round((j.get("tri_diff_same_t", 0) + j.get("tri_diff_other", 0)) / n, 9),
-                    "count_rate": round(j.get("count_diff", 0) / n, 9),
-                    "max_rel_t_diff_same_tri": j.get("max_rel_t_diff_same_tri")}
+                    "hit_mask_differs": j.get("only_contract", 0) + j.get("only_watertight", 0),
+                    "tri_idx_differs": j.get("tri_diff_same_t", 0) + j.get("tri_diff_other", 0),
+                    "count_differs": j.get("count_diff", 0),
+                    "max_rel_t_diff_same_tri": j.get("max_rel_t_diff_same_tri"),
+                    "max_rel_uv_diff": j.get("max_rel_uv_diff"), "max_abs_uv_diff": j.get("max_abs_uv_diff"),
+                    "max_rel_loc_diff": j.get("max_rel_loc_diff"), "max_abs_loc_diff": j.get("max_abs_loc_diff")}
             out["source"] = "profiles/" + name
         except Exception as exc:      # noqa: BLE001
             out["error"] = str(exc)
@@ -495,7 +503,7 @@ def run_rank(args):
             self.packed_ok = gather_on and S._can_pack()       # the real tracer; stand-ins take the per-output exchange
             # 4-byte records: rank 0 (the caller of the reference's API: it hands in the whole batch) holds ALL rays and
             # finishes the peers' rays from (ray, slot); resident before the clock starts like every other input
-            self.slot_rec = self.packed_ok and S.exchange_mode == "slot"
+            self.slot_rec = self.packed_ok and S.exchange_mode in ("slot", "native")
             self.all_rays = w["all_rays"]() if (self.slot_rec and rank == 0) else None
 
         def step(self):
@@ -512,6 +520,11 @@ def run_rank(args):
                     return None
                 b = w["bshape"]
                 return [res_[0].view(b), res_[1].view(b), res_[2].view(b), res_[3].view(*b, 3), res_[4].view(*b, 2)]
+            if self.slot_rec and S.exchange_mode == "native":       # the same step as ONE C call (include/triro_rccl.h)
+                self.pending.append(S.closest_of_shard_native(w["origins"], w["dirs"], w["n_total"], batch_shape=w["bshape"], dst=0,
+                                                              chunks=self.chunks or None, bounds=w["bounds_all"],
+                                                              row_quantum=w["row_quantum"], all_rays=self.all_rays))
+                return self.pending.pop(0).wait() if len(self.pending) > 1 else None
             self.pending.append(S.closest_of_shard_async(w["origins"], w["dirs"], w["n_total"], batch_shape=w["bshape"], dst=0,
                                                          chunks=self.chunks or None, bounds=w["bounds_all"],
                                                          row_quantum=w["row_quantum"], records="slot" if self.slot_rec else "packed",

@@ -56,6 +56,7 @@ def lib():
     L.oracle_fetch_rays.argtypes = [fp, fp, i64p, i64p, i64p, C.c_int64, fp, fp]
     L.oracle_watertight.argtypes = [C.c_void_p, fp, fp, C.c_int64, C.c_int, ip, C.POINTER(C.c_double), ip,
                                     C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.oracle_anchor_rays.argtypes = [C.c_void_p, fp, fp, C.c_int64, fp]
     L.oracle_num_threads.restype = C.c_int
     _LIB = L
     return L
@@ -165,6 +166,15 @@ class OracleIntersector:
             lib().oracle_closest(*args)
             el += time.perf_counter() - t0
         return el
+
+    def anchor(self, origins, directions):
+        """the origins every query of the contract really traces: a ray that starts outside the mesh's box is moved along
+        itself to just before its entry point (contract 3, "ray anchoring": triro_oracle.c anchor_ray = csrc/tr_math.h
+        tr_ray_anchor); float32 [*b, 3].  For comparisons with references that take plain rays."""
+        b, o, d = self._rays(origins, directions)
+        out = np.empty_like(o)
+        lib().oracle_anchor_rays(self._h, _p(o, C.c_float), _p(d, C.c_float), len(o), _p(out, C.c_float))
+        return out.reshape(*b, 3)
 
     def watertight(self, origins, directions, with_bary=False):
         """(tri[*b] int32 (-1 miss), t[*b] float64, count[*b] int32) under the WATERTIGHT float64 test of

@@ -108,6 +108,9 @@ typedef struct {
     onode_t *nodes;
     int32_t nnodes;
     int32_t *prim; /* permutation of triangle ids */
+    /* the box rays are anchored to (contract: ray anchoring): the product's 16-bit grid frame over the padded bounds of
+     * the mesh -- base = the minimum, top = fma(65535, scale, base), scale a power of two (tr_qframe_make, tr_bvh.h) */
+    float alo[3], ahi[3];
 } omesh_t;
 
 static inline float minf_(float a, float b) { return a < b ? a : b; }
@@ -122,8 +125,36 @@ static inline void cross3(const float *x, const float *y, float *r) {
     r[2] = fmaf(x[0], y[1], -(x[1] * y[0]));
 }
 
-static void ray_setup(ray_t *r, const float *o, const float *d) {
+/* ray anchoring (contract 3; csrc/tr_math.h tr_ray_anchor): a ray that starts far outside the mesh's box is moved along
+ * itself to just in front of its entry point.  tn, tf = entry / exit of the slab test (reciprocals clamped to +-3e38, no
+ * padding), chord = tf - tn; anchored iff 0 < tn <= tf, tn < 1e7, tn > chord / 2; t0 = tn - max(chord / 16, tn * 2^-18);
+ * o' = o + t0 * d with a compensated product (fma) and sum (TwoSum): within an ulp of itself of the exact point. */
+static void anchor_ray(const omesh_t *m, const float *o, const float *d, float *oa) {
+    float tn = -INFINITY, tf = INFINITY;
+    for (int i = 0; i < 3; i++) {
+        float inv = 1.0f / d[i];
+        if (fabsf(inv) > TR_HUGE) inv = copysignf(TR_HUGE, d[i]);
+        const float t1 = (m->alo[i] - o[i]) * inv, t2 = (m->ahi[i] - o[i]) * inv;
+        /* (fmaxf / fminf as the product: a NaN operand is ignored) */
+        tn = fmaxf(tn, fminf(t1, t2));
+        tf = fminf(tf, fmaxf(t1, t2));
+    }
+    const float chord = tf - tn;
+    for (int i = 0; i < 3; i++) oa[i] = o[i];
+    if (!(tn > 0.0f && tn <= tf && tn < TR_TMAX && tn > 0.5f * chord)) return;
+    const float t0 = tn - fmaxf(chord * 0.0625f, tn * 3.814697265625e-06f);
+    for (int i = 0; i < 3; i++) {
+        const float p = t0 * d[i], e = fmaf(t0, d[i], -p);
+        const float s = p + o[i], bb = s - p;
+        const float err = (p - (s - bb)) + (o[i] - bb);
+        oa[i] = s + (e + err);
+    }
+}
+
+static void ray_setup(const omesh_t *m, ray_t *r, const float *o_in, const float *d) {
     int ok = 1;
+    float o[3];
+    anchor_ray(m, o_in, d, o);
     for (int i = 0; i < 3; i++) {
         r->o[i] = o[i];
         r->d[i] = d[i];
@@ -370,6 +401,29 @@ void *oracle_mesh_create(const float *verts, int64_t nv, const int32_t *faces, i
         for (int64_t f = 0; f < nf; f++) m->prim[f] = cents[f].id;
         free(cents);
     }
+    /* the grid frame over the padded bounds (tr_qframe_make restated): per axis scale = the power of two with
+     * fma(65535, scale, base) >= max, found from frexp(ext / 65535) and doubled while the last plane falls short */
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t f = 0; f < nf; f++) {
+        float lo[3], hi[3];
+        tri_box(m, (int32_t)f, lo, hi);
+        for (int i = 0; i < 3; i++) {
+            mn[i] = minf_(mn[i], lo[i]);
+            mx[i] = maxf_(mx[i], hi[i]);
+        }
+    }
+    for (int i = 0; i < 3; i++) {
+        float sc = 1.0f, base = nf > 0 ? mn[i] : 0.0f;
+        const float ext = nf > 0 ? mx[i] - mn[i] : 0.0f;
+        if (ext > 0.0f && ext <= 3.0e38f) {
+            int e = 0;
+            (void)frexpf(ext / 65535.0f, &e);
+            sc = ldexpf(1.0f, e < -126 ? -126 : e);
+        }
+        for (int it = 0; it < 300 && nf > 0 && !(fmaf(65535.0f, sc, base) >= mx[i]); it++) sc *= 2.0f;
+        m->alo[i] = base;
+        m->ahi[i] = fmaf(65535.0f, sc, base);
+    }
     return m;
 }
 
@@ -541,7 +595,7 @@ int oracle_closest(const void *mesh, const float *o, const float *d, int64_t n, 
     for (int64_t i = 0; i < n; i++) {
         ray_t r;
         best_t b;
-        ray_setup(&r, o + 3 * i, d + 3 * i);
+        ray_setup(m, &r, o + 3 * i, d + 3 * i);
         closest_ray(m, &r, mode, &b);
         float l3[3] = {0, 0, 0}, uv2[2] = {0, 0};
         uint8_t fr = 0;
@@ -567,7 +621,7 @@ int oracle_count(const void *mesh, const float *o, const float *d, int64_t n, in
         ray_t r;
         hitlist_t l;
         l.cap = 0;
-        ray_setup(&r, o + 3 * i, d + 3 * i);
+        ray_setup(m, &r, o + 3 * i, d + 3 * i);
         allhits_ray(m, &r, mode, &l);
         count[i] = (int32_t)l.total;
     }
@@ -587,7 +641,7 @@ int oracle_location_fill(const void *mesh, const float *o, const float *d, int64
         ray_t r;
         hitlist_t l;
         l.cap = cap;
-        ray_setup(&r, o + 3 * i, d + 3 * i);
+        ray_setup(m, &r, o + 3 * i, d + 3 * i);
         allhits_ray(m, &r, mode, &l);
         for (int32_t k = 0; k < l.n; k++) {
             int64_t g = offsets[i] + k;
@@ -755,6 +809,13 @@ int oracle_fetch_rays(const float *obase, const float *dbase, const int64_t shap
             d_out[3 * idx + k] = dbase[di + k * dstride[3]];
         }
     }
+    return 0;
+}
+
+/* the anchored origins of a batch (what every query above traces): for comparisons with references that take plain rays */
+int oracle_anchor_rays(const void *mesh, const float *o, const float *d, int64_t n, float *o_out) {
+    const omesh_t *m = (const omesh_t *)mesh;
+    for (int64_t i = 0; i < n; i++) anchor_ray(m, o + 3 * i, d + 3 * i, o_out + 3 * i);
     return 0;
 }
 

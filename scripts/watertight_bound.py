@@ -38,7 +38,9 @@ def compare(name, v, f, o, d):
     R = OracleIntersector(v, f, mode=1)
     hit, _, tri, loc, uv, t = R.closest_raw(o, d)
     cnt = R.intersects_count(o, d)
-    wtri, wt, wcnt, wuvw, wloc = R.watertight(o, d, with_bary=True)
+    # the reference sees the rays the contract traces: anchored where they enter the mesh's box (a float32 ray transform:
+    # OracleIntersector.anchor); distances of both are measured from there
+    wtri, wt, wcnt, wuvw, wloc = R.watertight(R.anchor(o, d), d, with_bary=True)
     hit, tri, t, cnt = hit.reshape(-1), tri.reshape(-1), t.reshape(-1).astype(np.float64), cnt.reshape(-1)
     loc, uv = loc.reshape(-1, 3).astype(np.float64), uv.reshape(-1, 2).astype(np.float64)
     wtri, wt, wcnt, wuvw, wloc = wtri.reshape(-1), wt.reshape(-1), wcnt.reshape(-1), wuvw.reshape(-1, 3), wloc.reshape(-1, 3)

@@ -264,7 +264,7 @@ static const tr_qnode* g_qnodes = nullptr;            // grid nodes + frame of t
 static tr_qframe g_frame = {{0, 0, 0}, {1, 1, 1}};    // (sim_set_qnodes; needed by the unordered schedule only)
 static tr_bvh_view view_of(const tr_node* nodes, const tr_link* links, const tr_tri* tris, int64_t nf) {
     tr_bvh_view v; v.nodes = nodes; v.links = links; v.tris = tris; v.num_tris = nf;
-    v.qnodes = g_qnodes; v.frame = g_frame;
+    v.qnodes = g_qnodes; v.frame = g_frame; v.frame_dev = nullptr;
     return v;
 }
 

@@ -124,7 +124,7 @@ def test_rays_aimed_at_shared_edges_and_vertices_never_slip_through(device):
         else:
             assert float(hit.float().mean()) > 0.99
             assert np.all(ec[:300_000] % 2 == 0)
-        wtri, wt, wcnt = R.watertight(eye, d)
+        wtri, wt, wcnt = R.watertight(R.anchor(eye, d), d)
         assert int(((wtri >= 0) != eh).sum()) <= 8 and int(((wtri >= 0) != eh)[:300_000].sum()) == 0
 
 
@@ -140,3 +140,37 @@ def test_native_step_matches_the_python_pipeline_and_runs_on_rccl(device):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, os.path.join(root, "tests", "native_step_world1.py")], capture_output=True, text=True, env=env, timeout=540)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+
+
+def test_graph_replay_follows_a_refit_that_moves_the_bounds(device):
+    """A launch captured in a HIP graph freezes its kernel arguments -- the grid frame of the mesh among them, which the
+    grid nodes' decode AND the rays' anchor depend on.  Since round 6 the kernels read the frame from device memory
+    (TR_VIEW_LIVE), which refit / update_raw keep current: a replay after a refit that GROWS the mesh gives the new
+    mesh's answers bit for bit -- stealing closest launch on the grid nodes, count, and the list query."""
+    v, f = W.icosphere(5)
+    v = W.displaced(v, seed=2, amplitude=0.05)
+    r = make(v, f, device)
+    o, d = W.pinhole_grid(256, 192, distance=3.5)
+    ot, dt = T(np.ascontiguousarray(o), device), T(d, device)
+    gs = torch.cuda.Stream(device)
+    gs.wait_stream(torch.cuda.current_stream(device))
+    with torch.cuda.stream(gs):
+        for _ in range(4):
+            r.intersects_closest(ot, dt)
+            r.intersects_count(ot, dt)
+    torch.cuda.current_stream(device).wait_stream(gs)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=gs):
+        out = r.intersects_closest(ot, dt)
+        cnt = r.intersects_count(ot, dt)
+    v2 = (W.displaced(v, seed=9, amplitude=0.08) * np.float32(1.35) + np.float32([0.2, -0.1, 0.15])).astype(np.float32)      # other bounds, other frame
+    for vv in (v, v2, v):
+        r.refit(T(vv, device))
+        graph.replay()
+        torch.cuda.synchronize()
+        R = OracleIntersector(vv, f, mode=1)
+        eh, ef, et, el, eu = R.intersects_closest(o, d)
+        assert np.array_equal(out[0].cpu().numpy(), eh) and np.array_equal(out[2].cpu().numpy(), et)
+        assert np.array_equal(out[3].cpu().numpy(), el) and np.array_equal(out[4].cpu().numpy(), eu)
+        assert np.array_equal(cnt.cpu().numpy(), R.intersects_count(o, d))

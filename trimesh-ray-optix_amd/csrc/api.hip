@@ -293,6 +293,7 @@ int tr_bvh_deserialize(const void* h_buffer, int64_t size, void* stream, tr_bvh*
             bvh->num_tris = h.num_tris; bvh->num_nodes = h.num_nodes; bvh->depth = h.depth; bvh->key_mode = h.key_mode;
             for (int k = 0; k < 3; k++) { bvh->aabb_min[k] = h.aabb_min[k]; bvh->aabb_max[k] = h.aabb_max[k]; }
             tr_qframe_make(bvh->aabb_min, bvh->aabb_max, &bvh->frame);   // the grid is a function of the bounds
+            s = tr_bvh_sync_frame(bvh);
         }
     }
     if (s != TR_OK) {
@@ -313,6 +314,7 @@ int tr_bvh_destroy(tr_bvh* bvh) {
         if (g.enter(bvh->device) == TR_OK) {
             if (bvh->arena && hipFree(bvh->arena) != hipSuccess) status = tr_fail(TR_ERR_HIP, "hipFree(arena)");
             if (bvh->refit_temp && hipFree(bvh->refit_temp) != hipSuccess) status = tr_fail(TR_ERR_HIP, "hipFree(refit_temp)");
+            if (bvh->frame_dev && hipFree(bvh->frame_dev) != hipSuccess) status = tr_fail(TR_ERR_HIP, "hipFree(frame_dev)");
             if (bvh->wnodes && hipFree(bvh->wnodes) != hipSuccess) status = tr_fail(TR_ERR_HIP, "hipFree(wnodes)");
             if (bvh->wflag && hipFree(bvh->wflag) != hipSuccess) status = tr_fail(TR_ERR_HIP, "hipFree(wflag)");
             if (bvh->widx && hipFree(bvh->widx) != hipSuccess) status = tr_fail(TR_ERR_HIP, "hipFree(widx)");

@@ -501,6 +501,12 @@ int tr_arena_alloc(tr_bvh* bvh, int64_t nf) {
 
 int64_t tr_arena_used_bytes(int64_t nf) { return (int64_t)carve_arena(nullptr, nullptr, nf); }
 
+int tr_bvh_sync_frame(tr_bvh* bvh) {
+    if (!bvh->frame_dev) TR_HIP_TRY(hipMalloc((void**)&bvh->frame_dev, sizeof(tr_qframe)));
+    TR_HIP_TRY(hipMemcpy(bvh->frame_dev, &bvh->frame, sizeof(tr_qframe), hipMemcpyHostToDevice));
+    return TR_OK;
+}
+
 void tr_bvh_reset(tr_bvh* bvh) {
     bvh->wide_valid = false; bvh->wide_unavailable = false;
     bvh->frame = tr_qframe{{0.f, 0.f, 0.f}, {1.f, 1.f, 1.f}};
@@ -703,6 +709,7 @@ int tr_build_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_
             memcpy(&bvh->aabb_max[k], &b1, 4);
         }
         tr_qframe_make(bvh->aabb_min, bvh->aabb_max, &bvh->frame);   // == k_qframe's (same function, same bounds)
+        if (tr_bvh_sync_frame(bvh) != TR_OK && status == TR_OK) status = TR_ERR_HIP;
     }
     int rs = tr_build_temp_release(st);   // the stream is drained: the next build may reuse the buffer
     if (rs != TR_OK && status == TR_OK) status = rs;
@@ -766,13 +773,17 @@ int tr_refit_impl(tr_bvh* bvh, const float* d_vertices, int64_t nv, const int32_
         if (status == TR_OK) {
             for (int k = 0; k < 3; k++) { bvh->aabb_min[k] = rootbox[k]; bvh->aabb_max[k] = rootbox[3 + k]; }
             tr_qframe_make(bvh->aabb_min, bvh->aabb_max, &bvh->frame);
+            if (tr_bvh_sync_frame(bvh) != TR_OK) status = TR_ERR_HIP;
         }
     } else {
         float box[6];
         check(hipMemcpyAsync(box, sbox, sizeof(box), hipMemcpyDeviceToHost, stream), "memcpy box");
         check(hipStreamSynchronize(stream), "sync refit");
-        if (status == TR_OK)
+        if (status == TR_OK) {
             for (int k = 0; k < 3; k++) { bvh->aabb_min[k] = box[k]; bvh->aabb_max[k] = box[3 + k]; }
+            tr_qframe_make(bvh->aabb_min, bvh->aabb_max, &bvh->frame);      // (the box rays are anchored to: also for one triangle)
+            if (tr_bvh_sync_frame(bvh) != TR_OK) status = TR_ERR_HIP;
+        }
     }
     if (status == TR_OK && hbad != 0xffffffffu)
         status = tr_fail(TR_ERR_INVALID_ARG, "face " + std::to_string(hbad) + " has a vertex index outside [0, " +

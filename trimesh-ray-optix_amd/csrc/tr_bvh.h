@@ -148,8 +148,19 @@ TR_HD void tr_ray_fuse(tr_ray& r, const tr_qframe& f) {
     tr_fuse_axis(r.oz, r.iz, f.base[2], f.scale[2], r.kz, r.ez, r.qaz, r.qnz, r.qfz);
     r.qaz2 = r.qaz;
 }
+// the box a ray is anchored to (tr_ray_anchor, tr_math.h): the grid frame of the mesh, base ... plane 65535
+TR_HD void tr_ray_anchor_q(const tr_qframe& f, float& ox, float& oy, float& oz, float dx, float dy, float dz) {
+    const float hi[3] = {fmaf(65535.0f, f.scale[0], f.base[0]), fmaf(65535.0f, f.scale[1], f.base[1]), fmaf(65535.0f, f.scale[2], f.base[2])};
+    tr_ray_anchor(f.base, hi, ox, oy, oz, dx, dy, dz);
+}
+// ray set-up of the kernels that walk the exact nodes: anchor, then the constants of tr_math.h
+TR_HD bool tr_ray_setup_a(tr_ray& r, const tr_qframe& f, float ox, float oy, float oz, float dx, float dy, float dz) {
+    tr_ray_anchor_q(f, ox, oy, oz, dx, dy, dz);
+    return tr_ray_setup(r, ox, oy, oz, dx, dy, dz);
+}
 // ray set-up for the kernels that walk grid nodes / 8-wide nodes
 TR_HD bool tr_ray_setup_q(tr_ray& r, const tr_qframe& f, float ox, float oy, float oz, float dx, float dy, float dz) {
+    tr_ray_anchor_q(f, ox, oy, oz, dx, dy, dz);
     const bool valid = tr_ray_setup(r, ox, oy, oz, dx, dy, dz);
     tr_ray_fuse(r, f);
     return valid;
@@ -237,7 +248,15 @@ struct tr_bvh_view {
     int64_t num_tris;
     const tr_qnode* qnodes;   // 32-byte grid nodes of the unordered schedule (same topology as `nodes`)
     tr_qframe frame;
+    const tr_qframe* frame_dev;   // device copy of `frame`, kept current by build / refit / load (NULL: host simulation)
 };
+// first statement of every kernel that takes a view: the frame as it is NOW (a graph replay after a refit: the arguments
+// of the captured launch still hold the old one, and both the grid nodes' decode and the rays' anchor depend on it)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TR_VIEW_LIVE(b) do { if ((b).frame_dev) (b).frame = *(b).frame_dev; } while (0)
+#else
+#define TR_VIEW_LIVE(b) ((void)0)
+#endif
 enum tr_query { TR_Q_ANY = 0, TR_Q_FIRST = 1, TR_Q_CLOSEST = 2, TR_Q_COUNT = 3, TR_Q_LOCATION = 4 };
 
 struct tr_counters {

@@ -74,6 +74,8 @@ struct tr_bvh {
     tr_tri* tris = nullptr;
     tr_qnode* qnodes = nullptr;   // 32-byte grid nodes of the unordered schedule (same arena)
     tr_qframe frame = {{0, 0, 0}, {1, 1, 1}};   // their grid: a function of the bounds below
+    tr_qframe* frame_dev = nullptr;             // ... and its copy in device memory, which the kernels READ (tr_view_live): a launch
+                                                // captured in a HIP graph must see the frame of a later refit, not the one its arguments froze
     float aabb_min[3] = {0, 0, 0};
     float aabb_max[3] = {0, 0, 0};
     void* refit_temp = nullptr;   // boxes + flags of tr_bvh_refit, kept between calls (animation loops)
@@ -97,6 +99,9 @@ struct tr_bvh {
     tr_launch_info last_launch = {};     // tr_bvh_last_launch (written under sched_mutex)
     bool have_last_launch = false;
 };
+
+// bvh->frame -> bvh->frame_dev (a small synchronous copy; build / refit / load have just synchronised anyway)
+int tr_bvh_sync_frame(tr_bvh* bvh);
 
 // per-device runtime state (tr_init) ------------------------------------------------------
 struct tr_device_state {

@@ -100,6 +100,46 @@ TR_HD float tr_inv(float d) {
 
 TR_HD bool tr_finite(float x) { return fabsf(x) <= 3.4028234663852886e38f; }  // false for NaN
 
+// ---- ray anchoring (contract 3, round 6) ---------------------------------------------------------------------------
+// A ray that starts FAR outside the mesh's bounding box is MOVED ALONG ITSELF to just in front of the point where it
+// enters the box, and everything downstream -- box tests, the inside test, the float64 part, the barycentrics -- sees the
+// ray (o', d).  Why: the rounding error of the float32 inside test (tr_tri_fast) grows with |o - vertex|; from a camera
+// 100 mesh sizes away a tenth of all leaf tests, from 1 000 sizes all of them, had to be decided in float64 (the same
+// image 1.2x / 2x slower: profiles/r06_far_camera.txt).  From the anchor that distance is about the box's size,
+// wherever the camera stands.
+//   tn, tf = entry / exit distance of the slab test on the box [lo, hi] (clamped reciprocals, no padding); chord = tf - tn;
+//   anchored iff  0 < tn <= tf,  tn < 1e7  and  tn > chord / 2  (an origin closer than half a chord gains nothing);
+//   t0 = tn - max(chord / 16, tn * 2^-18)          (in front of the entry by more than the slab test can be wrong);
+//   o' = o + t0 * d  per component with a COMPENSATED product and sum (the product's rounding error from an fma, the
+//   sum's from TwoSum, both added back): o' is within an ulp OF ITSELF of the exact point of the ray, however large o
+//   is -- the displaced ray is the float32 noise of any ray transform, the same point for every triangle (watertightness
+//   is untouched), and more accurate than round 5's arithmetic from the far origin was.
+// Distances are measured from the anchor: the interval [0, 1e7] of the reference (shaders.cu:86) starts there (nothing
+// lies in front of the box).  A pure function of (ray, box): the oracle restates it, every rank of a sharded run computes
+// the same anchor.
+TR_HD void tr_ray_anchor(const float* lo, const float* hi, float& ox, float& oy, float& oz, float dx, float dy, float dz) {
+    const float ix = tr_inv(dx), iy = tr_inv(dy), iz = tr_inv(dz);
+    const float x1 = (lo[0] - ox) * ix, x2 = (hi[0] - ox) * ix;
+    const float y1 = (lo[1] - oy) * iy, y2 = (hi[1] - oy) * iy;
+    const float z1 = (lo[2] - oz) * iz, z2 = (hi[2] - oz) * iz;
+    const float tn = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fminf(z1, z2));
+    const float tf = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fmaxf(z1, z2));
+    const float chord = tf - tn;
+    if (!(tn > 0.0f && tn <= tf && tn < TR_TMAX && tn > 0.5f * chord)) return;      // (NaN: not anchored)
+    const float t0 = tn - fmaxf(chord * 0.0625f, tn * 3.814697265625e-06f);
+#define TR_ANCHOR_AXIS(o, d)                                         \
+    {                                                                \
+        const float p = t0 * (d), e = fmaf(t0, (d), -p);             \
+        const float s = p + (o), bb = s - p;                         \
+        const float err = (p - (s - bb)) + ((o) - bb);               \
+        (o) = s + (e + err);                                         \
+    }
+    TR_ANCHOR_AXIS(ox, dx)
+    TR_ANCHOR_AXIS(oy, dy)
+    TR_ANCHOR_AXIS(oz, dz)
+#undef TR_ANCHOR_AXIS
+}
+
 // returns false when the ray has a non-finite component (such rays miss everything)
 TR_HD bool tr_ray_setup(tr_ray& r, float ox, float oy, float oz, float dx, float dy, float dz) {
     r.ox = ox; r.oy = oy; r.oz = oz;

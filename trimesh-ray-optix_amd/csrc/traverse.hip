@@ -1,17 +1,25 @@
-// traverse.hip -- query kernels and their C-ABI launchers (replace the five OptiX pipelines
-// of triro/backend/shaders.cu:67-246 and the launch wrappers of ray.cpp:161-378).
+// traverse.hip -- the query kernels and their C-ABI launchers: ONE translation unit assembled from the .inc files below
+// (replaces the five OptiX pipelines of triro/backend/shaders.cu:67-246 and the launch wrappers of ray.cpp:161-378).
 //
-// One ray per lane, wave64; the per-ray state machine is tr_fused_step (tr_bvh.h): stackless
-// trail + LDS far-child ring, one node visit and one queued leaf test per trip.  Launch shapes:
-//   direct     : grid = ceil(n/BS) workgroups of BS = 64/128/256 rays (default, k_query_direct).
-//                Which ray block a workgroup takes is a scheduling choice: the measured
-//                per-XCD cost order of the previous launch (k_sched_sort), else the
-//                XCD-chunked, scrambled static map.
-//   persistent : grid = CUs x blocks_per_cu; each wave pulls 64-ray batches from a global
-//                work counter (option, not faster at the measured sizes).  The per-lane refill
-//                variant of round 1 ("active-ray repacking": 0.8 vs 3.6 Grays/s) was removed in
-//                round 2 after the randomised sweep found a mismatch in it.
-// Kernel parameters travel by value (no per-call malloc/memcpy/free as in ray.cpp:279-287).
+//   kernels_common.inc   RayFetch / QueryOut (the per-call ABI of the kernels, LaunchParams.h:11-47), the strided ray
+//                        fetch (shaders.cu:27-63), write_result (shaders.cu:120-172)
+//   kernels_direct.inc   the DIRECT launch: one workgroup of 128 rays (two waves), one ray per lane; plain, with
+//                        intra-wave work stealing, the unordered two-phase schedule (count / location) with and without
+//                        stealing; the block -> ray map (XCD chunks, 8x8 tiles, learned order, split slots);
+//                        k_query_direct, k_query_direct_sort (carries the deferred sort of the measured block costs),
+//                        k_query_count_steal[_sort], k_query_direct_wide, k_sched_sort / k_sched_rescale
+//   traverse_wide.inc    the walk over the 8-wide compressed nodes (tr_wide.h): k_query_wide (persistent waves, refill)
+//   kernels_stream.inc   the STREAMING launch for incoherent batches: persistent waves, ranges from a work counter,
+//                        __ballot / mbcnt refill of idle lanes; k_probe_coherence picks between the shapes on the device
+//   kernels_lists.inc    multi-hit lists (k_location, k_fill_list), scans, stream compaction
+//   kernels_expand.inc   12-byte / 4-byte closest-hit records -> the five dense outputs (the sharded gather's far end)
+//   launch_policy.inc    which launch a batch gets: every threshold in one table (tr_policy) with the profile that set it
+//   abi.inc              the extern "C" entry points of include/triro_hip.h
+//
+// The per-lane state machine (stackless trail + LDS far-child ring, one node visit and one queued leaf test per trip, the
+// deferred float64 leaf decision) is tr_bvh.h; the arithmetic contract is tr_math.h.  Kernel parameters travel by value
+// (no per-call malloc / memcpy / free as in ray.cpp:279-287); the mesh's grid frame is re-read from device memory
+// (TR_VIEW_LIVE) so that a launch captured in a HIP graph follows a later refit.
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>

@@ -178,7 +178,9 @@ def default_chunks(rays_per_rank: int) -> int:
 
 
 # the exchange ladder of a gathered closest-hit query, most economical first (ShardedRayMeshIntersector.set_exchange_mode)
-LADDER = ("slot", "packed", "dense", "padded", "staged")
+# ("native": the "slot" exchange driven by ONE C call per step -- tr_sharded_closest_step, include/triro_rccl.h -- with its own
+# RCCL communicator; opt-in (TRIRO_NATIVE_STEP=1 or set_exchange_mode("native")): it has run on one GPU only)
+LADDER = ("native", "slot", "packed", "dense", "padded", "staged")
 
 
 class PendingClosest:
@@ -260,7 +262,8 @@ class ShardedRayMeshIntersector:
         self._base_stage = (self._stage, self._stage_cpu_too)
         self.preflight_log: List[dict] = []
         self._mode = None
-        self.set_exchange_mode({"packed": "slot", "dense": "dense", "padded": "padded"}[self.gather_mode])
+        self.set_exchange_mode({"packed": "native" if os.environ.get("TRIRO_NATIVE_STEP") == "1" else "slot", "dense": "dense",
+                                "padded": "padded"}[self.gather_mode])
 
     # ---- the exchange ladder ---------------------------------------------------------------------
     @property
@@ -271,6 +274,8 @@ class ShardedRayMeshIntersector:
         # (the handshake first, whatever this rank can do itself: it is a collective -- ADVICE r05: a rank without packed
         # records or with TRIRO_SLOT_RECORDS=0 short-circuited past it and left its peers waiting in the all-gather)
         slot_records = self.slot_records
+        if m == "native" and not (self._can_pack() and slot_records and self.native_available()):
+            m = "slot"
         if m == "slot" and not (self._can_pack() and slot_records):
             m = "packed"
         if m == "packed" and not self._can_pack():
@@ -284,8 +289,8 @@ class ShardedRayMeshIntersector:
         if mode == "staged" and self.ctrl_group is None and not self._base_stage[0]:
             raise ValueError("exchange mode 'staged' needs a gloo control group (ctrl_group)")
         self._mode = mode
-        self.gather_mode = {"slot": "packed", "packed": "packed", "dense": "dense", "padded": "padded", "staged": "dense"}[mode]
-        self._slot_records_on = mode == "slot" and os.environ.get("TRIRO_SLOT_RECORDS", "1") != "0"
+        self.gather_mode = {"native": "packed", "slot": "packed", "packed": "packed", "dense": "dense", "padded": "padded", "staged": "dense"}[mode]
+        self._slot_records_on = mode in ("native", "slot") and os.environ.get("TRIRO_SLOT_RECORDS", "1") != "0"
         if mode == "staged" and not self._base_stage[0]:
             self._stage, self._stage_cpu_too = True, False
         else:
@@ -1010,6 +1015,9 @@ class ShardedRayMeshIntersector:
         b, n, lo, hi, o, d = self._my_rays(origins, directions, bounds)
         rows = q if q > 1 and all(a % q == 0 and z % q == 0 for a, z in bounds) else None
         # the whole batch is visible on every rank: the destination holds the rays, 4-byte records will do
+        if self.exchange_mode == "native" and dst is not None:
+            return self.closest_of_shard_native(o, d, n, batch_shape=b, dst=dst, chunks=chunks, bounds=bounds, row_quantum=rows,
+                                                all_rays=(origins, directions.expand(*origins.shape)))
         if self.slot_records:
             return self.closest_of_shard_async(o, d, n, batch_shape=b, dst=dst, chunks=chunks, bounds=bounds, row_quantum=rows,
                                                records="slot", all_rays=(origins, directions.expand(*origins.shape)))
