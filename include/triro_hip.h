@@ -125,6 +125,19 @@ int tr_bvh_get_info(const tr_bvh *bvh, tr_bvh_info *info);
  *    coherence probe handed to the streaming launch still reports the direct shape it enqueued).
  *    TR_ERR_INVALID_ARG before the first such query.                                          */
 int tr_bvh_last_launch(const tr_bvh *bvh, tr_launch_info *info);
+
+/* What the launch policy knows about the device, and the ray-count boundaries it derives from it (ABI 10; no counterpart in
+ * the reference).  The boundaries between the launch shapes are multiples of the device's RESIDENT LANES -- CUs x resident
+ * waves per CU of the stealing closest launch (from the occupancy calculator) x 64 --: 32/3 rounds for stealing / tiles,
+ * 64/3 for the 8-wide nodes, 128/3 for streaming counts.  MI355X, SPX: 256 CUs, 8 XCDs, 24 waves -> 393 216 lanes ->
+ * 4 194 304 / 8 388 608 / 16 777 216 rays, the values they were measured at. */
+typedef struct tr_topology {
+    int32_t num_cus, num_xcd, waves_per_cu, reserved;
+    int64_t l2_bytes;               /* hipDeviceProp_t::l2CacheSize as reported (0: unknown) */
+    int64_t resident_lanes;
+    int64_t steal_max_rays, wide_min_rays, count_stream_min_rays;
+} tr_topology;
+int tr_device_topology(int device, tr_topology *out);
 /*    test hook: copy the traversal arrays to HOST buffers (any may be NULL).
  *    nodes: num_nodes*16 words (64 B), links: num_nodes*2 int32, tris: num_tris*12 words. */
 int tr_bvh_download(const tr_bvh *bvh, void *h_nodes, void *h_links, void *h_tris,

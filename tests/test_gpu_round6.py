@@ -174,3 +174,18 @@ def test_graph_replay_follows_a_refit_that_moves_the_bounds(device):
         assert np.array_equal(out[0].cpu().numpy(), eh) and np.array_equal(out[2].cpu().numpy(), et)
         assert np.array_equal(out[3].cpu().numpy(), el) and np.array_equal(out[4].cpu().numpy(), eu)
         assert np.array_equal(cnt.cpu().numpy(), R.intersects_count(o, d))
+
+
+def test_launch_policy_boundaries_come_from_the_device(device):
+    """VERDICT r05 "next" #6: XCD count, L2 size and resident waves per CU are read from the device (attribute query,
+    occupancy calculator), and the ray-count boundaries between the launch shapes are multiples of the device's resident
+    lanes.  On an MI355X in SPX mode they are the values every profile of rounds 2-5 was taken with."""
+    import triro.backend.ops as hops
+    t = hops.device_topology(0)
+    assert t["num_cus"] > 0 and t["num_xcd"] in (1, 2, 4, 8) and t["waves_per_cu"] >= 8
+    assert t["resident_lanes"] == t["num_cus"] * t["waves_per_cu"] * 64
+    assert t["steal_max_rays"] == t["resident_lanes"] * 32 // 3 and t["wide_min_rays"] == t["resident_lanes"] * 64 // 3
+    assert t["count_stream_min_rays"] == t["resident_lanes"] * 128 // 3
+    if t["num_cus"] == 256:          # the whole chip
+        assert t["num_xcd"] == 8 and t["waves_per_cu"] == 24
+        assert (t["steal_max_rays"], t["wide_min_rays"], t["count_stream_min_rays"]) == (1 << 22, 1 << 23, 1 << 24)

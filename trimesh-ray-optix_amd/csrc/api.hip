@@ -110,6 +110,12 @@ int tr_get_device_state(int device, tr_device_state** out) {
         TR_HIP_TRY(hipGetDeviceProperties(&prop, device));
         st.device = device;
         st.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        {
+            int nx = 0;
+            if (hipDeviceGetAttribute(&nx, hipDeviceAttributeNumberOfXccs, device) != hipSuccess || nx < 1) { (void)hipGetLastError(); nx = 8; }
+            st.num_xcd = nx;
+            st.l2_bytes = prop.l2CacheSize > 0 ? (int64_t)prop.l2CacheSize : 0;
+        }
         TR_HIP_TRY(hipMalloc((void**)&st.counters, sizeof(unsigned long long) * TR_NUM_COUNTERS));
         TR_HIP_TRY(hipMemset(st.counters, 0, sizeof(unsigned long long) * TR_NUM_COUNTERS));
         TR_HIP_TRY(hipStreamCreateWithFlags(&st.build_side, hipStreamNonBlocking));

@@ -108,6 +108,10 @@ struct tr_device_state {
     bool ready = false;
     int device = 0;
     int num_cus = 0;
+    // topology, read from the device (round 6; until then 8 XCDs and 24 resident waves per CU were constants of the MI355X in SPX mode)
+    int num_xcd = 8;                // hipDeviceAttributeNumberOfXccs (8 when the query fails)
+    int64_t l2_bytes = 0;           // hipDeviceProp_t::l2CacheSize as reported (0 = unknown)
+    int waves_per_cu = 0;           // resident waves of the stealing closest launch on one CU, from the occupancy query (tr_policy_units, launch_policy.inc); 0 = not asked yet
     int* counters = nullptr;        // ring of scratch words (coherence probe, work counter of the streaming launch) for handles without a free scheduling slot
     unsigned next_counter = 0;
     // builder temporaries (sort buffers, boxes, hierarchy), kept between builds so that a

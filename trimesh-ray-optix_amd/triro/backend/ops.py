@@ -41,6 +41,13 @@ class TrRays(C.Structure):
                 ("shape", C.c_int64 * 4), ("ostride", C.c_int64 * 4), ("dstride", C.c_int64 * 4)]
 
 
+class TrTopology(C.Structure):
+    """tr_topology (include/triro_hip.h)"""
+    _fields_ = [("num_cus", C.c_int32), ("num_xcd", C.c_int32), ("waves_per_cu", C.c_int32), ("reserved", C.c_int32),
+                ("l2_bytes", C.c_int64), ("resident_lanes", C.c_int64), ("steal_max_rays", C.c_int64),
+                ("wide_min_rays", C.c_int64), ("count_stream_min_rays", C.c_int64)]
+
+
 class TrBvhInfo(C.Structure):
     _fields_ = [("device", C.c_int32), ("num_tris", C.c_int64), ("num_nodes", C.c_int64),
                 ("depth", C.c_int32), ("key_mode", C.c_int32), ("arena_bytes", C.c_int64),
@@ -83,6 +90,7 @@ ABI = {
     "tr_bvh_deserialize": (_int, [_vp, _i64, _vp, C.POINTER(_vp)]),
     "tr_bvh_get_info": (_int, [_vp, C.POINTER(TrBvhInfo)]),
     "tr_bvh_last_launch": (_int, [_vp, C.POINTER(TrLaunchInfo)]),
+    "tr_device_topology": (_int, [_int, C.POINTER(TrTopology)]),
     "tr_bvh_replica_hash": (_int, [_vp, C.POINTER(C.c_uint64), _vp]),
     "tr_bvh_download": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "tr_bvh_download_qnodes": (_int, [_vp, _vp, _vp, _vp]),
@@ -520,6 +528,13 @@ def trace_stats(accel_structure, origins, dirs, query: str = "closest") -> dict:
         _check(get_module().tr_trace_stats_query(_handle(accel_structure, origins), C.byref(make_rays(origins, dirs)),
                                            QUERY_IDS[query], C.byref(st), _stream_ptr(origins.device)))
     return dict(rays=st.rays, node_visits=st.node_visits, tri_tests=st.tri_tests, climb_steps=st.climb_steps)
+
+
+def device_topology(device: int = 0) -> dict:
+    """tr_device_topology: what the launch policy reads from the device and the ray-count boundaries it derives"""
+    t = TrTopology()
+    _check(get_module().tr_device_topology(int(device), C.byref(t)))
+    return {k: int(getattr(t, k)) for k, _ in TrTopology._fields_ if k != "reserved"}
 
 
 def set_option(name: str, value: int):
