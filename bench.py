@@ -833,7 +833,7 @@ def run_rank(args):
                                  "kernel_avg_ms = the mean interval of kernel_samples HIP event pairs spread over the timed region "
                                  "(kernel_event_interval_ms) minus what a pair reports with NOTHING between its records "
                                  "(empty_event_pair_ms, the median of 200 measured in this run): the rocprofv3 dispatch time of "
-                                 "the same command is in profiles/r05m_summary.md; compulsory_frac counts the 50 B/ray only; the path is "
+                                 "the same command is in profiles/r06a_summary.md; compulsory_frac counts the 50 B/ray only; the path is "
                                  "cache-latency / instruction-issue bound, not HBM-bandwidth bound (DESIGN.md 5); "
                                  "frac_on_exact_node_bytes = the same time against round 1's numerator (64-byte nodes), "
                                  "for comparison across rounds only"},
@@ -1188,9 +1188,16 @@ def run_emulation(args):
     def trace_ctx():
         return torch.cuda.stream(hp) if hp is not None else contextlib.nullcontext()
 
+    native = args.exchange == "native" and args.records == "slot" and args.arrival == "none" and all_rays is not None
+
     def step():
-        pending.append(E.closest_of_shard_async(o0, d0, n_total, batch_shape=bshape, dst=0, chunks=args.chunks or None,
-                                                bounds=bounds, row_quantum=row_quantum, records=args.records, all_rays=all_rays))
+        if native:          # rank 0's step as ONE C call (include/triro_rccl.h); the peers' records are already there
+            pending.append(E.closest_of_shard_native(o0, d0, n_total, batch_shape=bshape, dst=0, chunks=args.chunks or None,
+                                                     bounds=bounds, row_quantum=row_quantum, all_rays=all_rays,
+                                                     flags=hops.STEP_NO_EXCHANGE, records=E.peer_records, world=N, rank=0))
+        else:
+            pending.append(E.closest_of_shard_async(o0, d0, n_total, batch_shape=bshape, dst=0, chunks=args.chunks or None,
+                                                    bounds=bounds, row_quantum=row_quantum, records=args.records, all_rays=all_rays))
         return pending.pop(0).wait() if len(pending) > 1 else None
 
     def drain():
@@ -1283,7 +1290,7 @@ def run_emulation(args):
                                f"({args.rays if args.workload == 'c5i' else 'hash'} rays), headline mesh {len(f)} tris",
                    "rays_total": n_total, "rays_rank0": bounds[0][1] - bounds[0][0], "rays_peer": bounds[1][1] - bounds[1][0],
                    "dst_share": share, "chunks": args.chunks or "auto", "arrival_priority": bool(args.arrival_priority),
-                   "arrival": args.arrival, "trace_priority": bool(args.trace_priority), "opts": list(args.opt), "record_form": "slot only, 4 B" if slot_rec else ("slot, u, v: 12 B" if slots else "face, u, v: 12 B")},
+                   "arrival": args.arrival, "step_driver": "native (tr_sharded_closest_step)" if native else "python", "trace_priority": bool(args.trace_priority), "opts": list(args.opt), "record_form": "slot only, 4 B" if slot_rec else ("slot, u, v: 12 B" if slots else "face, u, v: 12 B")},
         "emulation": {"plain_1gpu_ms_per_step": round(plain_ms, 4), "plain_1gpu_rays": plain_n,
                       "rank0_ms_per_step": round(rank0_ms, 4), "rank0_own_trace_only_ms": round(own_ms, 4),
                       "peer_trace_ms_per_step": round(peer_ms, 4), "expansion_alone_ms": round(expand_ms, 4),

@@ -34,6 +34,11 @@ def test_no_query_kernel_of_the_shipped_library_spills_inside_its_trips():
     assert wide and all(k["vgpr"] <= 96 and k["vgpr_spill"] <= 16 for k in wide), [(k["name"], k["vgpr"], k["vgpr_spill"]) for k in wide]
     bad = [(k["name"], k["vgpr"], k["vgpr_spill"]) for k in direct if k["vgpr_spill"] > 8]
     assert not bad, bad
+    # <Q, STATS, COMPACT, MODE, DEEP, QN>: the instantiations for hierarchies of more than 32 levels keep the compiler's own
+    # register budget -- forced to spill they die with a memory access fault (profiles/r06_deep_spill_fault.txt)
+    import re
+    deep = [k for k in direct if re.search(r"k_query_direct<\d, \w+, \w+, \d, true, \w+>", k["name"]) or re.search(r"k_query_count_steal(_sort)?<(\w+, )?true>", k["name"])]
+    assert len(deep) >= 10 and all(k["vgpr_spill"] == 0 for k in deep), [(k["name"], k["vgpr_spill"]) for k in deep]
     for want, kw in (("k_query_stream<", {}), ("k_query_direct<", {}), ("k_query_direct_sort<", {}), ("k_query_count_steal", {}),
                      # (the 8-bit planes' decode marks the trips of the 8-wide walk; a visit -- the root's -- also sits in the
                      # refill path: the SMALLEST loop around a decode is the trip loop)
