@@ -493,6 +493,12 @@ def run_rank(args):
         S.set_exchange_mode(args.exchange)
     elif S is not None and args.records == "packed" and S.exchange_mode == "slot":
         S.set_exchange_mode("packed")
+    elif (S is not None and world > 1 and not stub and not args.no_preflight and os.environ.get("TRIRO_NATIVE_STEP", "1") != "0"
+          and S.native_available()):
+        # Round 6: start on the top rung -- the whole step as ONE C call (60 us of host time against 150-390 for the
+        # Python driver, which is host-bound on a 0.2-ms step: profiles/r06_emulate.jsonl).  Only behind the preflight:
+        # it checks the rung's bits, and its watchdog aborts the rung's own communicator when nobody answers.
+        S.set_exchange_mode("native")
 
     class Runner:
         """one workload through the exchange mode S is in: step() / drain() as the timed loop calls them"""
@@ -617,7 +623,7 @@ def run_rank(args):
     # ---- preflight (VERDICT r04 "next" #1): the exchange this run is about to time, on a small batch, checked -------
     # One small batch of the same family (same sharding rule, same record form, two steps in flight) through the
     # exchange mode in force; rank 0 compares what it gathered with its own trace of the whole small batch.  A mismatch
-    # or an exception on any rank moves every rank one rung down the ladder slot -> packed -> dense -> padded -> staged
+    # or an exception on any rank moves every rank one rung down the ladder native -> slot -> packed -> dense -> padded -> staged
     # (triro.ray.sharded.preflight: the verdict is all-reduced on the gloo control group), and the run is timed in the
     # mode that passed: a first contact with N real GPUs that misbehaves costs bandwidth, not the bench line.
     exchange = None

@@ -43,11 +43,16 @@ int tr_comm_unique_id(uint8_t id[TR_COMM_ID_BYTES]);
 /* every rank: ncclCommInitRank on `device` (collective over the `world` ranks that hold the same id) */
 int tr_comm_create(const uint8_t id[TR_COMM_ID_BYTES], int world, int rank, int device, tr_comm **out);
 int tr_comm_destroy(tr_comm *comm);
+/* From any thread: ncclCommAbort -- ends a transfer that nobody answers (the kernels leave their streams) and frees the
+ * communicator; later steps on the handle fail, tr_comm_destroy still takes it.  What a preflight's watchdog calls. */
+int tr_comm_abort(tr_comm *comm);
 
 enum {
     TR_STEP_NO_EXCHANGE = 1, /* the peers' records are already in d_records (bench.py --emulate-world): no send / recv   */
-    TR_STEP_LOOPBACK = 2     /* test hook for ONE rank: this rank plays every rank in turn -- the peers' chunks are traced
+    TR_STEP_LOOPBACK = 2,    /* test hook for ONE rank: this rank plays every rank in turn -- the peers' chunks are traced
                                 into a staging buffer and travel through ncclSend / ncclRecv to itself (one group)      */
+    TR_STEP_TEST_DROP_SEND = 4 /* with LOOPBACK: the sends are left out, the receives wait for a peer that never answers --
+                                the situation tr_comm_abort exists for (tests/native_step_world1.py)                     */
 };
 
 typedef struct tr_shard_step {
@@ -67,7 +72,7 @@ typedef struct tr_shard_step {
     float *d_loc3;
     float *d_uv2;
     void *stream;          /* hipStream_t the caller's work is on                                                        */
-    void *side_stream;     /* destination: hipStream_t of the receives and of the peers' rows                            */
+    void *side_stream;     /* destination: hipStream_t of the receives and of the peers' rows; a peer: of its sends (NULL: `stream`) */
     void *done_event;      /* destination: hipEvent_t recorded on side_stream when every row is final                    */
     int32_t flags;
 } tr_shard_step;

@@ -64,9 +64,11 @@ def loops(ins):
     return out
 
 
-def scratch_in_trip_loops(so, want, marker="v_perm_b32", smallest_only=False):
+def scratch_in_trip_loops(so, want, marker="v_perm_b32", smallest_only=False, near_call=0):
     """scratch instructions inside the innermost loops that hold a `marker` instruction (the grid nodes' box test = the
-    traversal trips), per kernel whose demangled name contains `want`: {name: [instruction text]}"""
+    traversal trips), per kernel whose demangled name contains `want`: {name: [instruction text]}.
+    near_call = N: scratch instructions within N instructions of a call (s_swappc_b64) do not count -- round 6: the
+    registers the float64 part of the predicate clobbers are saved around that (rare, cold) call."""
     res = {}
     for name, lines in disassemble(so, want):
         ins = instructions(lines)
@@ -80,7 +82,9 @@ def scratch_in_trip_loops(so, want, marker="v_perm_b32", smallest_only=False):
                 spans.add(min(inner, key=lambda sp: sp[1] - sp[0]))
         if smallest_only and spans:       # (a marker may also sit outside the trips, e.g. the root visit of a refill)
             spans = {min(spans, key=lambda sp: sp[1] - sp[0])}
-        res[name] = [ins[i][1] for (a, z) in spans for i in range(a, z + 1) if ins[i][1].startswith("scratch_")]
+        calls = [i for i, (_, t) in enumerate(ins) if t.startswith("s_swappc_b64")]
+        res[name] = [ins[i][1] for (a, z) in spans for i in range(a, z + 1) if ins[i][1].startswith("scratch_")
+                     and not (near_call and any(abs(i - c) <= near_call for c in calls))]
     return res
 
 

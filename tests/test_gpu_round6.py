@@ -142,6 +142,21 @@ def test_native_step_matches_the_python_pipeline_and_runs_on_rccl(device):
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
 
 
+@pytest.mark.timeout(300)
+def test_native_step_that_nobody_answers_is_given_up_not_waited_for(device):
+    """The native rung's safety net (sharded.py: _native_watchdog / _native_drop, tr_comm_abort): a step whose sends are
+    left out (LOOPBACK | TEST_DROP_SEND) either fails on the host (RCCL refuses the unmatched receive) or is ended by
+    ncclCommAbort from the watchdog's thread; afterwards the rung is gone (exchange_mode != "native"), the process and the
+    GPU are fine and the tracer still gives its bits.  tests/native_abort_world1.py (a child process, under a timeout)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "native_abort_world1.py")], capture_output=True, text=True, env=env, timeout=240)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+
+
 def test_graph_replay_follows_a_refit_that_moves_the_bounds(device):
     """A launch captured in a HIP graph freezes its kernel arguments -- the grid frame of the mesh among them, which the
     grid nodes' decode AND the rays' anchor depend on.  Since round 6 the kernels read the frame from device memory

@@ -39,10 +39,13 @@ def test_no_query_kernel_of_the_shipped_library_spills_inside_its_trips():
     import re
     deep = [k for k in direct if re.search(r"k_query_direct<\d, \w+, \w+, \d, true, \w+>", k["name"]) or re.search(r"k_query_count_steal(_sort)?<(\w+, )?true>", k["name"])]
     assert len(deep) >= 10 and all(k["vgpr_spill"] == 0 for k in deep), [(k["name"], k["vgpr_spill"]) for k in deep]
-    for want, kw in (("k_query_stream<", {}), ("k_query_direct<", {}), ("k_query_direct_sort<", {}), ("k_query_count_steal", {}),
+    # (round 6, tr_drain_exact<COLD>: what the float64 call clobbers is saved AROUND the call, on the 0.6 % of leaf tests
+    # that reach it -- those stores / loads sit within a few dozen instructions of the s_swappc and are not "in the trips")
+    for want, kw in (("k_query_stream<", dict(near_call=64)), ("k_query_direct<", dict(near_call=64)), ("k_query_direct_sort<", dict(near_call=64)),
+                     ("k_query_count_steal", dict(near_call=64)),
                      # (the 8-bit planes' decode marks the trips of the 8-wide walk; a visit -- the root's -- also sits in the
                      # refill path: the SMALLEST loop around a decode is the trip loop)
-                     ("k_query_wide<", dict(marker="v_cvt_f32_ubyte", smallest_only=True))):
+                     ("k_query_wide<", dict(marker="v_cvt_f32_ubyte", smallest_only=True, near_call=64))):
         inside = isa_loops.scratch_in_trip_loops(so, want, **kw)
         assert inside and not any(inside.values()), {k: v for k, v in inside.items() if v}
     # the stealing closest launch of the headline: six waves per SIMD (80 registers)

@@ -32,6 +32,7 @@ struct Rccl {
     int (*GetUniqueId)(ncclUniqueId*) = nullptr;
     int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*CommAbort)(ncclComm_t) = nullptr;
     int (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     int (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
@@ -55,6 +56,7 @@ Rccl& rccl() {
         r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
         r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
         r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+        r.CommAbort = (decltype(r.CommAbort))sym("ncclCommAbort");
         r.Send = (decltype(r.Send))sym("ncclSend");
         r.Recv = (decltype(r.Recv))sym("ncclRecv");
         r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
@@ -151,6 +153,17 @@ int tr_comm_destroy(tr_comm* c) {
     return rc == ncclSuccess ? TR_OK : nccl_fail("ncclCommDestroy", rc);
 }
 
+int tr_comm_abort(tr_comm* c) {
+    // From ANY thread: ends the communicator's kernels (a receive nobody answers spins on its stream for good) and
+    // frees it.  The handle stays valid for tr_comm_destroy; steps on it fail from here on.
+    if (!c) return TR_OK;
+    ncclComm_t h = c->comm;
+    c->comm = nullptr;
+    if (!h || !rccl().ok) return TR_OK;
+    const int rc = rccl().CommAbort(h);
+    return rc == ncclSuccess ? TR_OK : nccl_fail("ncclCommAbort", rc);
+}
+
 int tr_sharded_closest_step(const tr_bvh* bvh, tr_comm* comm, const tr_shard_step* s) {
     if (!bvh || !s || !s->bounds || !s->my_rays) return fail(TR_ERR_INVALID_ARG, "null argument");
     const bool no_x = (s->flags & TR_STEP_NO_EXCHANGE) != 0, loop = (s->flags & TR_STEP_LOOPBACK) != 0;
@@ -158,6 +171,7 @@ int tr_sharded_closest_step(const tr_bvh* bvh, tr_comm* comm, const tr_shard_ste
     if (world < 1 || rank < 0 || rank >= world || dst < 0 || dst >= world || s->chunks < 1) return fail(TR_ERR_INVALID_ARG, "rank / world / dst / chunks out of range");
     const bool exchange = world > 1 && !no_x;
     if (exchange && (!comm || !rccl().ok)) return fail(TR_ERR_INVALID_ARG, comm ? rccl().why : "comm == NULL");
+    if (exchange && !comm->comm) return fail(TR_ERR_INVALID_ARG, "the communicator was aborted");
     if (exchange && !loop && (comm->world != world || comm->rank != rank)) return fail(TR_ERR_INVALID_ARG, "step.world / rank differ from the communicator's");
     if (loop && (rank != dst || !s->d_staging)) return fail(TR_ERR_INVALID_ARG, "LOOPBACK: rank must be dst and d_staging set");
     const int64_t q = s->per_row > 1 ? s->per_row : 1;
@@ -233,7 +247,8 @@ int tr_sharded_closest_step(const tr_bvh* bvh, tr_comm* comm, const tr_shard_ste
                     const tr_rays theirs = slice_rays(*s->all_rays, ndim, ca[r] / q, cz[r] / q);
                     note(tr_intersects_closest_slots(bvh, &theirs, s->d_staging, xs), "trace (loopback)");
                     NCCL_TRY("ncclGroupStart", rccl().GroupStart());
-                    NCCL_TRY("ncclSend", rccl().Send(s->d_staging, (size_t)(cz[r] - ca[r]), ncclInt32, 0, comm->comm, xs));
+                    if (!(s->flags & TR_STEP_TEST_DROP_SEND))
+                        NCCL_TRY("ncclSend", rccl().Send(s->d_staging, (size_t)(cz[r] - ca[r]), ncclInt32, 0, comm->comm, xs));
                     NCCL_TRY("ncclRecv", rccl().Recv(s->d_records + ca[r], (size_t)(cz[r] - ca[r]), ncclInt32, 0, comm->comm, xs));
                     NCCL_TRY("ncclGroupEnd", rccl().GroupEnd());
                 }
@@ -259,7 +274,19 @@ int tr_sharded_closest_step(const tr_bvh* bvh, tr_comm* comm, const tr_shard_ste
             const tr_rays mine = slice_rays(*s->my_rays, ndim, a / q, z / q);
             if (note(tr_intersects_closest_slots(bvh, &mine, s->d_records + a, cur), "trace") != TR_OK)
                 (void)hipMemsetAsync(s->d_records + a, 0xff, (size_t)(z - a) * 4, cur);      // records that say "miss"
-            if (exchange) NCCL_TRY("ncclSend", rccl().Send(s->d_records + a, (size_t)(z - a), ncclInt32, dst, comm->comm, cur));
+            if (exchange) {
+                // with a side stream the send leaves the caller's stream free for the next chunk's / step's trace (the
+                // caller keeps d_records alive and untouched until the side stream has passed the send)
+                hipStream_t ss = cur;
+                if (side) {
+                    hipEvent_t ek = comm->event();
+                    if (!ek) return fail(TR_ERR_HIP, "hipEventCreate");
+                    HIP_TRY(hipEventRecord(ek, cur));
+                    HIP_TRY(hipStreamWaitEvent(side, ek, 0));
+                    ss = side;
+                }
+                NCCL_TRY("ncclSend", rccl().Send(s->d_records + a, (size_t)(z - a), ncclInt32, dst, comm->comm, ss));
+            }
         }
     }
     if (want) HIP_TRY(hipEventRecord((hipEvent_t)s->done_event, xs));

@@ -428,11 +428,18 @@ TR_HD bool tr_fold_leaf(bool live, const tr_ray& r, const tr_tri& t, int32_t slo
 #endif
     return tr_fold_hit<Q, K>(live && c == TR_HIT, h.t, t.face, slot, res, top);
 }
-// decide the parked test (see tr_fold_leaf); wave-uniform skip when no lane has one
-template <int Q, int K, bool COMPACT = false>
+// decide the parked test (see tr_fold_leaf); wave-uniform skip when no lane has one.
+// COLD: the branch is marked as unlikely -- the register allocator then saves the registers the float64 call clobbers
+// AROUND THE CALL (four scratch stores and loads on 0.6 % of the leaf tests) instead of keeping six kernel-lifetime
+// values in scratch for the whole kernel (a store per lane in the prologue, a load after the loop: 48 MB of L2 <->
+// fabric traffic per launch of the headline, L2 misses +30 %).  Headline 0.1838 -> 0.1800 ms, every direct config
+// -1...-4 %; the streaming closest kernel on the binary nodes gets 10 spills and +6 % from the same hint and keeps
+// the plain branch (profiles/r06_ab_cold_drain.txt).
+template <int Q, int K, bool COMPACT = false, bool COLD = true>
 TR_HD bool tr_drain_exact(const tr_bvh_view& b, const tr_ray& r, int32_t& pe, tr_result& res, tr_topk<K>& top) {
     bool fin = false;
-    if (TR_WAVE_ANY(pe >= 0)) {
+    const bool any_parked = TR_WAVE_ANY(pe >= 0);
+    if (COLD ? __builtin_expect(any_parked, 0) : any_parked) {
         if (pe >= 0) {
             tr_counters* nc = nullptr;
             const tr_tri t = tr_load_tri<false, COMPACT>(b, pe, nc);
@@ -800,7 +807,7 @@ TR_HD void tr_rec_links(const tr_rec_q&, int32_t& parent, int32_t& sibling) { pa
 // everything of a trip after the node record has arrived (n0..n3: in vector registers, or -- on
 // trips where the whole wave visits the same node -- in scalar registers)
 // TEST = false: a trip WITHOUT the leaf block (tr_fused_step)
-template <int Q, int K, bool STATS, bool COMPACT, typename W, bool TEST, typename REC>
+template <int Q, int K, bool STATS, bool COMPACT, typename W, bool TEST, bool COLD, typename REC>
 TR_HD void tr_fused_body(const tr_bvh_view& b, const tr_ray& r, tr_state_t<W>& st, tr_result& res,
                          tr_topk<K>& top, tr_counters* cnt, const tr_ring ring, const bool has_node,
                          const REC& rec) {
@@ -899,7 +906,7 @@ TR_HD void tr_fused_body(const tr_bvh_view& b, const tr_ray& r, tr_state_t<W>& s
     }
     // the test this trip's leaf block left undecided, now that the trip's record and triangle are dead (tr_fold_leaf)
     if (TEST) {
-        if (tr_drain_exact<Q, K, COMPACT>(b, r, st.pe, res, top) && Q == TR_Q_ANY) { st.node = -1; st.p0 = -1; st.p1 = -1; st.p2 = -1; }
+        if (tr_drain_exact<Q, K, COMPACT, COLD>(b, r, st.pe, res, top) && Q == TR_Q_ANY) { st.node = -1; st.p0 = -1; st.p1 = -1; st.p2 = -1; }
         st.pe = -1;     // (it is: said once more so that the compiler does not carry it around the loop)
     }
 }
@@ -918,7 +925,7 @@ TR_HD void tr_fused_body(const tr_bvh_view& b, const tr_ray& r, tr_state_t<W>& s
 // ones still fit).  A leaf is tested at most one trip later than before; same tests, same results.
 // QN: walk the 32-byte grid nodes instead of the exact 64-byte ones (see tr_rec_q).
 template <int Q, int K, bool STATS, bool COMPACT = false, typename W = uint64_t, bool UNI = false, bool TEST = true,
-          bool QN = false>
+          bool QN = false, bool COLD = true>
 TR_HD void tr_fused_step(const tr_bvh_view& b, const tr_ray& r, tr_state_t<W>& st, tr_result& res,
                          tr_topk<K>& top, tr_counters* cnt, const tr_ring ring) {
     // one leaf test per trip: the head of the lane's FIFO (p0, p1, p2).  The node is visited
@@ -941,12 +948,12 @@ TR_HD void tr_fused_step(const tr_bvh_view& b, const tr_ray& r, tr_state_t<W>& s
                     typedef const __attribute__((address_space(4))) tr_i4* tr_ci4p;
                     const tr_ci4p sp = (tr_ci4p)(unsigned long long)tr_qnode_ptr<COMPACT>(b, nu);
                     const tr_rec_q rec = {sp[0], sp[1]};
-                    tr_fused_body<Q, K, STATS, COMPACT, W, TEST>(b, r, st, res, top, cnt, ring, has_node, rec);
+                    tr_fused_body<Q, K, STATS, COMPACT, W, TEST, COLD>(b, r, st, res, top, cnt, ring, has_node, rec);
                 } else {
                     typedef const __attribute__((address_space(4))) tr_f4* tr_cf4p;
                     const tr_cf4p sp = (tr_cf4p)(unsigned long long)tr_node_ptr<COMPACT>(b, nu);
                     const tr_rec_f rec = {sp[0], sp[1], sp[2], sp[3]};
-                    tr_fused_body<Q, K, STATS, COMPACT, W, TEST>(b, r, st, res, top, cnt, ring, has_node, rec);
+                    tr_fused_body<Q, K, STATS, COMPACT, W, TEST, COLD>(b, r, st, res, top, cnt, ring, has_node, rec);
                 }
                 return;
             }
@@ -959,11 +966,11 @@ TR_HD void tr_fused_step(const tr_bvh_view& b, const tr_ray& r, tr_state_t<W>& s
     if constexpr (QN) {
         const tr_i4* np = tr_qnode_ptr<COMPACT>(b, nidx);
         const tr_rec_q rec = {np[0], np[1]};
-        tr_fused_body<Q, K, STATS, COMPACT, W, TEST>(b, r, st, res, top, cnt, ring, has_node, rec);
+        tr_fused_body<Q, K, STATS, COMPACT, W, TEST, COLD>(b, r, st, res, top, cnt, ring, has_node, rec);
     } else {
         const tr_f4* np = tr_node_ptr<COMPACT>(b, nidx);
         const tr_rec_f rec = {np[0], np[1], np[2], np[3]};
-        tr_fused_body<Q, K, STATS, COMPACT, W, TEST>(b, r, st, res, top, cnt, ring, has_node, rec);
+        tr_fused_body<Q, K, STATS, COMPACT, W, TEST, COLD>(b, r, st, res, top, cnt, ring, has_node, rec);
     }
 }
 

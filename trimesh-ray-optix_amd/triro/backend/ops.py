@@ -555,7 +555,7 @@ class TrShardStep(C.Structure):
                 ("stream", C.c_void_p), ("side_stream", C.c_void_p), ("done_event", C.c_void_p), ("flags", C.c_int32)]
 
 
-STEP_NO_EXCHANGE, STEP_LOOPBACK = 1, 2
+STEP_NO_EXCHANGE, STEP_LOOPBACK, STEP_TEST_DROP_SEND = 1, 2, 4
 COMM_ID_BYTES = 128
 
 
@@ -578,8 +578,9 @@ def get_rccl_module():
         lib.tr_comm_unique_id.argtypes = [C.c_void_p]
         lib.tr_comm_create.argtypes = [C.c_void_p, _int, _int, _int, C.POINTER(_vp)]
         lib.tr_comm_destroy.argtypes = [_vp]
+        lib.tr_comm_abort.argtypes = [_vp]
         lib.tr_sharded_closest_step.argtypes = [_vp, _vp, C.POINTER(TrShardStep)]
-        for f in ("tr_comm_unique_id", "tr_comm_create", "tr_comm_destroy", "tr_sharded_closest_step"):
+        for f in ("tr_comm_unique_id", "tr_comm_create", "tr_comm_destroy", "tr_comm_abort", "tr_sharded_closest_step"):
             getattr(lib, f).restype = _int
         _rccl_module = lib
     return _rccl_module

@@ -357,9 +357,15 @@ class ShardedRayMeshIntersector:
                 if ok:
                     self._fp_ok, self._rec_ok, self._fp_key = False, False, self._handshake_key()
                 continue
-            if eff != mode:
-                attempts.append({"mode": mode, "ok": False, "reason": f"not available here (would run as '{eff}')"})
+            # (availability is a local fact -- a library that is not built, RCCL's symbols not found: agreed on like a
+            # verdict, or a rank without the rung would leave the others alone in its collective)
+            if not self._agree(eff == mode):
+                attempts.append({"mode": mode, "ok": False, "reason": f"not available here (would run as '{eff}')" if eff != mode
+                                 else "not available on another rank"})
+                if mode == "native":
+                    self._native_dead = True
                 continue
+            dog = self._native_watchdog() if mode == "native" else None
             try:
                 if mode in os.environ.get("TRIRO_PREFLIGHT_FAIL", "").split(","):
                     # test hook: make a rung fail on purpose (every rank alike), e.g. to rehearse the fallbacks on real hardware
@@ -379,9 +385,20 @@ class ShardedRayMeshIntersector:
                     torch.cuda.synchronize()
             except Exception as exc:      # noqa: BLE001 -- whatever the rung throws, the next one gets its chance
                 ok, reason = False, f"{type(exc).__name__}: {exc}"
+            if dog is not None:
+                dog[0].cancel()
+                if dog[1]["fired"]:
+                    ok, reason = False, f"no answer within {self.native_deadline_s:.0f} s: communicator aborted" + (f" ({reason})" if reason else "")
             all_ok = self._agree(ok)
             if not ok or not all_ok:
                 attempts.append({"mode": mode, "ok": False, "reason": reason or "failed on another rank"})
+                if mode == "native":
+                    self._native_drop()
+                    if torch.cuda.is_available() and torch.cuda.is_initialized():
+                        try:
+                            torch.cuda.synchronize()
+                        except Exception:      # noqa: BLE001
+                            pass
                 continue
             attempts.append({"mode": mode, "ok": True, "reason": ""})
             res = {"exchange_mode_used": mode, "requested": requested, "attempts": attempts}
@@ -872,6 +889,8 @@ class ShardedRayMeshIntersector:
     # ---- the native step: the same pipeline in ONE C call (include/triro_rccl.h, csrc/gather_rccl.cpp) -----------------
     def native_available(self) -> bool:
         """libtriro_rccl.so is built, RCCL can be found, and the tracer is the real one (a handle to hand to C)"""
+        if getattr(self, "_native_dead", False):       # its communicator was aborted / could not be made (preflight)
+            return False
         try:
             import triro.backend.ops as hops
             return (hops.rccl_available() and hasattr(self.local, "as_wrapper") and bool(getattr(self.local.as_wrapper, "_inner", None))
@@ -900,9 +919,65 @@ class ShardedRayMeshIntersector:
             ident = t.cpu()
         raw = (C.c_uint8 * hops.COMM_ID_BYTES)(*ident.tolist())
         h = C.c_void_p()
-        hops._check_rccl(lib.tr_comm_create(raw, self.world, self.rank, torch.cuda.current_device(), C.byref(h)))
+        # ncclCommInitRank is a collective with no time limit of its own: it runs in a helper thread (ctypes drops the
+        # GIL), and a rank that waits longer than the deadline gives the native rung up instead of hanging in it
+        import threading
+        box = {}
+        device = torch.cuda.current_device()
+
+        def make():
+            try:
+                box["rc"] = lib.tr_comm_create(raw, self.world, self.rank, device, C.byref(h))
+                box["err"] = (lib.tr_rccl_last_error() or b"?").decode() if box["rc"] else ""
+            except Exception as exc:      # noqa: BLE001
+                box["rc"], box["err"] = -1, repr(exc)
+        th = threading.Thread(target=make, daemon=True, name="triro-native-comm")
+        th.start()
+        th.join(self.native_deadline_s)
+        if th.is_alive():
+            self._native_dead = True
+            raise RuntimeError(f"ncclCommInitRank did not return within {self.native_deadline_s:.0f} s")
+        if box.get("rc", -1) != 0:
+            self._native_dead = True
+            raise RuntimeError("libtriro_rccl: " + box.get("err", "?"))
         self._ncomm = h
         return h
+
+    native_deadline_s = float(os.environ.get("TRIRO_NATIVE_DEADLINE_S", "45"))
+
+    def _native_drop(self):
+        """gives the native rung up for this object: aborts the communicator (ncclCommAbort: ends transfers that nobody
+        answers), the exchange falls to the next rung"""
+        self._native_dead = True
+        h, self._ncomm = getattr(self, "_ncomm", None), None
+        if h is not None:
+            try:
+                import triro.backend.ops as hops
+                lib = hops.get_rccl_module()
+                lib.tr_comm_abort(h)
+                lib.tr_comm_destroy(h)
+            except Exception:      # noqa: BLE001
+                pass
+
+    def _native_watchdog(self):
+        """a timer that aborts the native communicator from another thread when a rung under preflight has not finished
+        within the deadline: the blocked stream synchronisation returns, the outputs mismatch, every rank steps down"""
+        import threading
+        state = {"fired": False}
+
+        def fire():
+            state["fired"] = True
+            h = getattr(self, "_ncomm", None)
+            if h is not None:
+                try:
+                    import triro.backend.ops as hops
+                    hops.get_rccl_module().tr_comm_abort(h)
+                except Exception:      # noqa: BLE001
+                    pass
+        t = threading.Timer(self.native_deadline_s, fire)
+        t.daemon = True
+        t.start()
+        return t, state
 
     def closest_of_shard_native(self, o: torch.Tensor, d: torch.Tensor, n_total: int, batch_shape=None, dst: int = 0,
                                 chunks: Optional[int] = None, bounds=None, row_quantum: Optional[int] = None, all_rays=None,
@@ -983,6 +1058,12 @@ class ShardedRayMeshIntersector:
             else:
                 rec = records if records is not None else self._alloc((max(m, 1),), torch.int32, dev)
                 keep.append(rec)
+                if world > 1 and not (flags & hops.STEP_NO_EXCHANGE):
+                    # a peer's sends leave on a side stream: the next step's trace does not queue behind them
+                    if self._side is None:
+                        self._side = torch.cuda.Stream(device=dev)
+                    st.side_stream = self._side.cuda_stream
+                    rec.record_stream(self._side)      # (the caching allocator hands `rec` out again only behind the send)
             st.d_records = rec.data_ptr()
             comm = None
             if world > 1 and not (flags & hops.STEP_NO_EXCHANGE):
