@@ -34,11 +34,26 @@ def test_no_query_kernel_of_the_shipped_library_spills_inside_its_trips():
     assert wide and all(k["vgpr"] <= 96 and k["vgpr_spill"] <= 16 for k in wide), [(k["name"], k["vgpr"], k["vgpr_spill"]) for k in wide]
     bad = [(k["name"], k["vgpr"], k["vgpr_spill"]) for k in direct if k["vgpr_spill"] > 8]
     assert not bad, bad
-    # <Q, STATS, COMPACT, MODE, DEEP, QN>: the instantiations for hierarchies of more than 32 levels keep the compiler's own
-    # register budget -- forced to spill they die with a memory access fault (profiles/r06_deep_spill_fault.txt)
+    # <Q, STATS, COMPACT, MODE, DEEP, QN>: the instantiations for hierarchies of more than 32 levels (64-bit trail words) are
+    # the ones that died with a memory access fault when KERNEL-LIFETIME values were forced into scratch (stored in the
+    # prologue, reloaded in the stealing loop's hand-over code: profiles/r06_deep_spill_fault.txt).  They may
+    # save registers around the float64 call (the cold drain branch) and nothing else: every scratch instruction of a DEEP
+    # kernel sits within a few dozen instructions of an s_swappc.
     import re
-    deep = [k for k in direct if re.search(r"k_query_direct<\d, \w+, \w+, \d, true, \w+>", k["name"]) or re.search(r"k_query_count_steal(_sort)?<(\w+, )?true>", k["name"])]
-    assert len(deep) >= 10 and all(k["vgpr_spill"] == 0 for k in deep), [(k["name"], k["vgpr_spill"]) for k in deep]
+    deep = [k for k in direct if re.search(r"k_query_direct<\d, \w+, \w+, \d, true, \w+>", k["name"]) or re.search(r"k_query_direct_sort<\d, true", k["name"])
+            or re.search(r"k_query_count_steal(_sort)?<(\w+, )?true>", k["name"])]
+    assert len(deep) >= 10, [k["name"] for k in deep]
+    checked = 0
+    for want in ("k_query_direct<", "k_query_direct_sort<", "k_query_count_steal"):
+        for name, lines in isa_loops.disassemble(so, want):
+            if not any(name.startswith(k["name"].split("(")[0]) or k["name"].startswith(name) for k in deep):
+                continue
+            checked += 1
+            ins = isa_loops.instructions(lines)
+            calls = [i for i, (_, t) in enumerate(ins) if t.startswith("s_swappc_b64")]
+            far = [t for i, (_, t) in enumerate(ins) if t.startswith("scratch_") and not any(abs(i - c) <= 64 for c in calls)]
+            assert not far, (name, far)
+    assert checked >= 10, checked
     # (round 6, tr_drain_exact<COLD>: what the float64 call clobbers is saved AROUND the call, on the 0.6 % of leaf tests
     # that reach it -- those stores / loads sit within a few dozen instructions of the s_swappc and are not "in the trips")
     for want, kw in (("k_query_stream<", dict(near_call=64)), ("k_query_direct<", dict(near_call=64)), ("k_query_direct_sort<", dict(near_call=64)),

@@ -395,6 +395,9 @@ TR_HD tr_tri tr_load_tri(const tr_bvh_view& b, int32_t slot, tr_counters* cnt) {
 // owns this leaf (the code runs unpredicated for the whole wave).  Returns true when the ray
 // is finished (ANY query, first accepted hit).
 // Fold one decided leaf test into the per-query state.  Returns true when the ray is finished (ANY query, first hit).
+#ifndef TR_FOLD_FLAT
+#define TR_FOLD_FLAT 0
+#endif
 template <int Q, int K>
 TR_HD bool tr_fold_hit(bool hit, float t, int32_t face, int32_t slot, tr_result& res, tr_topk<K>& top) {
     if (Q == TR_Q_ANY) {
@@ -405,9 +408,18 @@ TR_HD bool tr_fold_hit(bool hit, float t, int32_t face, int32_t slot, tr_result&
     } else if (Q == TR_Q_LOCATION) {
         if (hit) { res.count++; top.insert(t, face, slot); }
     } else {
+#if TR_FOLD_FLAT
+        // the (t, face) order of tr_closer as one mask and three selects (no divergent control flow)
+        const int32_t bf = res.best_face < 0 ? 0x7fffffff : res.best_face;
+        const bool take = (int)hit & ((int)(t < res.best_t) | ((int)(t == res.best_t) & (int)(face < bf)));
+        tr_set_best_t(res, take ? t : res.best_t);
+        res.best_face = take ? face : res.best_face;
+        res.best_slot = take ? slot : res.best_slot;
+#else
         if (hit && tr_closer(t, face, res.best_t, res.best_face < 0 ? 0x7fffffff : res.best_face)) {
             tr_set_best_t(res, t); res.best_face = face; res.best_slot = slot;
         }
+#endif
     }
     return false;
 }
@@ -435,11 +447,14 @@ TR_HD bool tr_fold_leaf(bool live, const tr_ray& r, const tr_tri& t, int32_t slo
 // fabric traffic per launch of the headline, L2 misses +30 %).  Headline 0.1838 -> 0.1800 ms, every direct config
 // -1...-4 %; the streaming closest kernel on the binary nodes gets 10 spills and +6 % from the same hint and keeps
 // the plain branch (profiles/r06_ab_cold_drain.txt).
+#ifndef TR_DRAIN_COLD
+#define TR_DRAIN_COLD 1     // 0: no branch hint anywhere (A/B and fault-hunting builds)
+#endif
 template <int Q, int K, bool COMPACT = false, bool COLD = true>
 TR_HD bool tr_drain_exact(const tr_bvh_view& b, const tr_ray& r, int32_t& pe, tr_result& res, tr_topk<K>& top) {
     bool fin = false;
     const bool any_parked = TR_WAVE_ANY(pe >= 0);
-    if (COLD ? __builtin_expect(any_parked, 0) : any_parked) {
+    if ((COLD && TR_DRAIN_COLD) ? __builtin_expect(any_parked, 0) : any_parked) {
         if (pe >= 0) {
             tr_counters* nc = nullptr;
             const tr_tri t = tr_load_tri<false, COMPACT>(b, pe, nc);
