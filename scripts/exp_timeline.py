@@ -50,12 +50,20 @@ fn = {"closest": lambda: r.intersects_closest(o, d), "any": lambda: r.intersects
 for _ in range(a.warmup):
     fn()
 torch.cuda.synchronize()
+lib = ctypes.CDLL(hops.library_path())
+susp = hasattr(lib, "tr_debug_susp")        # the suspend experiment build (-DTR_SUSPEND_EXP=G): reset its flag and counters
+if susp:
+    lib.tr_debug_susp(1, None)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 fn()
 e1.record()
 torch.cuda.synchronize()
-lib = ctypes.CDLL(hops.library_path())
+susp_counts = None
+if susp:
+    sc = (ctypes.c_uint * 4)()
+    lib.tr_debug_susp(0, sc)
+    susp_counts = {"flag": int(sc[0]), "entries": int(sc[1]), "lanes": int(sc[2]), "waves": int(sc[3])}
 nw = min(a.res * a.res // 64 + 4096, 131072)          # + the extra launch slots of split blocks
 if a.hash_rays:
     nw = min((a.hash_rays + 63) // 64, 131072)
@@ -112,4 +120,6 @@ if trips.max() > 0:
     out["us_per_trip"] = {"all": round(float(dur.sum() / max(1, trips.sum())), 3),
                           "top12": round(float(dur[top].sum() / max(1, trips[top].sum())), 3)}
     out["trips"] = {"mean": round(float(trips.mean()), 1), "p99": round(q(trips, 99), 1), "max": int(trips.max())}
+if susp_counts is not None:
+    out["suspended"] = susp_counts
 print(json.dumps(out))
