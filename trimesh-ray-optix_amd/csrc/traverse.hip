@@ -49,22 +49,6 @@ extern "C" int tr_debug_usteal(unsigned* host_out) {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_usteal_debug), 16);
 }
 #endif
-#ifdef TR_SUSPEND_EXP
-extern "C" int tr_debug_susp(int reset, unsigned* host_out) {
-    static std::vector<unsigned> w(131072);
-    if (reset) {
-        unsigned z[4] = {0, 0, 0, 0};
-        std::fill(w.begin(), w.end(), 0u);
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_susp_w), w.data(), w.size() * 4);
-        return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_susp), z, 16);
-    }
-    (void)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_susp), 16);
-    (void)hipMemcpyFromSymbol(w.data(), HIP_SYMBOL(g_susp_w), w.size() * 4);
-    host_out[1] = host_out[2] = host_out[3] = 0;
-    for (unsigned x : w) if (x) { host_out[1] += x & 0xfffffu; host_out[2] += x >> 20; host_out[3]++; }
-    return 0;
-}
-#endif
 #ifdef TR_TIMELINE
 extern "C" int tr_debug_timeline(unsigned long long* host_out, long long n_waves) {
     if (n_waves > TR_TIMELINE) n_waves = TR_TIMELINE;
