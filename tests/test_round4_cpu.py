@@ -11,13 +11,13 @@ sys.path.insert(0, os.path.join(ROOT, "scripts"))
 
 def test_no_query_kernel_of_the_shipped_library_spills_inside_its_trips():
     """VERDICT r03 #7a, restated in round 6.  The traversal kernels ask for a wave per SIMD more than the compiler's own
-    budget gives them -- the streaming launch on the 8-wide nodes since round 5 (five waves, 96 registers; the one on the
-    binary nodes ran at six until the float64 call of round 6 made five faster: profiles/r06_ab_stream_waves.txt), the
-    direct launches since round 6, where the float64 part of the hit predicate is a real call at the end of a
-    trip (tr_drain_exact: the callee owns 30 registers) and the stealing closest kernel would otherwise land at 83 --
-    and pay with kernel-lifetime values in scratch: stored in the prologue, read once per refill / after the traversal
-    loop.  What is pinned here, read off the shipped ISA: the budgets, a bound on the spilled registers, and NO scratch
-    instruction inside the traversal trips of any launch family."""
+    budget gives them -- the streaming launches five (96 registers: at six they spill inside the trip once the float64
+    call is in the kernel, profiles/r06_ab_stream_waves.txt), the direct launches six (80), where the float64 part of
+    the hit predicate is a real call at the end of a trip (tr_drain_exact: the callee owns v0-v31).  What that costs is
+    pinned here, read off the shipped ISA: the budgets; a bound on the spilled registers; NO scratch instruction inside
+    the traversal trips of any launch family except the save / restore around that call (a cold branch: 0.6 % of the
+    leaf tests); and, for the kernels of hierarchies deeper than 32 levels, no scratch instruction anywhere else at all
+    (the pattern that faulted: profiles/r06_deep_fault_probe.txt)."""
     import code_object_notes as con
     sys.path.insert(0, os.path.join(ROOT, "scripts", "round5"))
     import isa_loops
