@@ -328,15 +328,9 @@ struct tr_result {
     int32_t best_slot;
     // count
     int32_t count;
-#ifdef TR_LIM_REG
-    float lim;           // best_t * TR_CULL_SLACK, kept beside best_t (a register for one multiply per trip: A/B builds)
-#endif
 };
 TR_HD void tr_set_best_t(tr_result& res, float t) {
     res.best_t = t;
-#ifdef TR_LIM_REG
-    res.lim = t * TR_CULL_SLACK;
-#endif
 }
 
 // COMPACT addressing: byte offsets fit 32 bits (nodes*64 and tris*48 below 4 GiB), so the
@@ -367,11 +361,8 @@ TR_HD void tr_result_init(tr_result& res) {
 // the limit a box's entry distance is culled against (tr_math.h, TR_CULL_SLACK)
 template <int Q>
 TR_HD float tr_cull_limit(const tr_result& res) {
-#ifdef TR_LIM_REG
-    return (Q == TR_Q_FIRST || Q == TR_Q_CLOSEST) ? res.lim : TR_TLIM;
-#else
+    // (the product is recomputed per trip: kept in a register beside best_t it measured slower, profiles/r06_pmc_headline.txt)
     return (Q == TR_Q_FIRST || Q == TR_Q_CLOSEST) ? res.best_t * TR_CULL_SLACK : TR_TLIM;
-#endif
 }
 
 template <bool STATS, bool COMPACT = false>
@@ -395,9 +386,6 @@ TR_HD tr_tri tr_load_tri(const tr_bvh_view& b, int32_t slot, tr_counters* cnt) {
 // owns this leaf (the code runs unpredicated for the whole wave).  Returns true when the ray
 // is finished (ANY query, first accepted hit).
 // Fold one decided leaf test into the per-query state.  Returns true when the ray is finished (ANY query, first hit).
-#ifndef TR_FOLD_FLAT
-#define TR_FOLD_FLAT 0
-#endif
 template <int Q, int K>
 TR_HD bool tr_fold_hit(bool hit, float t, int32_t face, int32_t slot, tr_result& res, tr_topk<K>& top) {
     if (Q == TR_Q_ANY) {
@@ -408,18 +396,9 @@ TR_HD bool tr_fold_hit(bool hit, float t, int32_t face, int32_t slot, tr_result&
     } else if (Q == TR_Q_LOCATION) {
         if (hit) { res.count++; top.insert(t, face, slot); }
     } else {
-#if TR_FOLD_FLAT
-        // the (t, face) order of tr_closer as one mask and three selects (no divergent control flow)
-        const int32_t bf = res.best_face < 0 ? 0x7fffffff : res.best_face;
-        const bool take = (int)hit & ((int)(t < res.best_t) | ((int)(t == res.best_t) & (int)(face < bf)));
-        tr_set_best_t(res, take ? t : res.best_t);
-        res.best_face = take ? face : res.best_face;
-        res.best_slot = take ? slot : res.best_slot;
-#else
         if (hit && tr_closer(t, face, res.best_t, res.best_face < 0 ? 0x7fffffff : res.best_face)) {
             tr_set_best_t(res, t); res.best_face = face; res.best_slot = slot;
         }
-#endif
     }
     return false;
 }

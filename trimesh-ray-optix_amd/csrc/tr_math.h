@@ -275,9 +275,6 @@ TR_HD bool tr_tri_exact(const tr_ray& r, float ax, float ay, float az, float bx,
 // absorbs), otherwise undecided, too.  Accepted iff 0 <= t <= 1e7 (shaders.cu:86: tmin 0, tmax 1e7; no culling).
 // Early exits are kept: in a wave most candidate triangles are proven outside, and the compiler skips the rest when no
 // lane is left (s_cbranch_execz).
-#ifndef TR_TRI_FLAT
-#define TR_TRI_FLAT 0     // 0: four nested early exits, 1: one branch (more registers: spills), 2: two levels -- the same decisions
-#endif
 enum { TR_MISS = 0, TR_HIT = 1, TR_UNDECIDED = 2 };
 TR_HD float tr_tri_scale(float ax, float ay, float az, float bx, float by, float bz, float cx, float cy, float cz) {
     const float e1x = bx - ax, e1y = by - ay, e1z = bz - az;
@@ -304,12 +301,7 @@ TR_HD int tr_tri_fast(const tr_ray& r, float ax, float ay, float az, float bx, f
     const float mm = fmaf(kE, LsE, TR_BAND_ABS);
     // the bounds hold while nothing overflows and what underflows stays below the 2^-100 of mm: lengths up to 2^40
     // (the direction's: kd = inf makes mm inf or NaN, and nothing below is decided)
-#if TR_TRI_FLAT == 0
     if (!(LsE <= TR_BAND_MAXLEN)) return TR_UNDECIDED;      // (NaN, too)
-#elif TR_TRI_FLAT == 2
-    // (not a branch of its own: an infinite margin leaves everything undecided; NaN lengths, too)
-    const float mmx = (LsE <= TR_BAND_MAXLEN) ? mm : INFINITY;
-#endif
     // q = s x e1
     float qx = fmaf(sy, e1z, -(sz * e1y));
     float qy = fmaf(sz, e1x, -(sx * e1z));
@@ -318,32 +310,10 @@ TR_HD int tr_tri_fast(const tr_ray& r, float ax, float ay, float az, float bx, f
     const float Vf = tr_u2f(tr_f2u(V) ^ flip);
     const float Wf = (fabsf(det) - Uf) - Vf;
     // ONE decision from the smallest of the three (round 6 tried exits after U and after V: with five lanes of a wave in
-    // a leaf block some lane nearly always survives them, the branches cost more than they skipped)
+    // a leaf block some lane nearly always survives them, the branches cost more than they skipped; and FEWER levels of
+    // nested exits -- two, or one branch around the division: 13 scalar instructions less per trip, no time: commit 650222c
+    // has the variants (TR_TRI_FLAT, TR_FOLD_FLAT), profiles/r06_ab_flat_leaf.txt the numbers)
     const float m3 = fminf(fminf(Uf, Vf), Wf);
-#if TR_TRI_FLAT == 2
-    // two levels of divergent control flow instead of four (each costs the wave a saveexec / branch / restore triple whether
-    // or not a lane takes it): proven outside; then the division behind everything a float32 distance needs
-    if (m3 < -mmx) return TR_MISS;
-    const float T = tr_dot(e2x, e2y, e2z, qx, qy, qz);
-    if (!((int)(m3 > mmx) & (int)(fabsf(det) >= (kE * E) * 1024.0f) & (int)(fabsf(T) >= (Ls * 9.765625e-4f) * (E * E)))) return TR_UNDECIDED;
-    const float t = T / det;
-    h.t = t;
-    return (t >= TR_TMIN && t <= TR_TMAX) ? TR_HIT : TR_MISS;
-#elif TR_TRI_FLAT == 1
-    // the same decisions with ONE branch (around the division) instead of four nested ones: every level of divergent
-    // control flow costs the wave a saveexec / branch / restore triple whether or not a lane takes it
-    const float T = tr_dot(e2x, e2y, e2z, qx, qy, qz);
-    const bool sane = LsE <= TR_BAND_MAXLEN;                 // (NaN: false)
-    const bool out = sane & (m3 < -mm);
-    const bool in = sane & (m3 > mm) & (fabsf(det) >= (kE * E) * 1024.0f) & (fabsf(T) >= (Ls * 9.765625e-4f) * (E * E));
-    int c = out ? TR_MISS : TR_UNDECIDED;
-    if (in) {
-        const float t = T / det;
-        h.t = t;
-        c = (t >= TR_TMIN && t <= TR_TMAX) ? TR_HIT : TR_MISS;
-    }
-    return c;
-#else
     if (m3 < -mm) return TR_MISS;
     if (!(m3 > mm)) return TR_UNDECIDED;
     const float T = tr_dot(e2x, e2y, e2z, qx, qy, qz);
@@ -351,7 +321,6 @@ TR_HD int tr_tri_fast(const tr_ray& r, float ax, float ay, float az, float bx, f
     const float t = T / det;
     h.t = t;
     return (t >= TR_TMIN && t <= TR_TMAX) ? TR_HIT : TR_MISS;
-#endif
 }
 // the whole predicate in one call (brute force, single-triangle meshes, host code); the traversal kernels run the two
 // parts apart (tr_fold_leaf / tr_drain_exact, tr_bvh.h)
