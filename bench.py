@@ -778,6 +778,8 @@ def run_rank(args):
             if packed_ok:
                 gather_txt += (f" (4 B/ray slot records over {via}, finished on rank 0 from its copy of the rays, " if slot_rec else
                                f" (12 B/ray packed records over {via}, expanded on rank 0, ") + "exchange of step k overlaps trace of step k+1)"
+                if slot_rec and S.exchange_mode == "native":
+                    gather_txt += " [the step is ONE C call: tr_sharded_closest_step, libtriro_rccl.so]"
             else:
                 gather_txt += f" (26 B/ray dense outputs over {via}, exchange mode '{S.exchange_mode}')"
         metric = "Mrays/s closest-hit, 1M-tri mesh, 1024^2 ray batch"

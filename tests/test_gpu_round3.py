@@ -296,7 +296,10 @@ def test_bench_result_pipeline_on_rccl_one_rank():
     for extra in (["--workload", "c5i"], ["--workload", "c5i", "--scaling", "strong"],
                   ["--workload", "c5ii", "--total-rays", "7000001", "--chunks", "3"],
                   ["--workload", "c5i", "--records", "packed"],
-                  ["--workload", "c5ii", "--total-rays", "7000001", "--chunks", "3", "--records", "packed"]):
+                  ["--workload", "c5ii", "--total-rays", "7000001", "--chunks", "3", "--records", "packed"],
+                  # round 6: the step as one C call (libtriro_rccl.so), preflighted like every rung
+                  ["--workload", "c5i", "--exchange", "native"],
+                  ["--workload", "c5ii", "--total-rays", "7000001", "--chunks", "3", "--exchange", "native"]):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
                "--master-port", str(free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "6",
                "--warmup", "2", "--min-warmup-ms", "0", "--no-cpu-baseline", "--no-companions", "--force-gather"] + extra
@@ -307,6 +310,8 @@ def test_bench_result_pipeline_on_rccl_one_rank():
         assert r["verified"] is True and r["n_gpus"] == 1 and r["value"] > 100
         want = "12 B/ray packed records over RCCL" if "packed" in extra else "4 B/ray slot records over RCCL"       # (round 4: rank 0 holds the rays by default)
         assert want in r["config"]["parallelism"] and "--force-gather" in r["config"]["parallelism"]
+        if "native" in extra:
+            assert r["config"]["exchange_mode_used"] == "native" and "tr_sharded_closest_step" in r["config"]["parallelism"], r["config"]
 
 
 def test_packed_closest_edge_cases(device):
