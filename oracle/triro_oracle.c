@@ -77,6 +77,7 @@
 #endif
 
 #define TR_TMAX 1.0e7f
+#define TR_TANCHOR 9.99999e6f /* anchoring only when the whole box is nearer than this: every triangle then lies within tmax of the origin as well */
 #define TR_HUGE 3.0e38f
 #define TR_SLAB_PAD 1.000000476837158203125f /* 1 + 2^-21 */
 #define TR_CULL_SLACK 1.0009765625f         /* 1 + 2^-10 */
@@ -127,7 +128,7 @@ static inline void cross3(const float *x, const float *y, float *r) {
 
 /* ray anchoring (contract 3; csrc/tr_math.h tr_ray_anchor): a ray that starts far outside the mesh's box is moved along
  * itself to just in front of its entry point.  tn, tf = entry / exit of the slab test (reciprocals clamped to +-3e38, no
- * padding), chord = tf - tn; anchored iff 0 < tn <= tf, tn < 1e7, tn > chord / 2; t0 = tn - max(chord / 16, tn * 2^-18);
+ * padding), chord = tf - tn; anchored iff 0 < tn <= tf, tf < 1e7 (1 - 1e-6), tn > chord / 2; t0 = tn - max(chord / 16, tn * 2^-18);
  * o' = o + t0 * d with a compensated product (fma) and sum (TwoSum): within an ulp of itself of the exact point. */
 static void anchor_ray(const omesh_t *m, const float *o, const float *d, float *oa) {
     float tn = -INFINITY, tf = INFINITY;
@@ -141,7 +142,7 @@ static void anchor_ray(const omesh_t *m, const float *o, const float *d, float *
     }
     const float chord = tf - tn;
     for (int i = 0; i < 3; i++) oa[i] = o[i];
-    if (!(tn > 0.0f && tn <= tf && tn < TR_TMAX && tn > 0.5f * chord)) return;
+    if (!(tn > 0.0f && tn <= tf && tf < TR_TANCHOR && tn > 0.5f * chord)) return;
     const float t0 = tn - fmaxf(chord * 0.0625f, tn * 3.814697265625e-06f);
     for (int i = 0; i < 3; i++) {
         const float p = t0 * d[i], e = fmaf(t0, d[i], -p);

@@ -157,6 +157,28 @@ def test_native_step_that_nobody_answers_is_given_up_not_waited_for(device):
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
 
 
+def test_tmax_counts_from_the_origin_for_rays_that_would_be_anchored(device):
+    """the far end of the reference's interval [0, 1e7] under ray anchoring (tests/test_oracle.py has the scene and the reasoning):
+    the HIP path against the oracle, every query"""
+    sq = lambda x: [[x, -4, -4], [x, 4, -4], [x, 0, 4]]  # noqa: E731
+    v = np.array(sq(5.0e6) + sq(9.9e6) + sq(1.00005e7) + sq(1.0001e7), np.float32)
+    f = np.arange(12, dtype=np.int32).reshape(4, 3)
+    o = np.array([[0, 0, 0], [5.5e6, 0, 0], [9.95e6, 0, 0], [0, 0, 0], [0, 1, 0], [2.0e6, -1, 1]], np.float32)
+    d = np.array([[1, 0, 0], [1, 0, 0], [1, 0, 0], [2, 0, 0], [1, 0, 0], [1, 1e-7, 0]], np.float32)
+    r = make(v, f, device)
+    R = OracleIntersector(v, f, 1)
+    ot, dt = T(o, device), T(d, device)
+    cnt = r.intersects_count(ot, dt).cpu().numpy()
+    assert cnt.tolist() == R.intersects_count(o, d).tolist() and cnt[:4].tolist() == [2, 3, 2, 4]
+    got = [x.cpu().numpy() for x in r.intersects_closest(ot, dt)]
+    for g, e in zip(got, R.intersects_closest(o, d)[:5]):
+        assert np.array_equal(g, e, equal_nan=True)
+    assert np.array_equal(r.intersects_any(ot, dt).cpu().numpy(), R.intersects_any(o, d))
+    loc, ridx, tidx = r.intersects_location(ot, dt)
+    el, er, et = R.intersects_location(o, d)
+    assert np.array_equal(ridx.cpu().numpy(), er) and np.array_equal(tidx.cpu().numpy(), et) and np.array_equal(loc.cpu().numpy(), el)
+
+
 def test_graph_replay_follows_a_refit_that_moves_the_bounds(device):
     """A launch captured in a HIP graph freezes its kernel arguments -- the grid frame of the mesh among them, which the
     grid nodes' decode AND the rays' anchor depend on.  Since round 6 the kernels read the frame from device memory

@@ -148,6 +148,28 @@ def test_invalid_and_degenerate():
     assert R.intersects_any(o, d).tolist() == [False, True]
 
 
+def test_tmax_is_measured_from_the_origin_also_for_rays_that_would_be_anchored():
+    """Ray anchoring (tr_ray_anchor) moves a far origin to the mesh's box and measures distances from there -- which must not
+    lengthen the reference's interval [0, 1e7] (shaders.cu:86): a ray is only anchored when the WHOLE box lies within tmax of
+    its origin.  A mesh 5e6 ... 1.0001e7 units down the ray: the triangle at 9.9e6 is hit, the one at 1.00005e7 is not (the
+    first form of the anchor, `tn < 1e7`, started counting at 5e6 and hit it at t' = 5e6); brute force == BVH walk."""
+    sq = lambda x: [[x, -4, -4], [x, 4, -4], [x, 0, 4]]  # noqa: E731
+    v = np.array(sq(5.0e6) + sq(9.9e6) + sq(1.00005e7) + sq(1.0001e7), np.float32)
+    f = np.arange(12, dtype=np.int32).reshape(4, 3)
+    o = np.array([[0, 0, 0], [5.5e6, 0, 0], [9.95e6, 0, 0], [0, 0, 0]], np.float32)
+    d = np.array([[1, 0, 0], [1, 0, 0], [1, 0, 0], [2, 0, 0]], np.float32)
+    for mode in (0, 1):
+        R = OracleIntersector(v, f, mode)
+        assert R.intersects_count(o, d).tolist() == [2, 3, 2, 4]         # (direction of length 2: t = distance / 2, all four within 1e7)
+        hit, front, tri, loc, uv = R.intersects_closest(o, d)[:5]
+        assert tri.tolist() == [0, 1, 2, 0]
+    # a mesh that does lie within tmax IS anchored, with the same answers as from the far origin in float64
+    v2 = np.array(sq(5.0e6) + sq(5.0e6 + 8), np.float32)
+    R = OracleIntersector(v2, np.arange(6, dtype=np.int32).reshape(2, 3), 1)
+    oa = R.anchor(o[:1], d[:1])
+    assert oa[0, 0] > 4.9e6 and R.intersects_count(o[:1], d[:1]).tolist() == [2]
+
+
 def test_fetch_rays_strides():
     rng = np.random.default_rng(0)
     base = rng.random((5, 7, 6)).astype(np.float32)

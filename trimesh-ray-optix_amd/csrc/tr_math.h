@@ -49,6 +49,7 @@
 
 #define TR_TMIN 0.0f
 #define TR_TMAX 1.0e7f                          // shaders.cu:86 (tmax of every optixTrace)
+#define TR_TANCHOR 9.99999e6f                   // a ray is anchored only if its mesh's whole box lies nearer than this (tr_ray_anchor)
 #define TR_HUGE 3.0e38f                         // finite stand-in for 1/0
 // Robust slab (Ize 2013): a plane distance (lo - o) * inv is three roundings from the exact one (subtract, reciprocal,
 // multiply): within (1 +- 2^-24)^3.  An entry distance can come out 3 u too large and an exit distance 3 u too small, in
@@ -108,14 +109,17 @@ TR_HD bool tr_finite(float x) { return fabsf(x) <= 3.4028234663852886e38f; }  //
 // image 1.2x / 2x slower: profiles/r06_far_camera.txt).  From the anchor that distance is about the box's size,
 // wherever the camera stands.
 //   tn, tf = entry / exit distance of the slab test on the box [lo, hi] (clamped reciprocals, no padding); chord = tf - tn;
-//   anchored iff  0 < tn <= tf,  tn < 1e7  and  tn > chord / 2  (an origin closer than half a chord gains nothing);
+//   anchored iff  0 < tn <= tf,  tf < 1e7 (1 - 1e-6)  and  tn > chord / 2  (an origin closer than half a chord gains nothing;
+//   a box that reaches beyond the reference's tmax keeps its ray where it is, see below);
 //   t0 = tn - max(chord / 16, tn * 2^-18)          (in front of the entry by more than the slab test can be wrong);
 //   o' = o + t0 * d  per component with a COMPENSATED product and sum (the product's rounding error from an fma, the
 //   sum's from TwoSum, both added back): o' is within an ulp OF ITSELF of the exact point of the ray, however large o
 //   is -- the displaced ray is the float32 noise of any ray transform, the same point for every triangle (watertightness
 //   is untouched), and more accurate than round 5's arithmetic from the far origin was.
 // Distances are measured from the anchor: the interval [0, 1e7] of the reference (shaders.cu:86) starts there (nothing
-// lies in front of the box).  A pure function of (ray, box): the oracle restates it, every rank of a sharded run computes
+// lies in front of the box) -- and it ends where the reference's does for every triangle of the mesh: a ray is only
+// anchored when the whole box lies within 1e7 (1 - 1e-6) of its origin (tf, which the slab arithmetic gets wrong by a few
+// 2^-24 at most), so every triangle -- all inside the box -- is nearer than 1e7 from the origin AND from the anchor.  A pure function of (ray, box): the oracle restates it, every rank of a sharded run computes
 // the same anchor.
 TR_HD void tr_ray_anchor(const float* lo, const float* hi, float& ox, float& oy, float& oz, float dx, float dy, float dz) {
     const float ix = tr_inv(dx), iy = tr_inv(dy), iz = tr_inv(dz);
@@ -125,7 +129,7 @@ TR_HD void tr_ray_anchor(const float* lo, const float* hi, float& ox, float& oy,
     const float tn = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fminf(z1, z2));
     const float tf = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fmaxf(z1, z2));
     const float chord = tf - tn;
-    if (!(tn > 0.0f && tn <= tf && tn < TR_TMAX && tn > 0.5f * chord)) return;      // (NaN: not anchored)
+    if (!(tn > 0.0f && tn <= tf && tf < TR_TANCHOR && tn > 0.5f * chord)) return;      // (NaN: not anchored)
     const float t0 = tn - fmaxf(chord * 0.0625f, tn * 3.814697265625e-06f);
 #define TR_ANCHOR_AXIS(o, d)                                         \
     {                                                                \
