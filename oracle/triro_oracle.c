@@ -47,7 +47,8 @@
  *   inside: m3 < -mm -> outside (proven);  m3 > mm -> inside (proven), t = T/det in float32 provided
  *          |det| >= (kd*E*E)*1024 and |T| >= (Ls*2^-10)*(E*E) (relative error of t < 2^-11);
  *          anything else (also NaN) -> the EXACT part: Woop / Benthin / Wald 2013 edge functions in float64 from the
- *          float32 inputs, projective form (woop64 below): inside iff U,V,W all >= 0 or all <= 0 and U+V+W != 0;
+ *          float32 inputs, projective form (woop64 below): inside iff U,V,W all >= 0 or all <= 0 and U+V+W != 0 -- where one of
+ *          them is exactly ZERO (the ray passes through an edge or a vertex) only for the triangle that owns that edge (tie_own);
  *          t = (float)(fma(W,Cz, fma(V,Bz, U*Az)) / ((U+V+W) * d[kz]))
  *   accepted iff 0 <= t <= 1e7;  closest = lexicographic minimum of (t, tri_idx) over accepted triangles
  *   outputs of the winning triangle from the float64 edge functions: w0 = (float)(U/det64), w1 = (float)(V/det64),
@@ -237,7 +238,29 @@ static inline void woop64(const float *o, const float *d, const float *a, const 
     w->dz = dz;
 }
 
-/* inside test of the exact part (both windings; zero counts as inside: a ray through a shared edge hits both) */
+/* Exact ties (csrc/tr_math.h "exact ties"): an edge whose function is exactly zero belongs to ONE of its two triangles, as
+ * in a rasteriser's fill rule.  The directed edge p -> q seen along the ray (permuted components, float64; q - p is exact):
+ * e = ((qx - px) dz - dx (qz - pz), (qy - py) dz - dy (qz - pz)), exactly negated when p and q swap; with the orientation
+ * normalised (s = sign(U + V + W)) the owner is the triangle whose s e has ey > 0, or ey = 0 and ex > 0. */
+static inline int edge_own(double s, const float *d, int kx, int ky, int kz, const float *p, const float *q) {
+    const double ux = (double)q[kx] - (double)p[kx], uy = (double)q[ky] - (double)p[ky], uz = (double)q[kz] - (double)p[kz];
+    const double ex = s * fma(-(double)d[kx], uz, ux * (double)d[kz]), ey = s * fma(-(double)d[ky], uz, uy * (double)d[kz]);
+    return ey > 0.0 || (ey == 0.0 && ex > 0.0);
+}
+/* does the triangle own every edge whose function is zero (U: b -> c, V: c -> a, W: a -> b)? */
+static inline int tie_own(const woop_t *w, double det, const float *d, const float *a, const float *b, const float *c) {
+    int kz = 0;
+    if (fabsf(d[1]) > fabsf(d[kz])) kz = 1;
+    if (fabsf(d[2]) > fabsf(d[kz])) kz = 2;
+    const int kx = (kz + 1) % 3, ky = (kz + 2) % 3;
+    const double s = det < 0.0 ? -1.0 : 1.0;
+    if (w->U == 0.0 && !edge_own(s, d, kx, ky, kz, b, c)) return 0;
+    if (w->V == 0.0 && !edge_own(s, d, kx, ky, kz, c, a)) return 0;
+    if (w->W == 0.0 && !edge_own(s, d, kx, ky, kz, a, b)) return 0;
+    return 1;
+}
+
+/* inside test of the exact part: both windings, no strict sign conflict (zero edge functions: tie_own, at the call sites) */
 static inline int woop_inside(const woop_t *w, double *det_out) {
     const double U = w->U, V = w->V, W = w->W;
     if ((U < 0.0 || V < 0.0 || W < 0.0) && (U > 0.0 || V > 0.0 || W > 0.0)) return 0;
@@ -301,6 +324,7 @@ static inline int tri_hit(const ray_t *r, const float *a, const float *b, const 
         double det64;
         woop64(r->o, r->d, a, b, c, &w);
         if (!woop_inside(&w, &det64)) return 0;
+        if ((w.U == 0.0 || w.V == 0.0 || w.W == 0.0) && !tie_own(&w, det64, r->d, a, b, c)) return 0;      /* an exact tie: not this triangle's edge */
         t = (float)(fma(w.W, w.Cz, fma(w.V, w.Bz, w.U * w.Az)) / (det64 * w.dz));
     }
     if (!(t >= 0.0f && t <= TR_TMAX)) return 0;

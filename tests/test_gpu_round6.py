@@ -87,7 +87,8 @@ def test_rays_aimed_at_shared_edges_and_vertices_never_slip_through(device):
     is zero -- from eye points inside the mesh ALWAYS hit, whatever query and launch family; from outside they hit
     unless they graze the silhouette; everything agrees with the oracle bit for bit (the oracle's brute force on a
     sample, too) and, in the hit mask, with the independent float64 watertight reference up to the rays that pass
-    through a vertex exactly (where "zero counts as inside" and a sheared test with a rounded quotient may differ)."""
+    through a vertex exactly (where the owner rule of the contract and a sheared test with a rounded quotient may
+    differ).  From inside, every ray counts exactly ONE hit -- an edge or a vertex belongs to one triangle."""
     v, f = W.icosphere(5)
     v = W.displaced(v, seed=3, amplitude=0.08)
     r = make(v, f, device)
@@ -120,12 +121,14 @@ def test_rays_aimed_at_shared_edges_and_vertices_never_slip_through(device):
         assert np.array_equal(B.intersects_count(eye[sub], d[sub]), ec[sub])
         if eye is eye_in:
             assert bool(hit.all()), f"{int((~hit).sum())} rays slipped out of a closed mesh"
-            assert np.all(ec[:300_000] % 2 == 1)          # (rays through edges: an odd number of crossings from inside)
+            assert np.all(ec % 2 == 1)          # (through edges AND vertices: an odd number of crossings from inside -- one owner per edge)
         else:
             assert float(hit.float().mean()) > 0.99
-            assert np.all(ec[:300_000] % 2 == 0)
+            assert np.all(ec % 2 == 0)          # (... and an even number from outside, the rays through vertices included)
         wtri, wt, wcnt = R.watertight(R.anchor(eye, d), d)
-        assert int(((wtri >= 0) != eh).sum()) <= 8 and int(((wtri >= 0) != eh)[:300_000].sum()) == 0
+        # (edge rays: the same hit mask; vertex rays: at a vertex of the SILHOUETTE the contract's owner rule says none or both,
+        # the sheared test one -- a handful of the 2 000 rays that run through their vertex exactly)
+        assert int(((wtri >= 0) != eh).sum()) <= 48 and int(((wtri >= 0) != eh)[:300_000].sum()) == 0
 
 
 @pytest.mark.timeout(600)

@@ -102,12 +102,23 @@ def test_golden_fixtures(path, mode):
     assert np.array_equal(lloc, g["loc_loc"]) and np.array_equal(lt, g["loc_t"])
 
 
-def test_cube_boundary_rays_hit_both_sides():
+def test_cube_boundary_rays_see_a_half_open_square():
+    """Axis-parallel rays on a grid that contains the cube's silhouette lines x, y = +-1 exactly (exact ties: the ray runs
+    through an edge or a vertex).  With the ownership rule of contract 3 (tr_math.h "exact ties") the cube is, seen along
+    such a ray, a HALF-OPEN square -- the rasteriser's fill rule: the interior, exactly one of each pair of opposite boundary
+    lines, exactly one of the four corners -- so that cubes side by side would cover every ray exactly once; and every ray
+    that hits crosses the closed surface exactly twice (the first form, "zero counts as inside", counted 4 on 34 of them)."""
     g = np.load(os.path.join(GOLD, "cube_axis_rays.npz"))
-    o, hit = g["origins"], g["hit"]
-    first = slice(0, 625)
-    inside = (np.abs(o[first, 0]) <= 1) & (np.abs(o[first, 1]) <= 1)   # includes x = +-1, y = +-1
-    assert np.array_equal(hit[first], inside)
+    for sl in (slice(0, 625), slice(625, 1250)):
+        o, d, hit, cnt = g["origins"][sl], g["directions"][sl], g["hit"][sl], g["count"][sl]
+        ax = [i for i in range(3) if d[0, i] == 0]
+        x, y = o[:, ax[0]], o[:, ax[1]]
+        assert hit[(np.abs(x) < 1) & (np.abs(y) < 1)].all() and not hit[(np.abs(x) > 1) | (np.abs(y) > 1)].any()
+        for u, w in ((x, y), (y, x)):
+            lo, hi = hit[(u == -1) & (np.abs(w) < 1)], hit[(u == 1) & (np.abs(w) < 1)]
+            assert len(lo) == len(hi) == 15 and (lo.all() != hi.all()) and (lo.all() or not lo.any()) and (hi.all() or not hi.any())
+        assert int(hit[(np.abs(x) == 1) & (np.abs(y) == 1)].sum()) == 1
+        assert set(np.unique(cnt)) == {0, 2} and np.array_equal(cnt > 0, hit)
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2])

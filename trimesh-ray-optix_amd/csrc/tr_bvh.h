@@ -437,9 +437,19 @@ TR_HD bool tr_drain_exact(const tr_bvh_view& b, const tr_ray& r, int32_t& pe, tr
         if (pe >= 0) {
             tr_counters* nc = nullptr;
             const tr_tri t = tr_load_tri<false, COMPACT>(b, pe, nc);
-            tr_hit h;
-            const bool hit = tr_tri_exact(r, t.ax, t.ay, t.az, t.bx, t.by, t.bz, t.cx, t.cy, t.cz, h);
-            fin = tr_fold_hit<Q, K>(hit, h.t, t.face, pe, res, top);
+            const tr_exact_res e = tr_tri_exact_t(r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, t.ax, t.ay, t.az, t.bx, t.by, t.bz, t.cx, t.cy, t.cz);
+            float tt = e.t;
+            if (__builtin_expect(e.tie != 0, 0)) {
+                // an exact tie (the ray passes through an edge or a vertex): does this triangle own it?  The triangle is
+                // FETCHED AGAIN for that question -- kept alive across the call above it would cost every kernel eight registers
+#if defined(__HIP_DEVICE_COMPILE__)
+                __asm__ volatile("" ::: "memory");
+#endif
+                const tr_tri u = tr_load_tri<false, COMPACT>(b, pe, nc);
+                if (!tr_tie_own(r.dx, r.dy, r.dz, u.ax, u.ay, u.az, u.bx, u.by, u.bz, u.cx, u.cy, u.cz, e.tie)) tt = -1.0f;
+            }
+            const bool hit = tt >= TR_TMIN && tt <= TR_TMAX;
+            fin = tr_fold_hit<Q, K>(hit, tt, t.face, pe, res, top);
             pe = -1;
         }
     }

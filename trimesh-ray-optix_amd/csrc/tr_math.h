@@ -9,8 +9,9 @@
 //   * inside test: Moller-Trumbore in float32 wherever its answer is PROVEN (a running bound on the
 //     rounding error of U, V, det - U - V; the three must clear it), and otherwise -- the ray passes
 //     within rounding of an edge, a vertex or the triangle's plane -- Woop / Benthin / Wald 2013 edge
-//     functions in float64 (tr_woop64): exact negations for the two triangles of a shared edge, zero
-//     counts as inside, so no ray slips between two triangles of a closed mesh;
+//     functions in float64 (tr_woop64): exact negations for the two triangles of a shared edge, so no ray slips
+//     between two triangles of a closed mesh; a function that is exactly ZERO (the ray runs through the edge) counts
+//     for the ONE triangle that owns the edge (tr_tie_own: the fill rule of rasterisers), so none is hit twice;
 //   * distance: T / det in float32 where its relative error is proven below 2^-11, float64 otherwise;
 //   * outputs: the barycentrics of the WINNING triangle from the float64 edge functions.
 // The predicate is a pure function of (ray, triangle) -- no box, no clamp (contract 2 clamped the distance
@@ -231,28 +232,83 @@ TR_HD void tr_woop64(float ox, float oy, float oz, float dx, float dy, float dz,
     else if (kz == 0) tr_woop64_xyz(oy, oz, ox, dy, dz, dx, ay, az, ax, by, bz, bx, cy, cz, cx, w);
     else tr_woop64_xyz(oz, ox, oy, dz, dx, dy, az, ax, ay, bz, bx, by, cz, cx, cy, w);
 }
-// both windings; a zero edge function counts as inside (a ray through a shared edge hits both triangles)
+// both windings; no strict sign conflict (a ZERO edge function: see tr_tie_code / tr_tie_own)
 TR_HD bool tr_woop_inside(const tr_woop& w, double& det) {
     const bool neg = (w.U < 0.0) | (w.V < 0.0) | (w.W < 0.0), pos = (w.U > 0.0) | (w.V > 0.0) | (w.W > 0.0);
     det = (w.U + w.V) + w.W;
     return !(neg & pos) & (det != 0.0);
+}
+// ---- exact ties ---------------------------------------------------------------------------------------------------------
+// A ray through a shared edge makes that edge's function zero in BOTH neighbours, one through a vertex two functions of
+// every triangle of the fan.  "Zero counts as inside" (the first form of contract 3) hits them all: watertight, but an entry
+// through an edge counts twice and flips the parity of contains_points -- and for rays and meshes on a common grid (axis-
+// parallel rays through the vertices of a height field, a voxel surface) that is the ordinary case.  The rule of rasterisers
+// instead: an edge belongs to ONE of its two triangles.  The directed edge p -> q of a triangle, seen along the ray, is
+//     e = ((qx - px) dz - dx (qz - pz),  (qy - py) dz - dy (qz - pz))       (permuted components, float64; q - p is exact)
+// -- a function of (edge, ray direction) alone, exactly negated when p and q swap; with the triangle's orientation
+// normalised (s = the sign of U + V + W) the two neighbours of a shared edge see  s e  and  -s e, and the owner is the one
+// whose  s e  lies in the half plane  ey > 0  or  (ey = 0 and ex > 0).  A hit through an edge of a closed surface is ONE
+// hit; where the surface folds over in the ray's view (a silhouette edge) both neighbours see the same vector: none or both,
+// the parity stays.  tr_tie_code: which functions are zero (bits 0-2: U, V, W) and the orientation (bit 3: negative), 0 = no
+// tie; tr_tie_own: does the triangle own every edge named in the code (U belongs to b -> c, V to c -> a, W to a -> b).
+TR_HD int tr_tie_code(const tr_woop& w, double det) {
+    const int z = ((w.U == 0.0) ? 1 : 0) | ((w.V == 0.0) ? 2 : 0) | ((w.W == 0.0) ? 4 : 0);
+    return z ? (z | (det < 0.0 ? 8 : 0)) : 0;
+}
+TR_HD bool tr_edge_own(double s, double dx, double dy, double dz, float px, float py, float pz, float qx, float qy, float qz) {
+    const double ux = (double)qx - (double)px, uy = (double)qy - (double)py, uz = (double)qz - (double)pz;
+    const double ex = s * fma(-dx, uz, ux * dz), ey = s * fma(-dy, uz, uy * dz);
+    return (ey > 0.0) | ((ey == 0.0) & (ex > 0.0));
+}
+// (x, y, z) already permuted
+TR_HD bool tr_tie_own_xyz(float dx, float dy, float dz, float ax, float ay, float az, float bx, float by, float bz,
+                          float cx, float cy, float cz, int code) {
+    const double s = (code & 8) ? -1.0 : 1.0;
+    bool ok = true;
+    if (code & 1) ok &= tr_edge_own(s, dx, dy, dz, bx, by, bz, cx, cy, cz);
+    if (code & 2) ok &= tr_edge_own(s, dx, dy, dz, cx, cy, cz, ax, ay, az);
+    if (code & 4) ok &= tr_edge_own(s, dx, dy, dz, ax, ay, az, bx, by, bz);
+    return ok;
+}
+// a function of its own (a call on the device): it runs on exact ties only, and inlined into the float64 part it would
+// double that function's registers -- which every kernel that calls it must keep free
+TR_HD_CALL bool tr_tie_own(float dx, float dy, float dz, float ax, float ay, float az, float bx, float by, float bz,
+                           float cx, float cy, float cz, int code) {
+    int kz = 0;
+    float m = fabsf(dx);
+    if (fabsf(dy) > m) { kz = 1; m = fabsf(dy); }
+    if (fabsf(dz) > m) kz = 2;
+    if (kz == 2) return tr_tie_own_xyz(dx, dy, dz, ax, ay, az, bx, by, bz, cx, cy, cz, code);
+    if (kz == 0) return tr_tie_own_xyz(dy, dz, dx, ay, az, ax, by, bz, bx, cy, cz, cx, code);
+    return tr_tie_own_xyz(dz, dx, dy, az, ax, ay, bz, bx, by, cz, cx, cy, code);
 }
 TR_HD float tr_woop_t(const tr_woop& w, double det) {
     return (float)(fma(w.W, w.Cz, fma(w.V, w.Bz, w.U * w.Az)) / (det * w.dz));
 }
 // The exact part as one function: true iff the ray hits the triangle within [0, 1e7]; t = the distance.
 // A REAL CALL on the device (TR_HD_CALL): it runs for < 1 % of the leaf tests and owns ~30 registers.
-TR_HD_CALL float tr_tri_exact_t(float ox, float oy, float oz, float dx, float dy, float dz, float ax, float ay, float az,
-                                float bx, float by, float bz, float cx, float cy, float cz) {
+struct tr_exact_res { float t; int tie; };      // tie != 0: the hit stands only if the triangle owns its zero edges (tr_tie_own)
+TR_HD_CALL tr_exact_res tr_tri_exact_t(float ox, float oy, float oz, float dx, float dy, float dz, float ax, float ay, float az,
+                                       float bx, float by, float bz, float cx, float cy, float cz) {
     tr_woop w;
     double d64;
     tr_woop64(ox, oy, oz, dx, dy, dz, ax, ay, az, bx, by, bz, cx, cy, cz, w);
-    if (!tr_woop_inside(w, d64)) return -1.0f;        // (no accepted distance is negative)
-    return tr_woop_t(w, d64);
+    tr_exact_res e;
+    e.tie = 0;
+    e.t = -1.0f;                                      // (no accepted distance is negative)
+    if (tr_woop_inside(w, d64)) {
+        e.t = tr_woop_t(w, d64);
+        e.tie = tr_tie_code(w, d64);
+    }
+    return e;
 }
 TR_HD bool tr_tri_exact(const tr_ray& r, float ax, float ay, float az, float bx, float by, float bz,
                         float cx, float cy, float cz, tr_hit& h) {
-    const float t = tr_tri_exact_t(r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, ax, ay, az, bx, by, bz, cx, cy, cz);
+    const tr_exact_res e = tr_tri_exact_t(r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, ax, ay, az, bx, by, bz, cx, cy, cz);
+    float t = e.t;
+    if (__builtin_expect(e.tie != 0, 0)) {
+        if (!tr_tie_own(r.dx, r.dy, r.dz, ax, ay, az, bx, by, bz, cx, cy, cz, e.tie)) t = -1.0f;
+    }
     h.t = t;
     return t >= TR_TMIN && t <= TR_TMAX;
 }
