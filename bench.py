@@ -841,7 +841,7 @@ def run_rank(args):
                                  "kernel_avg_ms = the mean interval of kernel_samples HIP event pairs spread over the timed region "
                                  "(kernel_event_interval_ms) minus what a pair reports with NOTHING between its records "
                                  "(empty_event_pair_ms, the median of 200 measured in this run): the rocprofv3 dispatch time of "
-                                 "the same command is in profiles/r06b_summary.md; compulsory_frac counts the 50 B/ray only; the path is "
+                                 "the same command is in profiles/r06c_summary.md; compulsory_frac counts the 50 B/ray only; the path is "
                                  "cache-latency / instruction-issue bound, not HBM-bandwidth bound (DESIGN.md 5); "
                                  "frac_on_exact_node_bytes = the same time against round 1's numerator (64-byte nodes), "
                                  "for comparison across rounds only"},
