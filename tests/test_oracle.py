@@ -121,6 +121,39 @@ def test_cube_boundary_rays_see_a_half_open_square():
         assert set(np.unique(cnt)) == {0, 2} and np.array_equal(cnt > 0, hit)
 
 
+def test_rays_through_the_vertices_of_a_grid_mesh_count_once():
+    """Exact ties as the ordinary case: a height field on an integer grid under vertical rays through EVERY vertex, edge
+    midpoint and cell centre.  One owner per edge (tr_math.h "exact ties"): every ray over the patch's interior crosses the
+    surface exactly once -- the first form of contract 3 counted 2 on the edges and up to 6 at the vertices --, the open
+    patch is half-open at its boundary (one boundary row and one boundary column belong to it, like a rasterised quad), and
+    rays aimed in float32 exactly at vertices and edge points of a closed mesh from inside count exactly once."""
+    g = np.arange(-8, 9, dtype=np.float32)
+    X, Y = np.meshgrid(g, g, indexing="ij")
+    Z = ((X * 7 + Y * 3) % 5).astype(np.float32) * 0.25
+    v = np.stack([X, Y, Z], -1).reshape(-1, 3)
+    idx = np.arange(17 * 17).reshape(17, 17)
+    a, b, c, dd = idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel(), idx[:-1, 1:].ravel()
+    f = np.concatenate([np.stack([a, b, c], 1), np.stack([a, c, dd], 1)]).astype(np.int32)
+    h = np.arange(-8, 8.01, 0.5, dtype=np.float32)
+    gx, gy = np.meshgrid(h, h, indexing="ij")
+    o = np.stack([gx, gy, np.full_like(gx, 10)], -1).reshape(-1, 3)
+    d = np.tile(np.array([[0, 0, -1]], np.float32), (len(o), 1))
+    for mode in (0, 1):
+        cnt = OracleIntersector(v, f, mode).intersects_count(o, d).reshape(gx.shape)
+        assert set(np.unique(cnt)) == {0, 1} and (cnt[1:-1, 1:-1] == 1).all()
+        for edge_lo, edge_hi in ((cnt[0, 1:-1], cnt[-1, 1:-1]), (cnt[1:-1, 0], cnt[1:-1, -1])):
+            assert {int(edge_lo.min()), int(edge_lo.max()), int(edge_hi.min()), int(edge_hi.max())} == {0, 1} and edge_lo.min() == edge_lo.max() != edge_hi.max()
+        assert int(cnt[0, 0] + cnt[0, -1] + cnt[-1, 0] + cnt[-1, -1]) == 1
+    v, f = W.icosphere(3)
+    v = W.displaced(v, seed=3, amplitude=0.08)
+    R = OracleIntersector(v, f, 1)
+    rng = np.random.default_rng(5)
+    eye = (rng.normal(size=(60000, 3)) * 0.05).astype(np.float32)
+    e = rng.integers(0, len(f), 30000)
+    targets = np.concatenate([v[rng.integers(0, len(v), 30000)], (v[f[e, 0]] + np.float32(0.5) * (v[f[e, 1]] - v[f[e, 0]])).astype(np.float32)])
+    assert (R.intersects_count(eye, (targets - eye).astype(np.float32)) == 1).all()
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2])
 def test_brute_equals_bvh_random(seed):
     v, f = W.random_soup(600, seed=seed)
