@@ -32,7 +32,7 @@ def test_no_query_kernel_of_the_shipped_library_spills_inside_its_trips():
     # (<Q, COMPACT, BS, DEEP>: five waves per SIMD since round 6 -- 96 registers; four for the instantiations with 64-bit addressing)
     assert stream and all(k["vgpr"] <= (96 if ", true, 128," in k["name"] else 128) and k["vgpr_spill"] <= 8 for k in stream), [(k["name"], k["vgpr"], k["vgpr_spill"]) for k in stream]
     assert wide and all(k["vgpr"] <= 96 and k["vgpr_spill"] <= 16 for k in wide), [(k["name"], k["vgpr"], k["vgpr_spill"]) for k in wide]
-    bad = [(k["name"], k["vgpr"], k["vgpr_spill"]) for k in direct if k["vgpr_spill"] > 8]
+    bad = [(k["name"], k["vgpr"], k["vgpr_spill"]) for k in direct if k["vgpr_spill"] > (12 if "count_steal" in k["name"] else 8)]
     assert not bad, bad
     # <Q, STATS, COMPACT, MODE, DEEP, QN>: the instantiations for hierarchies of more than 32 levels (64-bit trail words) are
     # the ones that died with a memory access fault when KERNEL-LIFETIME values were forced into scratch (stored in the
@@ -41,7 +41,7 @@ def test_no_query_kernel_of_the_shipped_library_spills_inside_its_trips():
     # kernel sits within a few dozen instructions of an s_swappc.
     import re
     deep = [k for k in direct if re.search(r"k_query_direct<\d, \w+, \w+, \d, true, \w+>", k["name"]) or re.search(r"k_query_direct_sort<\d, true", k["name"])
-            or re.search(r"k_query_count_steal(_sort)?<(\w+, )?true>", k["name"])]
+            or re.search(r"k_query_count_steal<\w+, true>", k["name"]) or re.search(r"k_query_count_steal_sort<true", k["name"])]      # (<COMPACT, DEEP> / _sort<DEEP, COMPACT>)
     assert len(deep) >= 10, [k["name"] for k in deep]
     checked = 0
     for want in ("k_query_direct<", "k_query_direct_sort<", "k_query_count_steal"):
@@ -54,7 +54,8 @@ def test_no_query_kernel_of_the_shipped_library_spills_inside_its_trips():
             ins = isa_loops.instructions(lines)
             calls = [i for i, (_, t) in enumerate(ins) if t.startswith("s_swappc_b64")]
             far = [t for i, (_, t) in enumerate(ins) if t.startswith("scratch_") and not any(abs(i - c) <= 64 for c in calls)]
-            assert len(far) <= (0 if wide_word else 8), (name, far)
+            # (the 32-bit count launches run at seven waves per SIMD -- 72 registers, 8-10 kernel-lifetime spills: a dozen scratch instructions)
+            assert len(far) <= (0 if wide_word else (16 if "count_steal" in name else 8)), (name, far)
     assert checked >= 40, checked
     # (round 6, tr_drain_exact<COLD>: what the float64 call clobbers is saved AROUND the call, on the 0.6 % of leaf tests
     # that reach it -- those stores / loads sit within a few dozen instructions of the s_swappc and are not "in the trips")
