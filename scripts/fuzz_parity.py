@@ -11,7 +11,7 @@ from oracle.oracle import OracleIntersector
 from triro.ray.ray_optix import RayMeshIntersector
 from triro.backend import ops as hops
 
-ap = argparse.ArgumentParser(); ap.add_argument("--iters", type=int, default=60); ap.add_argument("--seed", type=int, default=1)
+ap = argparse.ArgumentParser(); ap.add_argument("--iters", type=int, default=60); ap.add_argument("--seed", type=int, default=1); ap.add_argument("--kind", type=int, default=-1, help="force one mesh family (5 = grid meshes with lattice rays: exact ties)")
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
 dev = torch.device("cuda:0")
@@ -23,17 +23,50 @@ DEFAULTS = {"steal": 1, "tile": 1, "block_size": 128, "adaptive": 1, "xcd_chunk"
             "wide": 2, "wide_stack": 12, "wide_direct": 1, "expand4": 1, "expand_cus": 0, "expand_tiles": 1, "sort_inline": 1}
 bad = 0
 for it in range(a.iters):
-    kind = rng.integers(0, 5)
-    if kind == 0: v, f = W.icosphere(int(rng.integers(1, 6)))
+    kind = rng.integers(0, 6)
+    if a.kind >= 0: kind = a.kind
+    grid = None
+    if kind == 5:
+        # round 6: EXACT TIES as the ordinary case -- a height field (or a stack of them) on an integer grid, rays on a lattice
+        # that run through its vertices, edges and cell diagonals (one owner per edge: tr_math.h "exact ties")
+        gn = int(rng.integers(3, 40)); layers = int(rng.integers(1, 4))
+        g = np.arange(gn, dtype=np.float32)
+        X, Y = np.meshgrid(g, g, indexing="ij")
+        vs, fs = [], []
+        for L in range(layers):
+            Z = ((X * int(rng.integers(1, 9)) + Y * int(rng.integers(1, 9))) % int(rng.integers(1, 6))).astype(np.float32) * np.float32(rng.choice([0.0, 0.25, 1.0])) + 3 * L
+            idx = np.arange(gn * gn).reshape(gn, gn) + L * gn * gn
+            qa, qb, qc, qd = idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel(), idx[:-1, 1:].ravel()
+            vs.append(np.stack([X, Y, Z], -1).reshape(-1, 3)); fs.append(np.concatenate([np.stack([qa, qb, qc], 1), np.stack([qa, qc, qd], 1)]))
+        v, f = np.concatenate(vs).astype(np.float32), np.concatenate(fs).astype(np.int32)
+        grid = gn
+    elif kind == 0: v, f = W.icosphere(int(rng.integers(1, 6)))
     elif kind == 1: v, f = W.random_soup(int(rng.integers(2, 6000)), seed=int(rng.integers(1 << 30)), size=float(rng.uniform(0.02, 0.6)))
     elif kind == 2: v, f = W.nested_shells(int(rng.integers(2, 5)))
     elif kind == 3:
         v, f = W.icosphere(int(rng.integers(3, 6))); v = W.displaced(v, seed=int(rng.integers(1000)), amplitude=float(rng.uniform(0.01, 0.3)))
     else: v, f = W.deep_tree_mesh(int(rng.integers(100, 3000)))
-    v = (v * np.float32(rng.uniform(0.1, 20.0)) + rng.uniform(-3, 3, 3).astype(np.float32)).astype(np.float32)
+    if grid is None:
+        v = (v * np.float32(rng.uniform(0.1, 20.0)) + rng.uniform(-3, 3, 3).astype(np.float32)).astype(np.float32)
+    else:
+        v = (v * np.float32(rng.choice([0.5, 1.0, 2.0])) + rng.integers(-4, 5, 3).astype(np.float32)).astype(np.float32)      # (stays on a binary lattice)
     lo, hi = v.min(0), v.max(0); ext = np.maximum(hi - lo, 1e-3)
     rk = rng.integers(0, 4)
-    if rk == 3:
+    if grid is not None and rng.random() < 0.8:
+        # lattice rays: origins on a half-step lattice over (and a little beyond) the patch, directions along an axis, a face
+        # diagonal or a small-integer vector -- through vertices, along edges, across cell diagonals
+        step = float(v[1, 1] - v[0, 1]) if len(v) > 1 and v[1, 1] != v[0, 1] else 1.0
+        h = np.arange(lo[0] - step, hi[0] + step + 1e-3, step / 2, dtype=np.float32)
+        k = np.arange(lo[1] - step, hi[1] + step + 1e-3, step / 2, dtype=np.float32)
+        gx, gy = np.meshgrid(h, k, indexing="ij")
+        dirs = np.array([[0, 0, -1], [0, 0, 1], [1, 0, -1], [0, 1, -1], [1, 1, -2], [1, -1, -1], [2, 1, -4], [1, 0, 0], [0, 1, 0], [1, 1, 0]], np.float32)
+        dsel = dirs[rng.integers(0, len(dirs), gx.size)] * np.float32(rng.choice([1.0, 0.5, 3.0]))
+        up = np.where(dsel[:, 2] > 0, lo[2] - 2 * step, np.where(dsel[:, 2] < 0, hi[2] + 2 * step, lo[2] + step * rng.integers(0, 4, gx.size) / 4)).astype(np.float32)
+        o = np.stack([gx.ravel(), gy.ravel(), up], -1).astype(np.float32)
+        flat = dsel[:, 2] == 0
+        o[flat, 0] = lo[0] - 2 * step
+        d = dsel.astype(np.float32)
+    elif rk == 3:
         # rays that START ON the mesh (vertices, edge midpoints, points inside a face): t_key = +-0.0
         # ties, the family that exposed the -0.0 key of the stealing merge
         n = int(rng.integers(64, 20000)); fi = rng.integers(0, len(f), n); tv = v[f[fi]]
