@@ -123,6 +123,32 @@ def _ladder_worker(rank, world, port, q):
         except RuntimeError as exc:
             ok &= "no exchange mode passed" in str(exc)
 
+        # 4b. round 6: the NATIVE rung (one C call per step, libtriro_rccl.so) on top of the ladder.  Without a GPU tracer it is
+        #     not available: starting there the preflight says so and lands on "slot" -- and a rank that BELIEVES it has the rung
+        #     while its peer has not (the library built on one node only) must not walk into ncclCommInitRank alone: availability
+        #     is agreed on like a verdict, both ranks skip the rung
+        V = ShardedRayMeshIntersector(CpuLocalSlots(v, f), ctrl_group=ctrl, dst_share=0.5)
+        V.set_exchange_mode("native")
+        ok &= V.exchange_mode == "slot"                     # (degrades by itself where the rung does not exist)
+        pf = V.preflight(o, d, dst=0)
+        ok &= pf["exchange_mode_used"] == "slot" and [(a["mode"], a["ok"]) for a in pf["attempts"]] == [("native", False), ("slot", True)]
+        ok &= "not available" in pf["attempts"][0]["reason"]
+
+        class HalfNative(ShardedRayMeshIntersector):
+            def native_available(self):
+                return self.rank == 0 and not getattr(self, "_native_dead", False)
+
+            def closest_of_shard_native(self, *a_, **k_):
+                raise AssertionError("the native rung must not run when a peer does not have it")
+        Hn = HalfNative(CpuLocalSlots(v, f), ctrl_group=ctrl, dst_share=0.5)
+        Hn.set_exchange_mode("native")
+        pf = Hn.preflight(o, d, dst=0)
+        ok &= pf["exchange_mode_used"] == "slot" and not pf["attempts"][0]["ok"] and pf["attempts"][0]["mode"] == "native"
+        ok &= ("another rank" in pf["attempts"][0]["reason"]) == (rank == 0)
+        g = Hn.intersects_closest(o, d, dst=0)
+        if rank == 0:
+            ok &= all(torch.equal(a, e) for a, e in zip(g, exp))
+
         # 5. the handshake is entered by every rank whatever its own capability: rank 1 has no slot form
         class Hashed(CpuLocalSlots):
             def __init__(self, v_, f_, h, slots_ok=True):
