@@ -149,6 +149,29 @@ def _ladder_worker(rank, world, port, q):
         if rank == 0:
             ok &= all(torch.equal(a, e) for a, e in zip(g, exp))
 
+        # 4c. ... and a native rung that does not answer in time: the preflight's watchdog fires (it would abort the rung's own
+        #     communicator), the rung is dropped on every rank -- even though the late answer is right -- and "slot" takes over
+        import time as _time
+
+        class SlowNative(ShardedRayMeshIntersector):
+            native_deadline_s = 0.5
+
+            def native_available(self):
+                return not getattr(self, "_native_dead", False)
+
+            def closest_of_shard_native(self, o_, d_, n_total, **k_):
+                if self.rank == 0:
+                    _time.sleep(1.5)
+                k_.pop("flags", None)
+                return self.closest_of_shard_async(o_, d_, n_total, records="slot", **k_)
+        Sn = SlowNative(CpuLocalSlots(v, f), ctrl_group=ctrl, dst_share=0.5)
+        Sn.set_exchange_mode("native")
+        pf = Sn.preflight(o, d, dst=0)
+        ok &= pf["exchange_mode_used"] == "slot" and pf["attempts"][0]["mode"] == "native" and not pf["attempts"][0]["ok"]
+        # (the peer waits for the slow destination inside the exchange: its own watchdog fires as well, or it is told)
+        ok &= ("no answer within" in pf["attempts"][0]["reason"] or "another rank" in pf["attempts"][0]["reason"]) and not Sn.native_available()
+        ok &= (rank != 0) or "no answer within" in pf["attempts"][0]["reason"]
+
         # 5. the handshake is entered by every rank whatever its own capability: rank 1 has no slot form
         class Hashed(CpuLocalSlots):
             def __init__(self, v_, f_, h, slots_ok=True):
