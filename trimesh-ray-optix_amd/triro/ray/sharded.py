@@ -365,8 +365,13 @@ class ShardedRayMeshIntersector:
                 if mode == "native":
                     self._native_dead = True
                 continue
-            dog = self._native_watchdog() if mode == "native" else None
+            dog = None
             try:
+                if mode == "native":
+                    # the communicator first, under its own (longer) deadline: the watchdog then times the STEP, not RCCL's set-up
+                    if self.world > 1 and self.native_available() and hasattr(self.local, "as_wrapper"):
+                        self._native_comm()
+                    dog = self._native_watchdog()
                 if mode in os.environ.get("TRIRO_PREFLIGHT_FAIL", "").split(","):
                     # test hook: make a rung fail on purpose (every rank alike), e.g. to rehearse the fallbacks on real hardware
                     raise RuntimeError(f"injected by TRIRO_PREFLIGHT_FAIL={os.environ['TRIRO_PREFLIGHT_FAIL']}")
@@ -933,17 +938,18 @@ class ShardedRayMeshIntersector:
                 box["rc"], box["err"] = -1, repr(exc)
         th = threading.Thread(target=make, daemon=True, name="triro-native-comm")
         th.start()
-        th.join(self.native_deadline_s)
+        th.join(self.native_init_deadline_s)
         if th.is_alive():
             self._native_dead = True
-            raise RuntimeError(f"ncclCommInitRank did not return within {self.native_deadline_s:.0f} s")
+            raise RuntimeError(f"ncclCommInitRank did not return within {self.native_init_deadline_s:.0f} s")
         if box.get("rc", -1) != 0:
             self._native_dead = True
             raise RuntimeError("libtriro_rccl: " + box.get("err", "?"))
         self._ncomm = h
         return h
 
-    native_deadline_s = float(os.environ.get("TRIRO_NATIVE_DEADLINE_S", "45"))
+    native_deadline_s = float(os.environ.get("TRIRO_NATIVE_DEADLINE_S", "45"))             # a preflighted step that nobody answers
+    native_init_deadline_s = float(os.environ.get("TRIRO_NATIVE_INIT_DEADLINE_S", "180"))   # ncclCommInitRank (slow is not hung)
 
     def _native_drop(self):
         """gives the native rung up for this object: aborts the communicator (ncclCommAbort: ends transfers that nobody
